@@ -1,0 +1,117 @@
+"""ctypes binding of libepik_amd.so -- the C-ABI declared in include/epik_amd.h.
+
+This is the same stub a maintainer of another host language would write (see
+INTEGRATION.md).  The library is built in-tree by `__graft_entry__.build()` /
+`make -C epik_amd/csrc`.  Loading fails loudly when it is missing: there is no
+Python or CPU fallback for the placement path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libepik_amd.so")
+
+ABI_VERSION = 1
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+
+#: numpy mirror of `epik_amd_placement` {branch, score, lwr} (16 bytes)
+PLACEMENT = np.dtype([("branch", np.uint32), ("score", np.float32), ("lwr", np.float64)])
+#: numpy mirror of `epik_amd_pkdb_value` / `i2l::pkdb_value` (8 bytes)
+PKDB_VALUE = np.dtype([("branch", np.uint32), ("score", np.float32)])
+
+#: every symbol include/epik_amd.h declares
+EXPORTS = (
+    "epik_amd_device_count",
+    "epik_amd_last_error",
+    "epik_amd_placer_create",
+    "epik_amd_placer_destroy",
+    "epik_amd_placer_place",
+    "epik_amd_placer_place_device",
+    "epik_amd_placer_algorithmic_bytes",
+    "epik_amd_placer_launch_info",
+    "epik_amd_placer_set_timing",
+    "epik_amd_placer_last_kernel_ms",
+)
+
+
+class PlacerDesc(ctypes.Structure):
+    """`epik_amd_placer_desc`."""
+
+    _fields_ = [
+        ("abi_version", ctypes.c_uint32),
+        ("kmer_size", ctypes.c_uint32),
+        ("alphabet_size", ctypes.c_uint32),
+        ("num_branches", ctypes.c_uint32),
+        ("keep_at_most", ctypes.c_uint32),
+        ("offset_bits", ctypes.c_uint32),
+        ("keep_factor", ctypes.c_double),
+        ("threshold", ctypes.c_float),
+        ("log_threshold", ctypes.c_float),
+        ("num_keys", ctypes.c_uint64),
+        ("num_entries", ctypes.c_uint64),
+        ("offsets", ctypes.c_void_p),
+        ("values", ctypes.c_void_p),
+        ("char_class", ctypes.c_void_p),
+        ("device", ctypes.c_int32),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
+class EpikAmdError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libepik_amd error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads libepik_amd.so (once) and declares the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C epik_amd/csrc` (hipcc, gfx950).  epik_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+    lib.epik_amd_device_count.restype = i32
+    lib.epik_amd_device_count.argtypes = []
+    lib.epik_amd_last_error.restype = ctypes.c_char_p
+    lib.epik_amd_last_error.argtypes = []
+    lib.epik_amd_placer_create.restype = i32
+    lib.epik_amd_placer_create.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.POINTER(vp)]
+    lib.epik_amd_placer_destroy.restype = None
+    lib.epik_amd_placer_destroy.argtypes = [vp]
+    lib.epik_amd_placer_place.restype = i32
+    lib.epik_amd_placer_place.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    lib.epik_amd_placer_place_device.restype = i32
+    lib.epik_amd_placer_place_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
+    lib.epik_amd_placer_algorithmic_bytes.restype = i32
+    lib.epik_amd_placer_algorithmic_bytes.argtypes = [vp, vp, vp, u64, vp, vp, ctypes.POINTER(u64)]
+    lib.epik_amd_placer_launch_info.restype = i32
+    lib.epik_amd_placer_launch_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32),
+                                                ctypes.POINTER(ctypes.c_uint32),
+                                                ctypes.POINTER(ctypes.c_uint32)]
+    lib.epik_amd_placer_set_timing.restype = i32
+    lib.epik_amd_placer_set_timing.argtypes = [vp, i32]
+    lib.epik_amd_placer_last_kernel_ms.restype = i32
+    lib.epik_amd_placer_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise EpikAmdError(code, (load().epik_amd_last_error() or b"").decode(errors="replace"))
+
+
+def device_count() -> int:
+    return int(load().epik_amd_device_count())

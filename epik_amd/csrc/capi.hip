@@ -1,0 +1,378 @@
+// capi.hip -- the C-ABI layer of libepik_amd.so (declared in include/epik_amd.h).
+//
+// Host side of the drop-in boundary: replaces the constructor and the OpenMP loop
+// of epik::placer (reference epik/src/epik/place.cpp:83-126, :201-275).  HIP
+// runtime only -- no torch, no C++ types in any signature, no exceptions out.
+// There is deliberately no CPU path: without a HIP device every compute entry
+// point fails with EPIK_AMD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "epik_amd.h"
+#include "place_kernel.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    return fail(EPIK_AMD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        const hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);    \
+    } while (0)
+
+constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // gfx950: 160 KiB per CU
+
+}  // namespace
+
+struct epik_amd_placer {
+    int device = 0;
+    bool offsets64 = false;
+    bool lds_atomic = true;
+    bool timing = false;
+    void *d_offsets = nullptr;
+    uint2 *d_values = nullptr;
+    uint32_t *d_char_class = nullptr;
+    epik_amd::PlaceParams params{};  // batch fields are filled per call
+    uint64_t num_keys = 0;
+    uint64_t num_entries = 0;
+    // launch geometry
+    uint32_t waves_per_block = 4;
+    uint32_t lds_block_bytes = 0;
+    uint32_t max_blocks = 0;
+    uint32_t last_blocks = 0;
+    // staging buffers for the host-pointer entry point (grown on demand)
+    uint8_t *d_seqs = nullptr;
+    size_t d_seqs_cap = 0;
+    uint64_t *d_seq_offsets = nullptr;
+    epik_amd_placement *d_rows = nullptr;
+    uint32_t *d_n_rows = nullptr;
+    uint32_t *d_counts = nullptr;
+    size_t d_reads_cap = 0;
+    unsigned long long *d_total = nullptr;
+    hipStream_t stream = nullptr;  // owned, for the synchronous entry point
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_recorded = false;
+};
+
+extern "C" {
+
+int epik_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *epik_amd_last_error(void) { return g_last_error.c_str(); }
+
+void epik_amd_placer_destroy(epik_amd_placer *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    (void)hipFree(p->d_offsets);
+    (void)hipFree(p->d_values);
+    (void)hipFree(p->d_char_class);
+    (void)hipFree(p->d_seqs);
+    (void)hipFree(p->d_seq_offsets);
+    (void)hipFree(p->d_rows);
+    (void)hipFree(p->d_n_rows);
+    (void)hipFree(p->d_counts);
+    (void)hipFree(p->d_total);
+    if (p->ev_start) (void)hipEventDestroy(p->ev_start);
+    if (p->ev_stop) (void)hipEventDestroy(p->ev_stop);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
+{
+    if (!d || !out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (d->abi_version != EPIK_AMD_ABI_VERSION)
+        return fail(EPIK_AMD_ERR_INVALID, "abi_version mismatch");
+    if (d->kmer_size < 1 || d->kmer_size > 32)
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "kmer_size must be in [1, 32]");
+    if (d->alphabet_size < 2 || d->alphabet_size > 32)
+        return fail(EPIK_AMD_ERR_INVALID, "alphabet_size must be in [2, 32]");
+    if (d->num_branches == 0 || d->num_branches >= 0x7fffffffu)
+        return fail(EPIK_AMD_ERR_INVALID, "num_branches out of range");
+    if (d->keep_at_most == 0 || d->keep_at_most > 64)
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "keep_at_most must be in [1, 64]");
+    if (d->offset_bits != 32 && d->offset_bits != 64)
+        return fail(EPIK_AMD_ERR_INVALID, "offset_bits must be 32 or 64");
+    if (!d->offsets || !d->char_class || (!d->values && d->num_entries))
+        return fail(EPIK_AMD_ERR_INVALID, "null database pointer");
+    // dense key space: num_keys == sigma^k, and codes are 32-bit on the device
+    {
+        uint64_t nk = 1;
+        for (uint32_t i = 0; i < d->kmer_size; ++i) {
+            nk *= d->alphabet_size;
+            if (nk > 0xffffffffull) return fail(EPIK_AMD_ERR_UNSUPPORTED, "alphabet_size^kmer_size exceeds 2^32 keys");
+        }
+        if (nk != d->num_keys) return fail(EPIK_AMD_ERR_INVALID, "num_keys != alphabet_size^kmer_size");
+    }
+    // offsets must be monotone and end at num_entries (cheap checks of both ends)
+    {
+        uint64_t first, last;
+        if (d->offset_bits == 32) {
+            const uint32_t *o = static_cast<const uint32_t *>(d->offsets);
+            first = o[0];
+            last = o[d->num_keys];
+            if (d->num_entries > 0xffffffffull) return fail(EPIK_AMD_ERR_INVALID, "num_entries needs 64-bit offsets");
+        } else {
+            const uint64_t *o = static_cast<const uint64_t *>(d->offsets);
+            first = o[0];
+            last = o[d->num_keys];
+        }
+        if (first != 0 || last != d->num_entries)
+            return fail(EPIK_AMD_ERR_INVALID, "offsets[0] != 0 or offsets[num_keys] != num_entries");
+    }
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(EPIK_AMD_ERR_NO_DEVICE, "no HIP device available (libepik_amd has no CPU fallback)");
+    if (d->device < 0 || d->device >= n_dev) return fail(EPIK_AMD_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(d->device));
+
+    epik_amd_placer *p = new (std::nothrow) epik_amd_placer();
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
+    p->device = d->device;
+    p->offsets64 = d->offset_bits == 64;
+    p->num_keys = d->num_keys;
+    p->num_entries = d->num_entries;
+    const char *env = std::getenv("EPIK_AMD_LDS_ATOMIC");
+    p->lds_atomic = !(env && env[0] == '0');
+
+    // every posting's branch must index the LDS score vector
+    for (uint64_t i = 0; i < d->num_entries; ++i) {
+        if (d->values[i].branch >= d->num_branches) {
+            delete p;
+            return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
+        }
+    }
+
+#define CREATE_TRY(expr)                                  \
+    do {                                                  \
+        const hipError_t e_ = (expr);                     \
+        if (e_ != hipSuccess) {                           \
+            epik_amd_placer_destroy(p);                   \
+            return fail_hip(e_, #expr);                   \
+        }                                                 \
+    } while (0)
+
+    const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
+    const size_t val_bytes = (size_t)d->num_entries * sizeof(epik_amd_pkdb_value);
+    CREATE_TRY(hipMalloc(&p->d_offsets, off_bytes));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_values), val_bytes ? val_bytes : 8));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_char_class), 256 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_total), sizeof(unsigned long long)));
+    CREATE_TRY(hipMemcpy(p->d_offsets, d->offsets, off_bytes, hipMemcpyHostToDevice));
+    if (val_bytes) CREATE_TRY(hipMemcpy(p->d_values, d->values, val_bytes, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(p->d_char_class, d->char_class, 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&p->ev_start));
+    CREATE_TRY(hipEventCreate(&p->ev_stop));
+
+    epik_amd::PlaceParams &pp = p->params;
+    pp.offsets = p->d_offsets;
+    pp.values = p->d_values;
+    pp.char_class = p->d_char_class;
+    pp.kmer_size = d->kmer_size;
+    pp.alphabet_size = d->alphabet_size;
+    pp.num_branches = d->num_branches;
+    pp.keep_at_most = d->keep_at_most;
+    pp.keep_factor = d->keep_factor;
+    pp.threshold = d->threshold;
+    pp.log_threshold = d->log_threshold;
+    pp.log10_keep_factor_margin =
+        d->keep_factor > 0.0 ? (float)(std::log10(d->keep_factor) - 1e-3) : -INFINITY;
+    pp.n_pad = (d->num_branches + 63u) & ~63u;
+    pp.lds_wave_bytes = pp.n_pad * 8u;
+
+    // geometry: as many waves per workgroup (<= 4) as fit the 160 KiB of LDS
+    if (pp.lds_wave_bytes > kMaxLdsPerBlock) {
+        epik_amd_placer_destroy(p);
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector (max 20480)");
+    }
+    p->waves_per_block = 4;
+    while (p->waves_per_block > 1 && p->waves_per_block * pp.lds_wave_bytes > kMaxLdsPerBlock / 2)
+        p->waves_per_block >>= 1;
+    p->lds_block_bytes = p->waves_per_block * pp.lds_wave_bytes;
+    CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->lds_block_bytes));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, d->device));
+    // persistent-style grid: exactly the workgroups that are resident at once
+    // (registers, LDS and the 32-waves/CU cap decide), each striding over the reads
+    int per_cu = 0;
+    CREATE_TRY(epik_amd::place_reads_occupancy(p->offsets64, p->lds_atomic, (int)(p->waves_per_block * 64u),
+                                               p->lds_block_bytes, &per_cu));
+    if (per_cu < 1) per_cu = 1;
+    p->max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+#undef CREATE_TRY
+
+    *out = p;
+    return EPIK_AMD_OK;
+}
+
+static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets, uint64_t n,
+                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream)
+{
+    if (n == 0) return EPIK_AMD_OK;
+    epik_amd::PlaceParams pp = p->params;
+    pp.seqs = static_cast<const uint8_t *>(d_seqs);
+    pp.seq_offsets = static_cast<const uint64_t *>(d_seq_offsets);
+    pp.n_reads = n;
+    pp.rows = static_cast<epik_amd_placement *>(d_rows);
+    pp.n_rows = static_cast<uint32_t *>(d_n_rows);
+    pp.kmer_counts = static_cast<uint32_t *>(d_counts);
+    uint64_t blocks = (n + p->waves_per_block - 1) / p->waves_per_block;
+    if (blocks > p->max_blocks) blocks = p->max_blocks;
+    p->last_blocks = (uint32_t)blocks;
+    if (p->timing) HIP_TRY(hipEventRecord(p->ev_start, stream));
+    HIP_TRY(epik_amd::launch_place_reads(pp, p->offsets64, p->lds_atomic, dim3((unsigned)blocks),
+                                         dim3(p->waves_per_block * 64u), p->lds_block_bytes, stream));
+    if (p->timing) {
+        HIP_TRY(hipEventRecord(p->ev_stop, stream));
+        p->ev_recorded = true;
+    }
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
+                                 uint64_t n, void *d_rows, void *d_n_rows, void *d_kmer_counts,
+                                 void *stream)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (n && (!d_seqs || !d_seq_offsets || !d_rows || !d_n_rows))
+        return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    return launch(p, d_seqs, d_seq_offsets, n, d_rows, d_n_rows, d_kmer_counts,
+                  static_cast<hipStream_t>(stream));
+}
+
+int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *seq_offsets,
+                          uint64_t n, epik_amd_placement *rows, uint32_t *n_rows,
+                          uint32_t *kmer_counts)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (n == 0) return EPIK_AMD_OK;
+    if (!seqs || !seq_offsets || !rows || !n_rows) return fail(EPIK_AMD_ERR_INVALID, "null host buffer");
+    if (seq_offsets[0] != 0) return fail(EPIK_AMD_ERR_INVALID, "seq_offsets[0] must be 0");
+    for (uint64_t i = 0; i < n; ++i)
+        if (seq_offsets[i + 1] < seq_offsets[i]) return fail(EPIK_AMD_ERR_INVALID, "seq_offsets not monotone");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t seq_bytes = (size_t)seq_offsets[n];
+    if (seq_bytes + 64 > p->d_seqs_cap) {
+        (void)hipFree(p->d_seqs);
+        p->d_seqs = nullptr;
+        p->d_seqs_cap = 0;
+        const size_t cap = seq_bytes + seq_bytes / 4 + 4096;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_seqs), cap));
+        p->d_seqs_cap = cap;
+    }
+    if (n > p->d_reads_cap) {
+        (void)hipFree(p->d_seq_offsets);
+        (void)hipFree(p->d_rows);
+        (void)hipFree(p->d_n_rows);
+        (void)hipFree(p->d_counts);
+        p->d_seq_offsets = nullptr;
+        p->d_rows = nullptr;
+        p->d_n_rows = nullptr;
+        p->d_counts = nullptr;
+        p->d_reads_cap = 0;
+        const size_t cap = (size_t)n + (size_t)n / 4 + 64;
+        const size_t keep = p->params.keep_at_most;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_seq_offsets), (cap + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_rows), cap * keep * sizeof(epik_amd_placement)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_n_rows), cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_counts), cap * keep * sizeof(uint32_t)));
+        p->d_reads_cap = cap;
+    }
+    const size_t keep = p->params.keep_at_most;
+    hipStream_t s = p->stream;
+    if (seq_bytes) HIP_TRY(hipMemcpyAsync(p->d_seqs, seqs, seq_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p->d_seq_offsets, seq_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    // rows beyond n_rows[i] are never written by the kernel: give them a defined value
+    HIP_TRY(hipMemsetAsync(p->d_rows, 0, n * keep * sizeof(epik_amd_placement), s));
+    HIP_TRY(hipMemsetAsync(p->d_counts, 0, n * keep * sizeof(uint32_t), s));
+    const int rc = launch(p, p->d_seqs, p->d_seq_offsets, n, p->d_rows, p->d_n_rows, p->d_counts, s);
+    if (rc != EPIK_AMD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rows, p->d_rows, n * keep * sizeof(epik_amd_placement), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(n_rows, p->d_n_rows, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (kmer_counts)
+        HIP_TRY(hipMemcpyAsync(kmer_counts, p->d_counts, n * keep * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
+                                      const void *d_seq_offsets, uint64_t n, const void *d_n_rows,
+                                      void *stream, uint64_t *bytes_out)
+{
+    if (!p || !bytes_out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *bytes_out = 0;
+    if (n == 0) return EPIK_AMD_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    epik_amd::PlaceParams pp = p->params;
+    pp.seqs = static_cast<const uint8_t *>(d_seqs);
+    pp.seq_offsets = static_cast<const uint64_t *>(d_seq_offsets);
+    pp.n_reads = n;
+    pp.n_rows = const_cast<uint32_t *>(static_cast<const uint32_t *>(d_n_rows));
+    HIP_TRY(hipMemsetAsync(p->d_total, 0, sizeof(unsigned long long), s));
+    HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->offsets64, p->d_total, s));
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, p->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *bytes_out = total;
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,
+                                uint32_t *blocks, uint32_t *lds_bytes)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (waves_per_block) *waves_per_block = p->waves_per_block;
+    if (blocks) *blocks = p->last_blocks ? p->last_blocks : p->max_blocks;
+    if (lds_bytes) *lds_bytes = p->lds_block_bytes;
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_set_timing(epik_amd_placer *p, int enabled)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    p->timing = enabled != 0;
+    p->ev_recorded = false;
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_last_kernel_ms(epik_amd_placer *p, float *ms_out)
+{
+    if (!p || !ms_out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *ms_out = -1.0f;
+    if (!p->ev_recorded) return EPIK_AMD_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, p->ev_start, p->ev_stop));
+    return EPIK_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// place_kernel.h -- launch interface between the C-ABI layer (capi.hip) and the
+// device kernels (place_kernel.hip).  Internal; the public boundary is include/epik_amd.h.
+#ifndef EPIK_AMD_PLACE_KERNEL_H
+#define EPIK_AMD_PLACE_KERNEL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "epik_amd.h"
+
+namespace epik_amd {
+
+// Kernel arguments: the database in HBM (CSR-like: code -> offsets -> postings),
+// the placer constants of place.cpp:83-96, and one batch of reads.
+struct PlaceParams {
+    const void *offsets;         // OffT[num_keys + 1]
+    const uint2 *values;         // {branch, float bits of log10 score}[num_entries]
+    const uint32_t *char_class;  // [256]
+    const uint8_t *seqs;
+    const uint64_t *seq_offsets; // [n_reads + 1]
+    uint64_t n_reads;
+    epik_amd_placement *rows;    // [n_reads * keep_at_most]
+    uint32_t *n_rows;            // [n_reads]
+    uint32_t *kmer_counts;       // [n_reads * keep_at_most] or null
+    uint32_t kmer_size;
+    uint32_t alphabet_size;
+    uint32_t num_branches;
+    uint32_t keep_at_most;
+    double keep_factor;
+    float threshold;
+    float log_threshold;
+    float log10_keep_factor_margin;  // log10(keep_factor) - 1e-3: early exit of the top-k rounds
+    uint32_t n_pad;                  // num_branches rounded up to 64
+    uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts)
+};
+
+hipError_t launch_place_reads(const PlaceParams &p, bool offsets64, bool lds_atomic, dim3 grid,
+                              dim3 block, size_t lds_bytes, hipStream_t stream);
+hipError_t set_place_reads_lds_limit(size_t lds_bytes);
+hipError_t place_reads_occupancy(bool offsets64, bool lds_atomic, int block_threads, size_t lds_bytes,
+                                 int *blocks_per_cu);
+hipError_t launch_algorithmic_bytes(const PlaceParams &p, bool offsets64,
+                                    unsigned long long *d_total, hipStream_t stream);
+
+}  // namespace epik_amd
+#endif

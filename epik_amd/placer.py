@@ -1,0 +1,222 @@
+"""Host-side mirror of `epik::placer` (reference epik/include/epik/place.h:81-140)
+over the C-ABI of libepik_amd.so.
+
+Same constructor arguments and `place()` contract as the reference class:
+
+    placer(db, tree, keep_at_most, keep_factor, max_threads)      place.h:94-95
+    placed_collection place(seq_records, num_threads)              place.h:103
+
+* the constructor precomputes the pendant lengths (place.cpp:99-125) and uploads
+  the database to HBM through `epik_amd_placer_create`;
+* `place()` groups identical sequences (place.cpp:73-81, 207-212), sends the unique
+  reads through the boundary, and joins distal/pendant lengths onto the returned
+  rows (place.cpp:435-437).
+
+The heavy lifting is the HIP kernel; nothing here computes a score.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+from . import alphabet, capi
+
+
+@dataclass
+class Placement:
+    """`epik::impl::placement` (place.h:45-56)."""
+
+    branch_id: int
+    score: float          # float32 value
+    weight_ratio: float   # double
+    count: int
+    distal_length: float
+    pendant_length: float
+
+
+@dataclass
+class PlacedSequence:
+    """`epik::impl::placed_sequence` (place.h:59-68)."""
+
+    sequence: str
+    placements: List[Placement]
+
+
+@dataclass
+class PlacedCollection:
+    """`epik::impl::placed_collection` (place.h:72-75): sequence -> headers, plus
+    one PlacedSequence per unique sequence (first-occurrence order; the reference's
+    order is std::unordered_map iteration order, place.cpp:57-61)."""
+
+    sequence_map: dict
+    placed_seqs: List[PlacedSequence]
+
+
+def pendant_lengths(branch_length: np.ndarray, subtree_num_nodes: np.ndarray,
+                    subtree_total_length: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(distal, pendant) per post-order id, place.cpp:99-125 / :435."""
+    branch_length = np.asarray(branch_length, dtype=np.float64)
+    num = np.asarray(subtree_num_nodes, dtype=np.float64)
+    tot = np.asarray(subtree_total_length, dtype=np.float64)
+    distal = branch_length / 2                      # :110
+    mean = np.where(num > 1, tot / np.maximum(num, 1), 0.0)  # :117-121
+    return distal, mean + distal                    # :123
+
+
+class Placer:
+    """MI355X placer.  `offsets`/`values` are the CSR database (host arrays),
+    `branch_length`/`subtree_*` the per-post-order-id tree data (may be None when
+    only raw rows are wanted)."""
+
+    def __init__(self, offsets: np.ndarray, values: np.ndarray, *, states: str, kmer_size: int,
+                 num_branches: int, threshold, log_threshold=None, keep_at_most: int = 7,
+                 keep_factor: float = 0.01, device: int = 0, branch_length=None,
+                 subtree_num_nodes=None, subtree_total_length=None, char_class=None):
+        lib = capi.load()
+        sigma = alphabet.alphabet_size(states)
+        self.states = states
+        self.kmer_size = int(kmer_size)
+        self.num_branches = int(num_branches)
+        self.keep_at_most = int(keep_at_most)
+        self.keep_factor = float(keep_factor)
+        self.device = int(device)
+        if log_threshold is None:
+            log_threshold = alphabet.log_threshold(np.float32(threshold))
+        offsets = np.asarray(offsets)
+        num_entries = int(offsets[-1])
+        if num_entries <= 0xFFFFFFFF:
+            off = np.ascontiguousarray(offsets, dtype=np.uint32)
+            bits = 32
+        else:
+            off = np.ascontiguousarray(offsets, dtype=np.uint64)
+            bits = 64
+        vals = np.ascontiguousarray(values)
+        if vals.dtype.itemsize != 8:
+            raise ValueError("values must be 8-byte {uint32 branch, float32 score} records")
+        cls = np.ascontiguousarray(
+            alphabet.char_class_table(states) if char_class is None else char_class, dtype=np.uint32)
+        desc = capi.PlacerDesc(
+            abi_version=capi.ABI_VERSION, kmer_size=self.kmer_size, alphabet_size=sigma,
+            num_branches=self.num_branches, keep_at_most=self.keep_at_most, offset_bits=bits,
+            keep_factor=self.keep_factor, threshold=float(threshold),
+            log_threshold=float(log_threshold), num_keys=int(off.shape[0] - 1),
+            num_entries=num_entries, offsets=off.ctypes.data, values=vals.ctypes.data,
+            char_class=cls.ctypes.data, device=self.device, reserved=0)
+        handle = ctypes.c_void_p()
+        capi.check(lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(handle)))
+        self._lib = lib
+        self._handle = handle
+        if branch_length is not None:
+            if len(branch_length) != self.num_branches:
+                # place.cpp:104-108: "Could not find node by post-order id"
+                raise RuntimeError(
+                    f"Could not find node by post-order id: {min(len(branch_length), self.num_branches)}")
+            self.distal, self.pendant = pendant_lengths(branch_length, subtree_num_nodes,
+                                                        subtree_total_length)
+        else:
+            self.distal = self.pendant = None
+
+    @classmethod
+    def from_synth(cls, db, tree=None, **kw):
+        extra = {}
+        if tree is not None:
+            extra = dict(branch_length=tree.branch_length, subtree_num_nodes=tree.subtree_num_nodes,
+                         subtree_total_length=tree.subtree_total_length)
+        return cls(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
+                   num_branches=db.num_branches, threshold=db.threshold,
+                   log_threshold=db.log_threshold, **extra, **kw)
+
+    # -- lifetime -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.epik_amd_placer_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the boundary, raw ----------------------------------------------------------
+    def place_packed(self, seqs: np.ndarray, seq_offsets: np.ndarray):
+        """Host buffers in, host buffers out (`epik_amd_placer_place`).  Returns
+        (rows[n, keep] PLACEMENT, n_rows[n] uint32, kmer_counts[n, keep] uint32)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = int(seq_offsets.shape[0] - 1)
+        rows = np.zeros((n, self.keep_at_most), dtype=capi.PLACEMENT)
+        n_rows = np.zeros(n, dtype=np.uint32)
+        counts = np.zeros((n, self.keep_at_most), dtype=np.uint32)
+        capi.check(self._lib.epik_amd_placer_place(
+            self._handle, seqs.ctypes.data, seq_offsets.ctypes.data, n, rows.ctypes.data,
+            n_rows.ctypes.data, counts.ctypes.data))
+        return rows, n_rows, counts
+
+    def place_device(self, d_seqs: int, d_seq_offsets: int, n: int, d_rows: int, d_n_rows: int,
+                     d_kmer_counts: int = 0, stream: int = 0) -> None:
+        """Device pointers in and out, asynchronous on `stream` (`epik_amd_placer_place_device`)."""
+        capi.check(self._lib.epik_amd_placer_place_device(
+            self._handle, d_seqs, d_seq_offsets, int(n), d_rows, d_n_rows, d_kmer_counts or None,
+            stream or None))
+
+    def algorithmic_bytes(self, d_seqs: int, d_seq_offsets: int, n: int, d_n_rows: int = 0,
+                          stream: int = 0) -> int:
+        out = ctypes.c_uint64(0)
+        capi.check(self._lib.epik_amd_placer_algorithmic_bytes(
+            self._handle, d_seqs, d_seq_offsets, int(n), d_n_rows or None, stream or None,
+            ctypes.byref(out)))
+        return int(out.value)
+
+    def launch_info(self) -> dict:
+        w, b, l = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        capi.check(self._lib.epik_amd_placer_launch_info(self._handle, ctypes.byref(w),
+                                                         ctypes.byref(b), ctypes.byref(l)))
+        return {"waves_per_block": w.value, "blocks": b.value, "lds_bytes_per_block": l.value}
+
+    def set_timing(self, enabled: bool) -> None:
+        capi.check(self._lib.epik_amd_placer_set_timing(self._handle, int(bool(enabled))))
+
+    def last_kernel_ms(self) -> float:
+        ms = ctypes.c_float(-1.0)
+        capi.check(self._lib.epik_amd_placer_last_kernel_ms(self._handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    # -- epik::placer::place ---------------------------------------------------------
+    def place(self, seq_records: Iterable[Tuple[str, str]], num_threads: int = 1) -> PlacedCollection:
+        """`seq_records` = (header, sequence) pairs (i2l::seq_record).  `num_threads`
+        is accepted for signature parity and ignored, as the parallelism is the GPU's."""
+        del num_threads
+        sequence_map: dict = {}
+        for header, sequence in seq_records:          # place.cpp:73-81
+            sequence_map.setdefault(sequence, []).append(header)
+        unique = list(sequence_map.keys())            # place.cpp:52-63
+        bufs = [s.encode() for s in unique]
+        offsets = np.zeros(len(bufs) + 1, dtype=np.uint64)
+        if bufs:
+            offsets[1:] = np.cumsum([len(b) for b in bufs], dtype=np.uint64)
+        data = np.frombuffer(b"".join(bufs), dtype=np.uint8) if bufs else np.zeros(0, np.uint8)
+        rows, n_rows, counts = self.place_packed(data, offsets)
+        placed = []
+        for i, seq in enumerate(unique):
+            pl = []
+            for r in range(int(n_rows[i])):
+                b = int(rows[i, r]["branch"])
+                in_tree = self.distal is not None and b < self.num_branches
+                pl.append(Placement(
+                    branch_id=b, score=float(rows[i, r]["score"]),
+                    weight_ratio=float(rows[i, r]["lwr"]), count=int(counts[i, r]),
+                    # rows fabricated for a read without hits carry 0.0 lengths (place.cpp:150)
+                    distal_length=float(self.distal[b]) if in_tree and counts[i, r] else 0.0,
+                    pendant_length=float(self.pendant[b]) if in_tree and counts[i, r] else 0.0))
+            placed.append(PlacedSequence(sequence=seq, placements=pl))
+        return PlacedCollection(sequence_map=sequence_map, placed_seqs=placed)

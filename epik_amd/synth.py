@@ -1,0 +1,231 @@
+"""Seeded synthetic trees, phylo-k-mer databases and reads.
+
+No real database is available offline (D652 / 16S are downloaded by the
+reference's README from another repository, README.md:66-67), so every test and
+the benchmark run on the synthetic model fixed in SURVEY.md 8(d) / BASELINE.md 3:
+
+* tree: random rooted binary tree, `n_leaves` leaves => N = 2*n_leaves - 1 nodes,
+  branch lengths Exp(mean 0.05), post-order ids 0..N-1 (root = N-1);
+* DB: each of the sigma^k keys present with probability `p_present`; list length
+  1 + min(N-1, floor(LogNormal(3.0, 1.5))); branches = a contiguous post-order
+  run starting at a uniform node (clade locality), distinct, ascending; scores
+  log10(U(threshold, 1)) as float32;
+* reads: uniform random over the alphabet, fixed length.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import alphabet
+
+#: numpy mirror of `i2l::pkdb_value {branch, score}` (8 bytes, main.cpp:257)
+PKDB_VALUE = np.dtype([("branch", np.uint32), ("score", np.float32)])
+
+
+@dataclass
+class SynthTree:
+    """A rooted binary tree in post-order numbering.
+
+    `subtree_num_nodes` / `subtree_total_length` mirror `db.tree_index()[i]`
+    (place.cpp:113-114): nodes in the subtree rooted at i (i included) and the
+    summed branch lengths strictly below i."""
+
+    parent: np.ndarray            # int64[N], -1 for the root
+    children: np.ndarray          # int64[N,2], -1 for leaves
+    branch_length: np.ndarray     # float64[N]
+    labels: list
+    subtree_num_nodes: np.ndarray = field(default=None)
+    subtree_total_length: np.ndarray = field(default=None)
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.parent.shape[0])
+
+    def newick(self, jplace: bool = False) -> str:
+        """Newick string; with jplace=True edges carry `{postorder_id}` as
+        `i2l::io::to_newick(tree, true)` does (main.cpp:296-297; syntax assumed)."""
+        out = []
+
+        def fmt(i: int) -> str:
+            s = f"{self.labels[i]}:{self.branch_length[i]:.6g}"
+            if jplace:
+                s += "{%d}" % i
+            return s
+
+        # iterative post-order emit
+        root = self.num_nodes - 1
+        stack = [(root, 0)]
+        while stack:
+            node, state = stack.pop()
+            l, r = self.children[node]
+            if l < 0:
+                out.append(fmt(node))
+                continue
+            if state == 0:
+                out.append("(")
+                stack.append((node, 1))
+                stack.append((int(l), 0))
+            elif state == 1:
+                out.append(",")
+                stack.append((node, 2))
+                stack.append((int(r), 0))
+            else:
+                out.append(")")
+                out.append(fmt(node))
+        return "".join(out) + ";"
+
+
+def make_tree(n_leaves: int, seed: int = 42, mean_branch_length: float = 0.05) -> SynthTree:
+    """Random rooted binary tree by random joins, renumbered in post-order."""
+    if n_leaves < 1:
+        raise ValueError("n_leaves must be >= 1")
+    rng = np.random.default_rng(seed)
+    n = 2 * n_leaves - 1
+    # build with temporary ids: leaves 0..n_leaves-1, internal afterwards
+    tmp_children = -np.ones((n, 2), dtype=np.int64)
+    active = list(range(n_leaves))
+    nxt = n_leaves
+    while len(active) > 1:
+        i, j = rng.choice(len(active), size=2, replace=False)
+        a, b = active[i], active[j]
+        tmp_children[nxt] = (a, b)
+        for idx in sorted((i, j), reverse=True):
+            active.pop(idx)
+        active.append(nxt)
+        nxt += 1
+    root = active[0]
+    # post-order renumbering
+    order = []
+    stack = [(root, False)]
+    while stack:
+        node, done = stack.pop()
+        if done or tmp_children[node, 0] < 0:
+            order.append(node)
+            continue
+        stack.append((node, True))
+        stack.append((int(tmp_children[node, 1]), False))
+        stack.append((int(tmp_children[node, 0]), False))
+    new_id = np.empty(n, dtype=np.int64)
+    new_id[np.array(order)] = np.arange(n)
+    children = -np.ones((n, 2), dtype=np.int64)
+    parent = -np.ones(n, dtype=np.int64)
+    labels = [""] * n
+    for old in range(n):
+        ni = new_id[old]
+        if tmp_children[old, 0] >= 0:
+            l, r = new_id[tmp_children[old, 0]], new_id[tmp_children[old, 1]]
+            children[ni] = (l, r)
+            parent[l] = ni
+            parent[r] = ni
+        else:
+            labels[ni] = f"t{old}"
+    branch_length = rng.exponential(mean_branch_length, size=n)
+    branch_length[n - 1] = 0.0  # root
+    tree = SynthTree(parent=parent, children=children, branch_length=branch_length, labels=labels)
+    num = np.ones(n, dtype=np.int64)
+    tot = np.zeros(n, dtype=np.float64)
+    for i in range(n):  # post-order: children precede parents
+        l, r = children[i]
+        if l >= 0:
+            num[i] += num[l] + num[r]
+            tot[i] += tot[l] + tot[r] + branch_length[l] + branch_length[r]
+    tree.subtree_num_nodes = num
+    tree.subtree_total_length = tot
+    return tree
+
+
+@dataclass
+class SynthDB:
+    """A phylo-k-mer database in CSR form: key -> values[offsets[key]:offsets[key+1]]."""
+
+    states: str
+    kmer_size: int
+    omega: float
+    num_branches: int
+    offsets: np.ndarray   # uint64[sigma^k + 1]
+    values: np.ndarray    # PKDB_VALUE[num_entries]
+    threshold: np.float32 = None
+    log_threshold: np.float32 = None
+
+    def __post_init__(self):
+        sigma = alphabet.alphabet_size(self.states)
+        if self.threshold is None:
+            self.threshold = alphabet.score_threshold(self.omega, self.kmer_size, sigma)
+        if self.log_threshold is None:
+            self.log_threshold = alphabet.log_threshold(self.threshold)
+
+    @property
+    def alphabet_size(self) -> int:
+        return alphabet.alphabet_size(self.states)
+
+    @property
+    def num_keys(self) -> int:
+        return int(self.offsets.shape[0] - 1)
+
+    @property
+    def num_entries(self) -> int:
+        return int(self.values.shape[0])
+
+
+def make_db(num_branches: int, states: str = "nucl", kmer_size: int = 10, omega: float = 1.5,
+            p_present: float = 0.6, seed: int = 43, lognormal=(3.0, 1.5),
+            scattered: bool = False) -> SynthDB:
+    """Synthetic DB of SURVEY.md 8(d).  `scattered=True` replaces the contiguous
+    branch run by a sorted random subset (stress for the LDS scatter-add)."""
+    sigma = alphabet.alphabet_size(states)
+    num_keys = sigma ** kmer_size
+    rng = np.random.default_rng(seed)
+    threshold = alphabet.score_threshold(omega, kmer_size, sigma)
+    present = rng.random(num_keys) < p_present
+    n_present = int(present.sum())
+    raw = np.floor(rng.lognormal(lognormal[0], lognormal[1], size=n_present))
+    lengths = (1 + np.minimum(num_branches - 1, raw)).astype(np.int64)
+    lens_all = np.zeros(num_keys, dtype=np.int64)
+    lens_all[present] = lengths
+    offsets = np.zeros(num_keys + 1, dtype=np.uint64)
+    np.cumsum(lens_all, out=offsets[1:].view(np.int64))
+    total = int(offsets[-1])
+    values = np.empty(total, dtype=PKDB_VALUE)
+    list_id = np.repeat(np.arange(n_present, dtype=np.int64), lengths)
+    list_start = np.cumsum(lengths) - lengths
+    within = np.arange(total, dtype=np.int64) - list_start[list_id]
+    if scattered:
+        # `len` distinct branches per list: (start + j * step) mod N with step coprime
+        # to N, then sorted ascending within each list
+        start = rng.integers(0, num_branches, size=n_present)
+        step = rng.integers(1, max(2, num_branches), size=n_present)
+        g = np.gcd(step, num_branches)
+        step = np.where(g == 1, step, 1)
+        br = (start[list_id] + within * step[list_id]) % num_branches
+        order = np.lexsort((br, list_id))
+        br = br[order]
+    else:
+        start = (rng.random(n_present) * (num_branches - lengths + 1)).astype(np.int64)
+        br = start[list_id] + within
+    values["branch"] = br.astype(np.uint32)
+    u = rng.random(total)
+    prob = float(threshold) + u * (1.0 - float(threshold))
+    values["score"] = np.log10(prob).astype(np.float32)
+    return SynthDB(states=states, kmer_size=kmer_size, omega=omega, num_branches=num_branches,
+                   offsets=offsets, values=values, threshold=threshold)
+
+
+def make_reads(n_reads: int, length: int, states: str = "nucl", seed: int = 44):
+    """Uniform random reads of fixed length.  Returns (bytes uint8[n*length], offsets uint64[n+1])."""
+    rng = np.random.default_rng(seed)
+    chars = np.frombuffer(alphabet.state_chars(states).encode(), dtype=np.uint8)
+    seqs = chars[rng.integers(0, len(chars), size=n_reads * length, dtype=np.uint8)]
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(length)
+    return seqs, offsets
+
+
+def pack_reads(reads) -> tuple:
+    """Concatenates an iterable of str/bytes reads -> (uint8 buffer, uint64 offsets[n+1])."""
+    bufs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    offsets = np.zeros(len(bufs) + 1, dtype=np.uint64)
+    if bufs:
+        offsets[1:] = np.cumsum([len(b) for b in bufs], dtype=np.uint64)
+    data = np.frombuffer(b"".join(bufs), dtype=np.uint8).copy() if bufs else np.zeros(0, np.uint8)
+    return data, offsets

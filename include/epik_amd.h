@@ -1,0 +1,152 @@
+/*
+ * epik_amd.h -- C ABI of the MI355X placement engine (libepik_amd.so).
+ *
+ * This is the drop-in boundary for EPIK's one hot path, the per-read loop of
+ * `epik::placer` (reference: epik/include/epik/place.h:81-140,
+ * epik/src/epik/place.cpp:201-440).  The reference has no FFI layer; the
+ * narrowest seam the path sits behind is the C++ class `epik::placer`:
+ *
+ *     placer(const i2l::phylo_kmer_db&, const i2l::phylo_tree&,
+ *            size_t keep_at_most, double keep_factor, size_t max_threads);   place.h:94-95
+ *     placed_collection place(const std::vector<i2l::seq_record>&, size_t);  place.h:103
+ *
+ * Each entry point below names the reference interface it replaces.  Plain
+ * pointers and sizes only; no C++ or torch types cross the boundary; no
+ * exception crosses it either (the reference throws std::runtime_error,
+ * place.cpp:104-108,430-433; here every call returns a status code and
+ * epik_amd_last_error() holds the message).
+ *
+ * There is no CPU fallback: every entry point that computes fails with
+ * EPIK_AMD_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef EPIK_AMD_H
+#define EPIK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPIK_AMD_ABI_VERSION 1
+
+enum epik_amd_status {
+    EPIK_AMD_OK = 0,
+    EPIK_AMD_ERR_INVALID = 1,   /* bad argument / inconsistent database */
+    EPIK_AMD_ERR_NO_DEVICE = 2, /* no usable HIP device (no CPU fallback exists) */
+    EPIK_AMD_ERR_HIP = 3,       /* HIP runtime error, see epik_amd_last_error() */
+    EPIK_AMD_ERR_UNSUPPORTED = 4 /* configuration outside what the kernels cover */
+};
+
+/* i2l::pkdb_value {branch, score}: one phylo-k-mer posting (main.cpp:257,
+ * place.cpp:358).  branch = post-order node id, score = log10 probability. */
+typedef struct {
+    uint32_t branch;
+    float score;
+} epik_amd_pkdb_value;
+
+/* One reported placement: the fields of epik::impl::placement computed on the
+ * hot path (place.h:45-56: branch_id, score, weight_ratio).  distal_length and
+ * pendant_length are per-branch constants the host joins (place.cpp:435-437). */
+typedef struct {
+    uint32_t branch;
+    float score;
+    double lwr;
+} epik_amd_placement;
+
+/*
+ * What `epik::placer`'s constructor receives through `db` and `tree`
+ * (place.cpp:83-96), flattened: the phylo-k-mer database as a CSR-like layout
+ * (k-mer code -> posting list) replacing the i2l hash map behind
+ * `phylo_kmer_db::search` (place.cpp:300,311).
+ *
+ * Key space: dense.  The code of a k-mer is the base-`alphabet_size` number of
+ * its k state codes, first character most significant; offsets[code] ..
+ * offsets[code+1] delimit its postings in values[].  num_keys must equal
+ * alphabet_size^kmer_size.  All pointers are HOST pointers; create() copies
+ * them to the device, the caller may free them afterwards.
+ */
+typedef struct {
+    uint32_t abi_version;    /* EPIK_AMD_ABI_VERSION */
+    uint32_t kmer_size;      /* db.kmer_size()                       place.cpp:87 */
+    uint32_t alphabet_size;  /* 4 = nucl (epik-dna), 20 = amino (epik-aa); epik/CMakeLists.txt:72,124 */
+    uint32_t num_branches;   /* tree.get_node_count()                place.cpp:92 */
+    uint32_t keep_at_most;   /* --keep-at-most, default 7            main.cpp:219 */
+    uint32_t offset_bits;    /* width of offsets[]: 32 or 64 */
+    double keep_factor;      /* --keep-factor, default 0.01          main.cpp:220 */
+    float threshold;         /* i2l::score_threshold(omega, k)       place.cpp:87 */
+    float log_threshold;     /* std::log10(threshold), as float      place.cpp:88 */
+    uint64_t num_keys;       /* alphabet_size ^ kmer_size */
+    uint64_t num_entries;    /* offsets[num_keys] = db.get_num_entries_loaded() */
+    const void *offsets;     /* uint32_t/uint64_t [num_keys + 1] */
+    const epik_amd_pkdb_value *values; /* [num_entries]; branches distinct within one list */
+    const uint32_t *char_class; /* [256]: bit s set <=> the character may be state s;
+                                   popcount 1 plain, >1 ambiguous, 0 invalid
+                                   (i2l::to_kmers<one_ambiguity_policy>, place.cpp:294) */
+    int32_t device;          /* HIP device ordinal */
+    uint32_t reserved;
+} epik_amd_placer_desc;
+
+typedef struct epik_amd_placer epik_amd_placer;
+
+/* Number of visible HIP devices (0 when there is none / no driver). */
+int epik_amd_device_count(void);
+
+/* Message of the last failing call on this thread. */
+const char *epik_amd_last_error(void);
+
+/* Replaces epik::placer::placer (place.cpp:83-126): uploads the database to
+ * the device's HBM once and precomputes what the kernel needs. */
+int epik_amd_placer_create(const epik_amd_placer_desc *desc, epik_amd_placer **out);
+
+/* Replaces ~placer (place.h:100). */
+void epik_amd_placer_destroy(epik_amd_placer *p);
+
+/*
+ * Replaces the OpenMP loop of epik::placer::place (place.cpp:218-268): places n
+ * reads that the host has already de-duplicated (place.cpp:207-212).
+ *   seqs / seq_offsets[n+1]: concatenated read bytes (HOST).
+ *   rows[n * keep_at_most], n_rows[n]: placements in final order (sorted by
+ *     score descending -- ties by branch ascending --, LWR-filtered,
+ *     place.cpp:240-267); n_rows[i] == 0 iff read i is shorter than k.
+ *   kmer_counts[n * keep_at_most] (nullable): placement::count (place.h:53).
+ * Synchronous: copies in, runs the kernel, copies out.
+ */
+int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *seq_offsets,
+                          uint64_t n, epik_amd_placement *rows, uint32_t *n_rows,
+                          uint32_t *kmer_counts);
+
+/*
+ * Same computation with every buffer already resident in device memory, enqueued
+ * on `stream` (a hipStream_t passed as void*; NULL = the default stream) without
+ * synchronising.  d_kmer_counts may be NULL.
+ */
+int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
+                                 uint64_t n, void *d_rows, void *d_n_rows, void *d_kmer_counts,
+                                 void *stream);
+
+/*
+ * Measurement helper: algorithmic bytes of a device-resident
+ * batch, sum over reads of L + 8*n_kmers + 8*sum|posting list| + 16*rows_out,
+ * with rows_out taken from d_n_rows (NULL counts no output rows).  Synchronous.
+ */
+int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
+                                      const void *d_seq_offsets, uint64_t n, const void *d_n_rows,
+                                      void *stream, uint64_t *bytes_out);
+
+/* Launch geometry actually used (for reports): waves per workgroup, workgroups
+ * of the last launch, dynamic LDS bytes per workgroup. */
+int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,
+                                uint32_t *blocks, uint32_t *lds_bytes);
+
+/* Times the last place_device launch on its own stream with HIP events recorded
+ * around the kernel inside the library (milliseconds; <0 if none was recorded).
+ * Event recording is enabled with epik_amd_placer_set_timing(p, 1). */
+int epik_amd_placer_set_timing(epik_amd_placer *p, int enabled);
+int epik_amd_placer_last_kernel_ms(epik_amd_placer *p, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

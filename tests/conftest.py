@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """Builds oracle/libepik_oracle.so with the committed Makefile (gcc only)."""
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def small_case():
+    """N=15 tree, k=4 nucl DB: small enough for the pure-Python restatement."""
+    from epik_amd import synth
+    tree = synth.make_tree(8, seed=1)
+    db = synth.make_db(tree.num_nodes, kmer_size=4, p_present=0.7, seed=5, lognormal=(1.0, 1.0))
+    return tree, db
+
+
+def mixed_reads(rng, n, k, alphabet_plain="ACGT", alphabet_amb="ACGTNRY-", max_len=60):
+    reads = []
+    for i in range(n):
+        length = int(rng.integers(k, max_len))
+        alpha = alphabet_plain if i % 3 else alphabet_amb
+        reads.append("".join(rng.choice(list(alpha), size=length)))
+    return reads
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    from epik_amd import capi
+    return capi.device_count() > 0
+
+
+def assert_rows_match(rows_gpu, n_gpu, cnt_gpu, rows_ref, n_ref, cnt_ref, lwr_tol=1e-5):
+    """The parity bar of BASELINE.json: branch order and float32 scores bit-exact,
+    |delta like_weight_ratio| <= 1e-5 (north_star).  Returns max |delta lwr|."""
+    assert np.array_equal(n_gpu, n_ref), (
+        f"row counts differ at reads {np.nonzero(n_gpu != n_ref)[0][:10]}")
+    keep = rows_ref.shape[1]
+    valid = np.arange(keep)[None, :] < n_ref[:, None]
+    assert np.array_equal(rows_gpu["branch"][valid], rows_ref["branch"][valid]), "branch ids differ"
+    a = rows_gpu["score"][valid].view(np.uint32)
+    b = rows_ref["score"][valid].view(np.uint32)
+    assert np.array_equal(a, b), f"float32 scores not bit-identical ({int((a != b).sum())} rows)"
+    assert np.array_equal(cnt_gpu[valid], cnt_ref[valid]), "k-mer counts differ"
+    d = np.abs(rows_gpu["lwr"][valid] - rows_ref["lwr"][valid])
+    worst = float(d.max()) if d.size else 0.0
+    assert worst <= lwr_tol, f"|delta lwr| = {worst} > {lwr_tol}"
+    return worst

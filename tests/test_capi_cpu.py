@@ -1,0 +1,96 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/epik_amd.h declares, validates its arguments, and refuses to compute
+without a GPU (there is no CPU fallback in the product path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from epik_amd import alphabet, capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "epik_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(epik_amd_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    declared = _header_symbols()
+    assert declared, "no prototypes found in include/epik_amd.h"
+    assert sorted(capi.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), f"libepik_amd.so does not export {name}"
+
+
+def test_struct_layouts_match_header():
+    assert capi.PLACEMENT.itemsize == 16
+    assert capi.PKDB_VALUE.itemsize == 8
+    assert ctypes.sizeof(capi.PlacerDesc) == 88
+    assert capi.PlacerDesc.keep_factor.offset == 24
+    assert capi.PlacerDesc.offsets.offset == 56
+    assert capi.PlacerDesc.device.offset == 80
+
+
+def _desc(db, **over):
+    off = np.ascontiguousarray(db.offsets, dtype=np.uint32)
+    cls = alphabet.char_class_table(db.states)
+    d = dict(abi_version=capi.ABI_VERSION, kmer_size=db.kmer_size, alphabet_size=db.alphabet_size,
+             num_branches=db.num_branches, keep_at_most=7, offset_bits=32, keep_factor=0.01,
+             threshold=float(db.threshold), log_threshold=float(db.log_threshold),
+             num_keys=db.num_keys, num_entries=db.num_entries, offsets=off.ctypes.data,
+             values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, reserved=0)
+    d.update(over)
+    return capi.PlacerDesc(**d), (off, cls)
+
+
+@pytest.mark.parametrize("over,code", [
+    (dict(abi_version=99), capi.ERR_INVALID),
+    (dict(kmer_size=0), capi.ERR_UNSUPPORTED),
+    (dict(keep_at_most=0), capi.ERR_UNSUPPORTED),
+    (dict(keep_at_most=65), capi.ERR_UNSUPPORTED),
+    (dict(offset_bits=16), capi.ERR_INVALID),
+    (dict(num_keys=17), capi.ERR_INVALID),
+    (dict(num_entries=3), capi.ERR_INVALID),
+    (dict(offsets=None), capi.ERR_INVALID),
+])
+def test_create_rejects_bad_descriptors(small_case, over, code):
+    _, db = small_case
+    lib = capi.load()
+    desc, keep = _desc(db, **over)
+    handle = ctypes.c_void_p()
+    rc = lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(handle))
+    assert rc == code, lib.epik_amd_last_error()
+    assert not handle.value
+    assert lib.epik_amd_last_error()
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(small_case):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    _, db = small_case
+    lib = capi.load()
+    desc, keep = _desc(db)
+    handle = ctypes.c_void_p()
+    rc = lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(handle))
+    assert rc == capi.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.epik_amd_last_error()
+    from epik_amd.placer import Placer
+    with pytest.raises(capi.EpikAmdError):
+        Placer.from_synth(db)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under epik_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "epik_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "epik_oracle" not in text, f

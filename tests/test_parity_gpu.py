@@ -1,0 +1,139 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs.  Bar (BASELINE.json north_star): branch ids in
+identical order, float32 scores bit-identical, |delta like_weight_ratio| <= 1e-5
+(observed: ~1e-16, only libm-vs-device pow ulps)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_rows_match, mixed_reads
+from epik_amd import alphabet, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def placer_cls(gpu_available):
+    assert gpu_available, "pytest -m gpu needs a HIP device (no CPU fallback exists)"
+    from epik_amd.placer import Placer
+    return Placer
+
+
+def _compare(placer_cls, oracle_lib, db, data, offs, **kw):
+    orc = oracle_lib.Oracle.from_synth(db, **kw)
+    ref = orc.place(data, offs, num_threads=0)
+    with placer_cls.from_synth(db, **kw) as pl:
+        got = pl.place_packed(data, offs)
+    return assert_rows_match(*got, *ref)
+
+
+def test_small_db_mixed_reads(placer_cls, oracle_lib, small_case):
+    _, db = small_case
+    rng = np.random.default_rng(0)
+    reads = mixed_reads(rng, 2000, db.kmer_size, max_len=300)
+    reads += ["ACG", "", "ACGT", "NNNNNNNN", "ACGTACGTNACGT", "-" * 10, "acgtacgtacgu", "T" * 50]
+    data, offs = synth.pack_reads(reads)
+    _compare(placer_cls, oracle_lib, db, data, offs)
+
+
+def test_golden_fixture(placer_cls):
+    """Committed vectors (tests/golden/make_golden.py)."""
+    with open(os.path.join(GOLDEN, "synth_k6.json")) as fh:
+        g = json.load(fh)
+    tree = synth.make_tree(g["n_leaves"], seed=g["tree_seed"])
+    db = synth.make_db(tree.num_nodes, kmer_size=g["kmer_size"], p_present=g["p_present"],
+                       seed=g["db_seed"], lognormal=tuple(g["lognormal"]))
+    data, offs = synth.pack_reads(g["reads"])
+    with placer_cls.from_synth(db) as pl:
+        rows, n_rows, counts = pl.place_packed(data, offs)
+    assert list(map(int, n_rows)) == g["n_rows"]
+    for i, exp in enumerate(g["rows"]):
+        for j, (b, score_bits, lwr, c) in enumerate(exp):
+            assert int(rows[i, j]["branch"]) == b
+            assert int(rows[i, j]["score"].view(np.uint32)) == score_bits
+            assert abs(float(rows[i, j]["lwr"]) - lwr) <= 1e-5
+            assert int(counts[i, j]) == c
+
+
+@pytest.mark.parametrize("lds_atomic", ["1", "0"])
+def test_config1_shape_k10(placer_cls, oracle_lib, lds_atomic, monkeypatch):
+    """BASELINE configs[0]/[1] shape at a size the oracle finishes in seconds:
+    nucl k=10, N=1303 (652 leaves, the D652 substitute), 150 bp reads.  Both the
+    LDS-atomic accumulate and the read-add-write one must be bit-exact."""
+    monkeypatch.setenv("EPIK_AMD_LDS_ATOMIC", lds_atomic)
+    tree = synth.make_tree(652, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
+    data, offs = synth.make_reads(20000, 150, seed=44)
+    worst = _compare(placer_cls, oracle_lib, db, data, offs)
+    assert worst < 1e-9
+
+
+def test_scattered_branches_and_long_reads(placer_cls, oracle_lib):
+    """Posting lists with non-contiguous branch sets; read lengths 10..3000
+    (several 64-character tiles, lists longer than one wave step)."""
+    tree = synth.make_tree(300, seed=2)
+    db = synth.make_db(tree.num_nodes, kmer_size=8, seed=3, p_present=0.8, scattered=True)
+    rng = np.random.default_rng(9)
+    reads = ["".join(rng.choice(list("ACGT"), size=int(n)))
+             for n in rng.integers(8, 3000, size=600)]
+    data, offs = synth.pack_reads(reads)
+    _compare(placer_cls, oracle_lib, db, data, offs)
+
+
+def test_keep_parameters(placer_cls, oracle_lib, small_case):
+    _, db = small_case
+    rng = np.random.default_rng(5)
+    data, offs = synth.pack_reads(mixed_reads(rng, 500, db.kmer_size))
+    for keep_at_most, keep_factor in [(1, 0.01), (3, 0.5), (7, 0.0), (20, 0.001), (64, 0.0)]:
+        _compare(placer_cls, oracle_lib, db, data, offs, keep_at_most=keep_at_most,
+                 keep_factor=keep_factor)
+
+
+def test_underflowing_scores_zero_lwr(placer_cls, oracle_lib):
+    """Very long reads: 10^score underflows double -> score_sum == 0 -> every LWR is 0
+    and nothing is filtered (place.cpp:243-251)."""
+    tree = synth.make_tree(40, seed=4)
+    db = synth.make_db(tree.num_nodes, kmer_size=6, seed=6, p_present=0.3)
+    rng = np.random.default_rng(1)
+    reads = ["".join(rng.choice(list("ACGT"), size=n)) for n in (4000, 9000, 20000)]
+    data, offs = synth.pack_reads(reads)
+    orc = oracle_lib.Oracle.from_synth(db)
+    ref = orc.place(data, offs)
+    assert (ref[0]["lwr"][-1] == 0).all() and ref[1][-1] == 7
+    with placer_cls.from_synth(db) as pl:
+        got = pl.place_packed(data, offs)
+    assert_rows_match(*got, *ref)
+
+
+def test_amino_k4(placer_cls, oracle_lib):
+    """20-state encoder (epik-aa), incl. ambiguous B/Z/J/X and invalid '*'."""
+    tree = synth.make_tree(30, seed=8)
+    db = synth.make_db(tree.num_nodes, states="amino", kmer_size=4, seed=12, p_present=0.4,
+                       lognormal=(1.5, 1.0))
+    rng = np.random.default_rng(2)
+    reads = []
+    for i in range(800):
+        alpha = alphabet.AMINO_STATES if i % 3 else alphabet.AMINO_STATES + "BZJX*"
+        reads.append("".join(rng.choice(list(alpha), size=int(rng.integers(4, 400)))))
+    data, offs = synth.pack_reads(reads)
+    _compare(placer_cls, oracle_lib, db, data, offs)
+
+
+def test_placer_place_mirrors_reference_contract(placer_cls, oracle_lib, small_case):
+    """Placer.place(): duplicate sequences are placed once and carry all their
+    headers (place.cpp:73-81); lengths are joined per branch (place.cpp:110-123)."""
+    tree, db = small_case
+    records = [("r1", "ACGTACGTAC"), ("r2", "TTTTACGTAA"), ("r3", "ACGTACGTAC"), ("r4", "GG")]
+    with placer_cls.from_synth(db, tree) as pl:
+        out = pl.place(records)
+    assert out.sequence_map["ACGTACGTAC"] == ["r1", "r3"]
+    assert len(out.placed_seqs) == 3
+    first = out.placed_seqs[0]
+    assert first.sequence == "ACGTACGTAC" and first.placements
+    for p in first.placements:
+        if p.count:
+            assert p.distal_length == pytest.approx(tree.branch_length[p.branch_id] / 2)
+    assert out.placed_seqs[2].placements == []      # shorter than k
