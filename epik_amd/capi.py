@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libepik_amd.so")
+LIB_PATH = os.environ.get("EPIK_AMD_LIB") or os.path.join(_HERE, "libepik_amd.so")
 
 ABI_VERSION = 1
 

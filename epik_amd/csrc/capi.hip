@@ -112,8 +112,10 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
         return fail(EPIK_AMD_ERR_UNSUPPORTED, "kmer_size must be in [1, 32]");
     if (d->alphabet_size < 2 || d->alphabet_size > 32)
         return fail(EPIK_AMD_ERR_INVALID, "alphabet_size must be in [2, 32]");
-    if (d->num_branches == 0 || d->num_branches >= 0x7fffffffu)
+    if (d->num_branches == 0 || d->num_branches >= (1u << 24))
         return fail(EPIK_AMD_ERR_INVALID, "num_branches out of range");
+    if (d->num_entries >= (1ull << 40))
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "more than 2^40 postings");
     if (d->keep_at_most == 0 || d->keep_at_most > 64)
         return fail(EPIK_AMD_ERR_UNSUPPORTED, "keep_at_most must be in [1, 64]");
     if (d->offset_bits != 32 && d->offset_bits != 64)
@@ -159,7 +161,7 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     p->num_keys = d->num_keys;
     p->num_entries = d->num_entries;
     const char *env = std::getenv("EPIK_AMD_LDS_ATOMIC");
-    p->lds_atomic = !(env && env[0] == '0');
+    p->lds_atomic = env && env[0] == '1';  // default: 64-bit LDS read-add-write (faster than ds_add_f32)
 
     // every posting's branch must index the LDS score vector
     for (uint64_t i = 0; i < d->num_entries; ++i) {
@@ -205,7 +207,11 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     pp.log10_keep_factor_margin =
         d->keep_factor > 0.0 ? (float)(std::log10(d->keep_factor) - 1e-3) : -INFINITY;
     pp.n_pad = (d->num_branches + 63u) & ~63u;
-    pp.lds_wave_bytes = pp.n_pad * 8u;
+    pp.lds_wave_bytes = pp.n_pad * 8u + EPIK_AMD_TILES_PER_PASS * 64u * 8u;
+    pp.ablate = 0;
+#ifdef EPIK_AMD_ABLATION
+    if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
+#endif
 
     // geometry: as many waves per workgroup (<= 4) as fit the 160 KiB of LDS
     if (pp.lds_wave_bytes > kMaxLdsPerBlock) {

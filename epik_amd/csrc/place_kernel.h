@@ -8,6 +8,8 @@
 
 #include "epik_amd.h"
 
+#define EPIK_AMD_TILES_PER_PASS 3
+
 namespace epik_amd {
 
 // Kernel arguments: the database in HBM (CSR-like: code -> offsets -> postings),
@@ -31,7 +33,8 @@ struct PlaceParams {
     float log_threshold;
     float log10_keep_factor_margin;  // log10(keep_factor) - 1e-3: early exit of the top-k rounds
     uint32_t n_pad;                  // num_branches rounded up to 64
-    uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts)
+    uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + pass descriptors)
+    uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
 };
 
 hipError_t launch_place_reads(const PlaceParams &p, bool offsets64, bool lds_atomic, dim3 grid,

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "place_kernel.h"
 
 namespace epik_amd {
@@ -28,6 +30,12 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr uint32_t kAmbSeen = 0x80000000u;  // counts[] bit: branch already scored by an ambiguous key
+constexpr int kTilesPerPass = EPIK_AMD_TILES_PER_PASS;  // 64-character tiles encoded per pass
+constexpr int kRing = 8;            // posting-chunk loads kept in flight per wave
+constexpr int kDescLenShift = 40;   // descriptor = start (40 bits) | len << 40 (24 bits)
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 
@@ -45,38 +53,72 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
+// Cross-lane moves inside a row of 16 lanes (DPP, no LDS round trip):
+// 0xB1 = quad_perm[1,0,3,2], 0x4E = quad_perm[2,3,0,1], 0x141 = row_half_mirror, 0x140 = row_mirror.
+// Applying them in this order leaves every lane of a row with the row's reduction.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const uint64_t o = shfl_xor_u64(v, m);
-        v = o > v ? o : v;
-    }
-    return v;
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, 0xf, 0xf, false);
+}
+template <int kCtrl>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
+{
+    return ((uint64_t)dpp_u32<kCtrl>((uint32_t)(v >> 32)) << 32) | dpp_u32<kCtrl>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
+{
+    // the builtin returns int: cast before widening, or the low half sign-extends
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l);
+    return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v)
+// Wave reductions; the result is wave-uniform (combined from the four rows' lane 0/16/32/48).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        v += __longlong_as_double((long long)shfl_xor_u64((uint64_t)__double_as_longlong(v), m));
-    }
-    return v;
+    v = max(v, dpp_u32<0xB1>(v));
+    v = max(v, dpp_u32<0x4E>(v));
+    v = max(v, dpp_u32<0x141>(v));
+    v = max(v, dpp_u32<0x140>(v));
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
 }
-
-__device__ __forceinline__ double readlane0_f64(double v)
-{
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, 0);
-    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), 0);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
-    return v;
+    v += dpp_u32<0xB1>(v);
+    v += dpp_u32<0x4E>(v);
+    v += dpp_u32<0x141>(v);
+    v += dpp_u32<0x140>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v)
+{
+    v |= dpp_u64<0xB1>(v);
+    v |= dpp_u64<0x4E>(v);
+    v |= dpp_u64<0x141>(v);
+    v |= dpp_u64<0x140>(v);
+    return readlane_u64(v, 0) | readlane_u64(v, 16) | readlane_u64(v, 32) | readlane_u64(v, 48);
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    auto mv = [](double x, auto tag) {
+        return __longlong_as_double((long long)dpp_u64<decltype(tag)::value>((uint64_t)__double_as_longlong(x)));
+    };
+    v += mv(v, std::integral_constant<int, 0xB1>{});
+    v += mv(v, std::integral_constant<int, 0x4E>{});
+    v += mv(v, std::integral_constant<int, 0x141>{});
+    v += mv(v, std::integral_constant<int, 0x140>{});
+    auto rl = [&](int l) { return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), l)); };
+    return (rl(0) + rl(16)) + (rl(32) + rl(48));
+}
+
+// inverse of ord_f32
+__device__ __forceinline__ float unord_f32(uint32_t o)
+{
+    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
 // 10^x in double.  The reference calls glibc pow(10.0, x) (place.cpp:46,181,254);
@@ -129,9 +171,13 @@ __device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uin
     return t;
 }
 
+// Wave-private LDS.  cell[b] = {float bits of _scores[thread][b], _counts[thread][b]}
+// (place.h:126-131) side by side, so one 8-byte LDS access serves both; bit 31 of the
+// count is kAmbSeen.  `desc` holds the found posting lists of the current pass in read
+// order and is reused by the epilogue for its top-k candidates.
 struct WaveLds {
-    float *scores;     // [N]  _scores[thread]  (place.h:126)
-    uint32_t *counts;  // [N]  _counts[thread]  (place.h:131); bit 31 = kAmbSeen
+    uint2 *cell;     // [n_pad]
+    uint64_t *desc;  // [kTilesPerPass * 64]
 };
 
 // One chunk of one posting list: lanes [0, cnt) each take one posting and add it
@@ -140,15 +186,18 @@ template <bool kLdsAtomic>
 __device__ __forceinline__ void accumulate_chunk(const WaveLds &lds, uint2 e, bool active)
 {
     if (active) {
-        const uint32_t b = e.x;
+        uint2 *c = &lds.cell[e.x];
         const float sc = __uint_as_float(e.y);
         if (kLdsAtomic) {
-            // ds_add_f32 / ds_add_u32, no return: one RNE float add per cell, in wave issue order
-            __hip_atomic_fetch_add(&lds.scores[b], sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(&lds.counts[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            // ds_add_f32 / ds_add_u32, no return (bit-exact too, but ~2x slower on gfx950)
+            __hip_atomic_fetch_add(reinterpret_cast<float *>(&c->x), sc, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&c->y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         } else {
-            lds.scores[b] = __fadd_rn(lds.scores[b], sc);
-            lds.counts[b] = lds.counts[b] + 1u;
+            uint2 v = *c;                                                      // ds_read_b64
+            v.x = __float_as_uint(__fadd_rn(__uint_as_float(v.x), sc));        // :366
+            v.y += 1u;                                                         // :365
+            *c = v;                                                            // ds_write_b64
         }
     }
 }
@@ -166,14 +215,11 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
     WaveLds lds;
     {
         unsigned char *base = lds_raw + (size_t)wave_in_block * p.lds_wave_bytes;
-        lds.scores = reinterpret_cast<float *>(base);
-        lds.counts = reinterpret_cast<uint32_t *>(base + (size_t)p.n_pad * 4);
+        lds.cell = reinterpret_cast<uint2 *>(base);
+        lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * 8);
     }
     const uint32_t N = p.num_branches;
-    for (uint32_t i = lane; i < p.n_pad; i += kWave) {
-        lds.scores[i] = 0.0f;
-        lds.counts[i] = 0u;
-    }
+    for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
 
     const OffT *__restrict__ offsets = static_cast<const OffT *>(p.offsets);
     const uint2 *__restrict__ values = p.values;
@@ -182,6 +228,7 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
     const uint32_t stride = kWave - (k - 1);  // windows per 64-character tile
     const float k_f = (float)k;
     const float log_thr = p.log_threshold;
+    const int lane8 = lane * 8;
 
     const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave_in_block;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
@@ -198,37 +245,127 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
         bool any_amb = false;
 
         // ---- exact k-mers, read order (place.cpp:294-305, 349-371) -------------------
-        for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
-            const Tile t = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
-            uint64_t start = 0;
-            uint32_t llen = 0;
-            bool exact = t.in_range;
-            if ((t.inv_mask | t.amb_mask) != 0) {  // wave-uniform, cold
-                const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-                const uint64_t inv_w = (t.inv_mask >> lane) & wmask;
-                const uint64_t amb_w = (t.amb_mask >> lane) & wmask;
-                const bool is_amb = t.in_range && inv_w == 0 && __popcll(amb_w) == 1;
-                exact = t.in_range && inv_w == 0 && amb_w == 0;
-                any_amb = any_amb || (__ballot(is_amb) != 0);
-            }
-            if (exact) load_range(offsets, t.key, start, llen);
-
-            // lists of this tile, one k-mer at a time, 64 postings per step
-            uint64_t found = __ballot(llen != 0);
-            while (found) {
-                const int m = __builtin_ctzll(found);
-                found &= found - 1;
-                const uint32_t s_lo = __builtin_amdgcn_readlane((uint32_t)start, m);
-                const uint32_t s_hi = __builtin_amdgcn_readlane((uint32_t)(start >> 32), m);
-                const uint32_t n = __builtin_amdgcn_readlane(llen, m);
-                const uint2 *__restrict__ list = values + (((uint64_t)s_hi << 32) | s_lo);
-                for (uint32_t off = 0; off < n; off += kWave) {
-                    const bool active = off + (uint32_t)lane < n;
-                    uint2 e = make_uint2(0u, 0u);
-                    if (active) e = list[off + lane];
-                    accumulate_chunk<kLdsAtomic>(lds, e, active);
+        // A pass covers kTilesPerPass 64-character tiles: (1) encode every window and
+        // issue all offset-table loads at once, (2) compact the found lists, in read
+        // order, into the wave's LDS descriptor array, (3) stream their postings through
+        // a ring of kRing in-flight 512-byte loads.
+        for (uint64_t pass_pos = 0; pass_pos < n_kmers; pass_pos += (uint64_t)kTilesPerPass * stride) {
+            uint64_t start[kTilesPerPass];
+            uint32_t llen[kTilesPerPass];
+#pragma unroll
+            for (int t = 0; t < kTilesPerPass; ++t) {
+                start[t] = 0;
+                llen[t] = 0;
+                const uint64_t tile_pos = pass_pos + (uint64_t)t * stride;
+                if (tile_pos < n_kmers) {  // wave-uniform
+                    const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
+                    bool exact = tl.in_range;
+                    if ((tl.inv_mask | tl.amb_mask) != 0) {  // wave-uniform, cold
+                        const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+                        const uint64_t inv_w = (tl.inv_mask >> lane) & wmask;
+                        const uint64_t amb_w = (tl.amb_mask >> lane) & wmask;
+                        const bool is_amb = tl.in_range && inv_w == 0 && __popcll(amb_w) == 1;
+                        exact = tl.in_range && inv_w == 0 && amb_w == 0;
+                        any_amb = any_amb || (__ballot(is_amb) != 0);
+                    }
+                    if (exact) load_range(offsets, tl.key, start[t], llen[t]);
                 }
             }
+            uint32_t n_desc = 0;
+#pragma unroll
+            for (int t = 0; t < kTilesPerPass; ++t) {
+                const uint64_t found = __ballot(llen[t] != 0);
+                if (llen[t] != 0) {
+                    const uint32_t slot = n_desc + (uint32_t)__popcll(found & ((1ull << lane) - 1ull));
+                    lds.desc[slot] = start[t] | ((uint64_t)llen[t] << kDescLenShift);
+                }
+                n_desc += (uint32_t)__popcll(found);
+            }
+
+            // generator of (base, count<=64) chunks over the descriptor list; all state is wave-uniform
+            uint32_t di = 0;
+            uint32_t cur_rem = 0;
+            uint64_t cur_base = 0;
+            auto next_chunk = [&](uint64_t &base, uint32_t &cnt) {
+                if (cur_rem == 0 && di < n_desc) {
+                    const uint64_t d = lds.desc[di];
+                    ++di;
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)d);
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(d >> 32));
+                    cur_base = ((uint64_t)(hi & ((1u << (kDescLenShift - 32)) - 1u)) << 32) | lo;
+                    cur_rem = hi >> (kDescLenShift - 32);
+                }
+                cnt = cur_rem < (uint32_t)kWave ? cur_rem : (uint32_t)kWave;
+                base = cur_base;
+                cur_base += cnt;
+                cur_rem -= cnt;
+            };
+            // The ring's loads are issued from inline asm so that hipcc does not count them:
+            // its own bookkeeping would drain the ring (vmcnt(0)) once per trip of the loop.
+            // Each consumer is preceded by wait_slot(): exactly kRing-1 younger ring loads
+            // exist at that point, and vmcnt retires in issue order.
+            auto issue = [&](uint64_t base, uint32_t cnt) -> v2u {
+                // buffer load with num_records = cnt postings: lanes >= cnt read nothing and get 0
+                const uint64_t addr = (uint64_t)(values + base);
+                v4i rsrc;
+                rsrc.x = (int)(uint32_t)addr;
+                rsrc.y = (int)(uint32_t)(addr >> 32);  // stride 0, no swizzle
+                rsrc.z = (int)(cnt * 8u);
+                rsrc.w = 0x00020000;
+                v2u out;
+                asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen"
+                             : "=v"(out)
+                             : "v"(lane8), "s"(rsrc)
+                             : "memory");
+                return out;
+            };
+            auto wait_slot = [&](v2u &slot) {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "i"(kRing - 1) : "memory");
+            };
+
+            v2u ring[kRing];
+            uint32_t ring_cnt[kRing];
+#pragma unroll
+            for (int i = 0; i < kRing; ++i) {
+                ring_cnt[i] = 0;
+                ring[i] = v2u{0u, 0u};
+            }
+            // Trip 0 only fills the ring; every later trip consumes slot i (oldest load)
+            // and refills it.  One loop, one asm definition per slot register: hipcc has
+            // no reason to copy a slot while its load is in flight (checked in the .s).
+            bool primed = false;
+            bool more = n_desc != 0;
+            while (more) {
+#pragma unroll
+                for (int i = 0; i < kRing; ++i) {
+                    if (primed) {
+                        if (ring_cnt[i] == 0) {  // end of the stream (chunks are handed out in order)
+                            more = false;
+                            break;
+                        }
+                        wait_slot(ring[i]);
+#ifdef EPIK_AMD_ABLATION
+                        if (p.ablate & 1u) {  // keep the load live, skip the LDS scatter-add
+                            asm volatile("" ::"v"(ring[i]));
+                        } else
+#endif
+                        accumulate_chunk<kLdsAtomic>(lds, make_uint2(ring[i].x, ring[i].y),
+                                                     (uint32_t)lane < ring_cnt[i]);
+                    }
+                    uint64_t base;
+                    next_chunk(base, ring_cnt[i]);
+                    ring[i] = issue(base, ring_cnt[i]);
+                }
+                primed = true;
+            }
+            // Zero-length loads behind the end of the stream are still in flight and hipcc
+            // does not know it: retire them before it may reuse their registers.
+            asm volatile("s_waitcnt vmcnt(0)"
+                         :
+                         : "v"(ring[0]), "v"(ring[1]), "v"(ring[2]), "v"(ring[3]), "v"(ring[4]),
+                           "v"(ring[5]), "v"(ring[6]), "v"(ring[7])
+                         : "memory");
+            static_assert(kRing == 8, "update the drain statement's operand list");
         }
 
         // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
@@ -261,8 +398,8 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
                         for (uint32_t off = 0; off < n; off += kWave) {
                             if (off + (uint32_t)lane < n) {
                                 const uint2 e = list[off + lane];
-                                const uint32_t b = e.x;
-                                const uint32_t c = lds.counts[b];
+                                uint2 cv = lds.cell[e.x];
+                                const uint32_t c = cv.y;
                                 // Only the first ambiguous key that reaches a branch scores it:
                                 // later ones find counts_amb[b] != 0 and stay out of l_amb (:385-388).
                                 if (!(c & kAmbSeen)) {
@@ -270,8 +407,9 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
                                     const float prob = (float)pow(10.0, (double)__uint_as_float(e.y));
                                     const float avg = __fdiv_rn(
                                         __fadd_rn(prob, __fmul_rn((float)(k - 1u), thr)), k_f);  // :400-402
-                                    lds.counts[b] = (c | kAmbSeen) + 1u;                          // :409
-                                    lds.scores[b] = __fadd_rn(lds.scores[b], avg);                // :410
+                                    cv.y = (c | kAmbSeen) + 1u;                                    // :409
+                                    cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), avg)); // :410
+                                    lds.cell[e.x] = cv;
                                 }
                             }
                         }
@@ -280,22 +418,33 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
             }
         }
 
+#ifdef EPIK_AMD_ABLATION
+        if (p.ablate & 2u) {  // skip the whole epilogue
+            if (lane == 0) p.n_rows[read] = 0;
+            if (!(p.ablate & 4u))
+                for (uint32_t i = lane; i < N; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+            continue;
+        }
+#endif
         // ---- score correction (:418-422) + sum_scores (:164-184), dense over N -----------
+        // cell[i].x becomes the corrected score (-inf = "not an edge"), cell[i].y the count.
         const float nk_f = (float)n_kmers;
         double sum_placed = 0.0;
         uint32_t touched = 0;
+        uint32_t lane_best = 0;  // ord key of this lane's best score; 0 = none
         for (uint32_t i = lane; i < N; i += kWave) {
-            const uint32_t c = lds.counts[i] & ~kAmbSeen;
+            uint2 cv = lds.cell[i];
+            const uint32_t c = cv.y & ~kAmbSeen;
             float s = -INFINITY;
             if (c != 0) {
-                s = lds.scores[i];
+                s = __uint_as_float(cv.x);
                 s = __fadd_rn(s, __fmul_rn((float)(n_kmers - (uint64_t)c), log_thr));  // :420
                 s = __fdiv_rn(s, k_f);                                                 // :421
                 sum_placed += pow10_f64((double)s);                                    // :181
                 ++touched;
+                lane_best = max(lane_best, ord_f32(s));
             }
-            lds.scores[i] = s;  // -inf marks "not an edge"
-            lds.counts[i] = c;
+            lds.cell[i] = make_uint2(__float_as_uint(s), c);
         }
         touched = wave_sum_u32(touched);
         sum_placed = wave_sum_f64(sum_placed);
@@ -305,71 +454,141 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
         const double score_sum = sum_not_placed + sum_placed;                       // :183
         const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;        // :247-251
 
-        // ---- select_best_placements (:134-159): lane r ends up holding row r ------------
+        // ---- select_best_placements (:134-159) ---------------------------------------------
+        // Candidates = every edge whose score reaches tau, the n_sel-th largest of the 64
+        // per-lane maxima: at least n_sel edges qualify, usually only a few more.  They are
+        // compacted into LDS and ranked by counting, rank = final row (score desc, branch asc).
         const uint32_t keep = p.keep_at_most;
-        uint32_t n_sel;
-        float row_s = 0.0f;
-        uint32_t row_b = 0, row_c = 0;
-        if (touched == 0) {  // :141-152
-            n_sel = keep;
-            row_s = thr_score;
-            row_b = (uint32_t)lane;
-            row_c = 0;
+        uint2 *cand = reinterpret_cast<uint2 *>(lds.desc);  // {ord(score), branch}
+        constexpr uint32_t kCandCap = (uint32_t)kTilesPerPass * kWave;
+        uint32_t n_sel, n_cand;
+        float best_score;
+        bool ranked_in_place = false;  // cand[] already sorted: rank == index
+        if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
+            n_sel = n_cand = keep;
+            best_score = thr_score;
+            if ((uint32_t)lane < keep) cand[lane] = make_uint2(ord_f32(thr_score), (uint32_t)lane);
+            ranked_in_place = true;
         } else {
             n_sel = keep < touched ? keep : touched;  // :137
-            uint64_t prev = ~0ull;                   // key of the previous winner
-            float stop_below = -INFINITY;
-            uint32_t r = 0;
-            for (; r < n_sel; ++r) {
-                uint64_t best = 0;  // (ord(score) << 32) | ~branch : max = higher score, then lower branch
-                for (uint32_t i = lane; i < N; i += kWave) {
-                    const float s = lds.scores[i];
-                    const uint64_t key = ((uint64_t)ord_f32(s) << 32) | (uint64_t)(~i);
-                    if (s != -INFINITY && key < prev && key > best) best = key;
+            uint32_t cur = lane_best, got = 0, tau = 1, top = 0;
+            while (got < n_sel) {
+                const uint32_t m = wave_max_u32(cur);
+                if (m == 0) {  // fewer lanes hold edges than rows wanted: every edge is a candidate
+                    tau = 1;
+                    break;
                 }
-                best = wave_max_u64(best);
-                const uint32_t bb = ~(uint32_t)best;
-                const float bs = lds.scores[bb];
-                // rows below best + log10(keep_factor) cannot pass filter_by_ratio (:188-199)
-                if (r == 0 && keep_factor > 0.0) stop_below = bs + p.log10_keep_factor_margin;
-                if (bs < stop_below) break;
-                if ((uint32_t)lane == r) {
-                    row_s = bs;
-                    row_b = bb;
-                    row_c = lds.counts[bb];
-                }
-                prev = best;
+                if (got == 0) top = m;
+                got += (uint32_t)__popcll(__ballot(cur == m));
+                tau = m;
+                if (cur == m) cur = 0;
             }
-            n_sel = r;
+            best_score = unord_f32(top);
+            n_cand = 0;
+            for (uint32_t base = 0; base < N; base += kWave) {
+                const uint32_t i = base + (uint32_t)lane;
+                uint32_t key = 0;
+                if (i < N) {
+                    const uint2 cv = lds.cell[i];
+                    if (cv.y != 0) key = ord_f32(__uint_as_float(cv.x));
+                }
+                const bool is_cand = key >= tau;  // tau >= 1, key 0 = not an edge
+                const uint64_t m = __ballot(is_cand);
+                if (m) {
+                    const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (is_cand && slot < kCandCap) cand[slot] = make_uint2(key, i);
+                    n_cand += (uint32_t)__popcll(m);
+                }
+            }
+            if (n_cand > kCandCap) {
+                // Too many ties at tau for the candidate buffer: repeated selection over all
+                // edges instead (slow, rare).  Leaves cand[0..n_sel) sorted.
+                uint64_t prev = ~0ull;
+                for (uint32_t r = 0; r < n_sel; ++r) {
+                    uint64_t best = 0;
+                    for (uint32_t i = lane; i < N; i += kWave) {
+                        const uint2 cv = lds.cell[i];
+                        const uint64_t key = ((uint64_t)ord_f32(__uint_as_float(cv.x)) << 32) | (uint64_t)(~i);
+                        if (cv.y != 0 && key < prev && key > best) best = key;
+                    }
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) {
+                        const uint64_t o = shfl_xor_u64(best, m);
+                        best = o > best ? o : best;
+                    }
+                    if (lane == 0) cand[r] = make_uint2((uint32_t)(best >> 32), ~(uint32_t)best);
+                    prev = best;
+                }
+                n_cand = n_sel;
+                ranked_in_place = true;
+            }
         }
 
-        // ---- LWR (:241-264) and filter_by_ratio (:188-199), one row per lane ---------------
-        const bool has_row = (uint32_t)lane < n_sel;
-        double lwr = 0.0;
-        if (has_row && score_sum != 0.0) {
-            const double power = pow10_f64((double)row_s);           // :254
-            lwr = (power == 0.0) ? 0.0 : power / score_sum;          // :255-262
+        // ---- rank, LWR (:241-264), filter_by_ratio (:188-199); <= 3 candidates per lane ------
+        const double best_power = pow10_f64((double)best_score);
+        const double best_ratio =
+            (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
+        const double ratio_threshold = best_ratio * keep_factor;                      // :192
+        const uint32_t n_q = (n_cand + kWave - 1) / kWave;
+        uint64_t my_key[kTilesPerPass];
+        uint32_t my_rank[kTilesPerPass];
+        double my_lwr[kTilesPerPass];
+#pragma unroll
+        for (int q = 0; q < kTilesPerPass; ++q) {
+            const uint32_t idx = (uint32_t)q * kWave + (uint32_t)lane;
+            my_key[q] = 0;
+            my_rank[q] = ranked_in_place ? idx : 0u;
+            my_lwr[q] = 0.0;
+            if ((uint32_t)q < n_q && idx < n_cand) {
+                const uint2 c = cand[idx];
+                my_key[q] = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
+            }
         }
-        const double best_ratio = readlane0_f64(lwr);              // :191, rows are sorted
-        const double ratio_threshold = best_ratio * keep_factor;    // :192
-        const bool kept = has_row && lwr >= ratio_threshold;        // :197
-        const uint64_t kept_mask = __ballot(kept);
-        if (kept) {
-            const uint32_t slot = (uint32_t)__popcll(kept_mask & ((1ull << lane) - 1ull));
-            epik_amd_placement out;
-            out.branch = row_b;
-            out.score = row_s;
-            out.lwr = lwr;
-            p.rows[read * keep + slot] = out;
-            if (p.kmer_counts) p.kmer_counts[read * keep + slot] = row_c;
+        if (!ranked_in_place) {
+            for (uint32_t j = 0; j < n_cand; ++j) {
+                const uint2 c = cand[j];  // same address in every lane: LDS broadcast
+                const uint64_t kj = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
+                my_rank[0] += kj > my_key[0] ? 1u : 0u;
+                if (n_q > 1) {
+#pragma unroll
+                    for (int q = 1; q < kTilesPerPass; ++q) my_rank[q] += kj > my_key[q] ? 1u : 0u;
+                }
+            }
         }
-        if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_mask);
+        uint64_t kept_ranks = 0;  // bit r set <=> the row of rank r passes the filter
+#pragma unroll
+        for (int q = 0; q < kTilesPerPass; ++q) {
+            if ((uint32_t)q < n_q) {
+                const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
+                if (has_row && score_sum != 0.0) {
+                    const double power = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));  // :254
+                    my_lwr[q] = (power == 0.0) ? 0.0 : power / score_sum;                             // :255-262
+                }
+                if (has_row && my_lwr[q] >= ratio_threshold) kept_ranks |= 1ull << my_rank[q];      // :197
+            }
+        }
+        kept_ranks = wave_or_u64(kept_ranks);
+#pragma unroll
+        for (int q = 0; q < kTilesPerPass; ++q) {
+            if ((uint32_t)q < n_q) {
+                const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
+                if (has_row && ((kept_ranks >> my_rank[q]) & 1ull)) {
+                    const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << my_rank[q]) - 1ull));
+                    const uint32_t branch = ~(uint32_t)my_key[q];
+                    epik_amd_placement out;
+                    out.branch = branch;
+                    out.score = unord_f32((uint32_t)(my_key[q] >> 32));
+                    out.lwr = my_lwr[q];
+                    p.rows[read * keep + slot] = out;
+                    if (p.kmer_counts)
+                        p.kmer_counts[read * keep + slot] = (touched && branch < N) ? lds.cell[branch].y : 0u;
+                }
+            }
+        }
+        if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
 
         // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
-        for (uint32_t i = lane; i < N; i += kWave) {
-            lds.scores[i] = 0.0f;
-            lds.counts[i] = 0u;
-        }
+        for (uint32_t i = lane; i < N; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
     }
 }
 

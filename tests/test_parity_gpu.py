@@ -137,3 +137,23 @@ def test_placer_place_mirrors_reference_contract(placer_cls, oracle_lib, small_c
         if p.count:
             assert p.distal_length == pytest.approx(tree.branch_length[p.branch_id] / 2)
     assert out.placed_seqs[2].placements == []      # shorter than k
+
+
+def test_many_ties_overflow_candidate_buffer(placer_cls, oracle_lib):
+    """Every posting has the same score and every list covers all branches, so all
+    N=301 corrected scores tie: more candidates than the kernel's LDS candidate
+    buffer (192) -> the slow repeated-selection path; ties resolve by branch asc."""
+    tree = synth.make_tree(151, seed=3)
+    n = tree.num_nodes
+    k, sigma = 4, 4
+    num_keys = sigma ** k
+    offsets = (np.arange(num_keys + 1, dtype=np.uint64) * np.uint64(n))
+    values = np.zeros(num_keys * n, dtype=synth.PKDB_VALUE)
+    values["branch"] = np.tile(np.arange(n, dtype=np.uint32), num_keys)
+    values["score"] = np.float32(-1.25)
+    db = synth.SynthDB(states="nucl", kmer_size=k, omega=1.5, num_branches=n, offsets=offsets,
+                       values=values)
+    data, offs = synth.make_reads(300, 40, seed=5)
+    for keep_at_most, keep_factor in [(7, 0.01), (64, 0.0)]:
+        _compare(placer_cls, oracle_lib, db, data, offs, keep_at_most=keep_at_most,
+                 keep_factor=keep_factor)
