@@ -283,7 +283,8 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
     if (!seqs || !seq_offsets || !rows || !n_rows) return fail(EPIK_AMD_ERR_INVALID, "null host buffer");
     if (seq_offsets[0] != 0) return fail(EPIK_AMD_ERR_INVALID, "seq_offsets[0] must be 0");
     for (uint64_t i = 0; i < n; ++i)
-        if (seq_offsets[i + 1] < seq_offsets[i]) return fail(EPIK_AMD_ERR_INVALID, "seq_offsets not monotone");
+        if (seq_offsets[i + 1] < seq_offsets[i] || seq_offsets[i + 1] - seq_offsets[i] > 0xffffffffull)
+            return fail(EPIK_AMD_ERR_INVALID, "seq_offsets not monotone, or a read of 2^32 characters or more");
     HIP_TRY(hipSetDevice(p->device));
     const size_t seq_bytes = (size_t)seq_offsets[n];
     if (seq_bytes + 64 > p->d_seqs_cap) {

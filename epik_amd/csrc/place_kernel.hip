@@ -31,7 +31,10 @@ namespace {
 constexpr int kWave = 64;
 constexpr uint32_t kAmbSeen = 0x80000000u;  // counts[] bit: branch already scored by an ambiguous key
 constexpr int kTilesPerPass = EPIK_AMD_TILES_PER_PASS;  // 64-character tiles encoded per pass
-constexpr int kRing = 8;            // posting-chunk loads kept in flight per wave
+#ifndef EPIK_AMD_RING
+#define EPIK_AMD_RING 8
+#endif
+constexpr int kRing = EPIK_AMD_RING;  // posting-chunk loads kept in flight per wave
 constexpr int kDescLenShift = 40;   // descriptor = start (40 bits) | len << 40 (24 bits)
 
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
         const uint64_t seq_begin = p.seq_offsets[read];
         const uint64_t len = p.seq_offsets[read + 1] - seq_begin;
         const uint8_t *__restrict__ seq = p.seqs + seq_begin;
-        if (len < k) {  // place.cpp:322 underflows here; we report "no placement"
+        if (len < k || len > 0xffffffffull) {  // place.cpp:322 underflows for len < k; we report "no placement"
             if (lane == 0) p.n_rows[read] = 0;
             continue;
         }
@@ -360,12 +363,11 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
             }
             // Zero-length loads behind the end of the stream are still in flight and hipcc
             // does not know it: retire them before it may reuse their registers.
-            asm volatile("s_waitcnt vmcnt(0)"
-                         :
-                         : "v"(ring[0]), "v"(ring[1]), "v"(ring[2]), "v"(ring[3]), "v"(ring[4]),
-                           "v"(ring[5]), "v"(ring[6]), "v"(ring[7])
-                         : "memory");
-            static_assert(kRing == 8, "update the drain statement's operand list");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // volatile asm statements keep their order: naming every slot AFTER the wait
+            // keeps its register allocated (not reusable by hipcc) until the wait has run
+#pragma unroll
+            for (int i = 0; i < kRing; ++i) asm volatile("" ::"v"(ring[i]));
         }
 
         // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
@@ -426,10 +428,10 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
             continue;
         }
 #endif
-        // ---- score correction (:418-422) + sum_scores (:164-184), dense over N -----------
+        // ---- score correction (:418-422), dense over N --------------------------------------
         // cell[i].x becomes the corrected score (-inf = "not an edge"), cell[i].y the count.
         const float nk_f = (float)n_kmers;
-        double sum_placed = 0.0;
+        const uint32_t nk_u = (uint32_t)n_kmers;  // the host rejects reads of 2^32 characters or more
         uint32_t touched = 0;
         uint32_t lane_best = 0;  // ord key of this lane's best score; 0 = none
         for (uint32_t i = lane; i < N; i += kWave) {
@@ -438,32 +440,34 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
             float s = -INFINITY;
             if (c != 0) {
                 s = __uint_as_float(cv.x);
-                s = __fadd_rn(s, __fmul_rn((float)(n_kmers - (uint64_t)c), log_thr));  // :420
-                s = __fdiv_rn(s, k_f);                                                 // :421
-                sum_placed += pow10_f64((double)s);                                    // :181
+                s = __fadd_rn(s, __fmul_rn((float)(nk_u - c), log_thr));  // :420
+                s = __fdiv_rn(s, k_f);                                    // :421
                 ++touched;
                 lane_best = max(lane_best, ord_f32(s));
             }
             lds.cell[i] = make_uint2(__float_as_uint(s), c);
         }
         touched = wave_sum_u32(touched);
-        sum_placed = wave_sum_f64(sum_placed);
         const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
-        const double p_thr = pow10_f64((double)thr_score);
-        const double sum_not_placed = (double)((float)N - (float)touched) * p_thr;  // :174-175
-        const double score_sum = sum_not_placed + sum_placed;                       // :183
-        const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;        // :247-251
 
-        // ---- select_best_placements (:134-159) ---------------------------------------------
+        // ---- select_best_placements (:134-159) + sum_scores (:164-184) --------------------
         // Candidates = every edge whose score reaches tau, the n_sel-th largest of the 64
         // per-lane maxima: at least n_sel edges qualify, usually only a few more.  They are
         // compacted into LDS and ranked by counting, rank = final row (score desc, branch asc).
+        // The same sweep accumulates sum_scores relative to the largest term, 10^ref_score:
+        //   score_sum = 10^ref_score * (sum_i 10^(score_i - ref_score) + (N - n) * 10^(thr - ref_score))
+        // with the relative terms in float32 (v_exp_f32): ~1e-7 relative on score_sum, i.e. on
+        // every like_weight_ratio (bar: 1e-5).  Row scores and 10^ref_score stay in double, and
+        // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
         const uint32_t keep = p.keep_at_most;
         uint2 *cand = reinterpret_cast<uint2 *>(lds.desc);  // {ord(score), branch}
         constexpr uint32_t kCandCap = (uint32_t)kTilesPerPass * kWave;
+        constexpr float kLog2Of10 = 3.32192809488736f;
         uint32_t n_sel, n_cand;
         float best_score;
+        float rel_sum = 0.0f;          // this lane's share of sum_i 10^(score_i - ref_score)
         bool ranked_in_place = false;  // cand[] already sorted: rank == index
+        uint32_t tau = 1;
         if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
             n_sel = n_cand = keep;
             best_score = thr_score;
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
             ranked_in_place = true;
         } else {
             n_sel = keep < touched ? keep : touched;  // :137
-            uint32_t cur = lane_best, got = 0, tau = 1, top = 0;
+            uint32_t cur = lane_best, got = 0, top = 0;
             while (got < n_sel) {
                 const uint32_t m = wave_max_u32(cur);
                 if (m == 0) {  // fewer lanes hold edges than rows wanted: every edge is a candidate
@@ -484,13 +488,21 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
                 if (cur == m) cur = 0;
             }
             best_score = unord_f32(top);
+        }
+        const float ref_score = fmaxf(best_score, thr_score);
+        const bool relative_sum = ref_score > -280.0f;  // wave-uniform
+        if (touched != 0) {
             n_cand = 0;
             for (uint32_t base = 0; base < N; base += kWave) {
                 const uint32_t i = base + (uint32_t)lane;
                 uint32_t key = 0;
                 if (i < N) {
                     const uint2 cv = lds.cell[i];
-                    if (cv.y != 0) key = ord_f32(__uint_as_float(cv.x));
+                    if (cv.y != 0) {
+                        const float sc = __uint_as_float(cv.x);
+                        key = ord_f32(sc);
+                        rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
+                    }
                 }
                 const bool is_cand = key >= tau;  // tau >= 1, key 0 = not an edge
                 const uint64_t m = __ballot(is_cand);
@@ -523,6 +535,27 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
                 ranked_in_place = true;
             }
         }
+        double score_sum;
+        {
+            const float not_placed = (float)N - (float)touched;  // :174
+            if (relative_sum) {
+                double rel = wave_sum_f64((double)rel_sum);
+                if (not_placed != 0.0f)
+                    rel += (double)(not_placed *
+                                    __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
+                score_sum = pow10_f64((double)ref_score) * rel;
+            } else {
+                // everything in double, term by term, as place.cpp:174-183
+                double sum_placed = 0.0;
+                for (uint32_t i = lane; i < N; i += kWave) {
+                    const uint2 cv = lds.cell[i];
+                    if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
+                }
+                sum_placed = wave_sum_f64(sum_placed);
+                score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
+            }
+        }
+        const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
 
         // ---- rank, LWR (:241-264), filter_by_ratio (:188-199); <= 3 candidates per lane ------
         const double best_power = pow10_f64((double)best_score);

@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path, called through the C-ABI, against the CPU
 oracle on the same seeded inputs.  Bar (BASELINE.json north_star): branch ids in
 identical order, float32 scores bit-identical, |delta like_weight_ratio| <= 1e-5
-(observed: ~1e-16, only libm-vs-device pow ulps)."""
+(observed: ~1e-7, from the float32 relative accumulation of score_sum)."""
 import json
 import os
 
@@ -68,7 +68,9 @@ def test_config1_shape_k10(placer_cls, oracle_lib, lds_atomic, monkeypatch):
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
     data, offs = synth.make_reads(20000, 150, seed=44)
     worst = _compare(placer_cls, oracle_lib, db, data, offs)
-    assert worst < 1e-9
+    # score_sum is accumulated relative to its largest term in float32 (v_exp_f32):
+    # observed |delta LWR| ~1e-7; the bar is 1e-5
+    assert worst < 2e-6
 
 
 def test_scattered_branches_and_long_reads(placer_cls, oracle_lib):
