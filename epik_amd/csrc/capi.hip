@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "epik_amd.h"
 #include "place_kernel.h"
@@ -45,10 +46,13 @@ constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // gfx950: 160 KiB per CU
 struct epik_amd_placer {
     int device = 0;
     bool offsets64 = false;
-    bool lds_atomic = true;
+    epik_amd::DbLayout layout = epik_amd::DbLayout::kCompact32;
+    bool lds_atomic = false;
     bool timing = false;
-    void *d_offsets = nullptr;
+    void *d_offsets = nullptr;   // compact layout
     uint2 *d_values = nullptr;
+    uint8_t *d_db = nullptr;     // slotted layout: slot table + tail region
+    uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
     epik_amd::PlaceParams params{};  // batch fields are filled per call
     uint64_t num_keys = 0;
@@ -89,6 +93,7 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipSetDevice(p->device);
     (void)hipFree(p->d_offsets);
     (void)hipFree(p->d_values);
+    (void)hipFree(p->d_db);
     (void)hipFree(p->d_char_class);
     (void)hipFree(p->d_seqs);
     (void)hipFree(p->d_seq_offsets);
@@ -156,6 +161,14 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
 
     epik_amd_placer *p = new (std::nothrow) epik_amd_placer();
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
+#define CREATE_TRY(expr)                                  \
+    do {                                                  \
+        const hipError_t e_ = (expr);                     \
+        if (e_ != hipSuccess) {                           \
+            epik_amd_placer_destroy(p);                   \
+            return fail_hip(e_, #expr);                   \
+        }                                                 \
+    } while (0)
     p->device = d->device;
     p->offsets64 = d->offset_bits == 64;
     p->num_keys = d->num_keys;
@@ -171,31 +184,114 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
         }
     }
 
-#define CREATE_TRY(expr)                                  \
-    do {                                                  \
-        const hipError_t e_ = (expr);                     \
-        if (e_ != hipSuccess) {                           \
-            epik_amd_placer_destroy(p);                   \
-            return fail_hip(e_, #expr);                   \
-        }                                                 \
-    } while (0)
 
-    const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
-    const size_t val_bytes = (size_t)d->num_entries * sizeof(epik_amd_pkdb_value);
-    CREATE_TRY(hipMalloc(&p->d_offsets, off_bytes));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_values), val_bytes ? val_bytes : 8));
+    // ---- choose the HBM layout ---------------------------------------------------------
+    // Slotted (one 128-byte line per k-mer code, short lists inline, 6-byte postings) moves
+    // ~25 % fewer bytes per read but costs num_keys * 128 bytes of table; it is eligible when
+    // that is at most a quarter of the device's free memory.  EPIK_AMD_LAYOUT=compact|slotted
+    // overrides the default.
+    size_t free_mem = 0, total_mem = 0;
+    CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
+    const uint64_t slot_bytes = 128;
+    const bool narrow = d->num_branches <= 65536u;
+    const uint32_t posting_bytes = narrow ? 6u : 8u;
+    const uint32_t slot_cap = (uint32_t)((slot_bytes - 8u) / posting_bytes);
+    const bool slotted_fits = d->num_keys * slot_bytes <= free_mem / 4;
+    bool slotted = false;  // measured: the compact CSR is the faster of the two today
+    if (const char *lay = std::getenv("EPIK_AMD_LAYOUT")) {
+        if (std::strcmp(lay, "compact") == 0) slotted = false;
+        else if (std::strcmp(lay, "slotted") == 0) slotted = slotted_fits;
+    }
+    auto offset_at = [&](uint64_t key) -> uint64_t {
+        return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
+                            : static_cast<const uint32_t *>(d->offsets)[key];
+    };
+    for (uint64_t key = 0; key < d->num_keys; ++key) {
+        if (offset_at(key + 1) < offset_at(key)) {
+            epik_amd_placer_destroy(p);
+            return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
+        }
+        if (offset_at(key + 1) - offset_at(key) >= (1ull << 24)) {
+            epik_amd_placer_destroy(p);
+            return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
+        }
+    }
+    epik_amd::PlaceParams &pp = p->params;
+    if (slotted) {
+        p->layout = narrow ? epik_amd::DbLayout::kSlotted16 : epik_amd::DbLayout::kSlotted32;
+        // tail size: lists longer than a slot's payload, each padded to 128 bytes
+        const uint64_t table_bytes = d->num_keys * slot_bytes;
+        uint64_t tail_units = 0;
+        for (uint64_t key = 0; key < d->num_keys; ++key) {
+            const uint64_t len = offset_at(key + 1) - offset_at(key);
+            if (len > slot_cap) tail_units += (len * posting_bytes + 127u) / 128u;
+        }
+        if (tail_units >= (1ull << 32)) {
+            epik_amd_placer_destroy(p);
+            return fail(EPIK_AMD_ERR_UNSUPPORTED, "tail region of 512 GiB or more");
+        }
+        p->db_bytes = table_bytes + tail_units * 128u + 256u;  // +256: the kernel's loads stay inside
+        std::vector<uint8_t> host;
+        try {
+            host.assign(p->db_bytes, 0);
+        } catch (const std::bad_alloc &) {
+            epik_amd_placer_destroy(p);
+            return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the slotted database");
+        }
+        // one list = chunks of <= 64 postings, each chunk: f32 score[cnt] then branch[cnt]
+        auto write_list = [&](uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len) {
+            for (uint64_t c0 = 0; c0 < len; c0 += 64) {
+                const uint32_t cnt = (uint32_t)((len - c0 < 64) ? len - c0 : 64);
+                float *scores = reinterpret_cast<float *>(dst);
+                for (uint32_t j = 0; j < cnt; ++j) scores[j] = src[c0 + j].score;
+                if (narrow) {
+                    uint16_t *br = reinterpret_cast<uint16_t *>(dst + 4u * cnt);
+                    for (uint32_t j = 0; j < cnt; ++j) br[j] = (uint16_t)src[c0 + j].branch;
+                } else {
+                    uint32_t *br = reinterpret_cast<uint32_t *>(dst + 4u * cnt);
+                    for (uint32_t j = 0; j < cnt; ++j) br[j] = src[c0 + j].branch;
+                }
+                dst += (size_t)cnt * posting_bytes;
+            }
+        };
+        uint64_t unit = 0;
+        for (uint64_t key = 0; key < d->num_keys; ++key) {
+            const uint64_t b = offset_at(key), len = offset_at(key + 1) - b;
+            uint8_t *slot = host.data() + key * slot_bytes;
+            uint32_t hdr[2] = {(uint32_t)len, 0u};
+            if (len > slot_cap) {
+                hdr[1] = (uint32_t)unit;
+                write_list(host.data() + table_bytes + unit * 128u, d->values + b, len);
+                unit += (len * posting_bytes + 127u) / 128u;
+            } else if (len) {
+                write_list(slot + 8, d->values + b, len);
+            }
+            std::memcpy(slot, hdr, 8);
+        }
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_db), p->db_bytes));
+        CREATE_TRY(hipMemcpy(p->d_db, host.data(), p->db_bytes, hipMemcpyHostToDevice));
+        pp.db = p->d_db;
+        pp.tail_offset = table_bytes;
+        pp.slot_bytes = (uint32_t)slot_bytes;
+        pp.slot_cap = slot_cap;
+    } else {
+        p->layout = p->offsets64 ? epik_amd::DbLayout::kCompact64 : epik_amd::DbLayout::kCompact32;
+        const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
+        const size_t val_bytes = (size_t)d->num_entries * sizeof(epik_amd_pkdb_value);
+        CREATE_TRY(hipMalloc(&p->d_offsets, off_bytes));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_values), val_bytes ? val_bytes : 8));
+        CREATE_TRY(hipMemcpy(p->d_offsets, d->offsets, off_bytes, hipMemcpyHostToDevice));
+        if (val_bytes) CREATE_TRY(hipMemcpy(p->d_values, d->values, val_bytes, hipMemcpyHostToDevice));
+        pp.offsets = p->d_offsets;
+        pp.values = p->d_values;
+    }
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_char_class), 256 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_total), sizeof(unsigned long long)));
-    CREATE_TRY(hipMemcpy(p->d_offsets, d->offsets, off_bytes, hipMemcpyHostToDevice));
-    if (val_bytes) CREATE_TRY(hipMemcpy(p->d_values, d->values, val_bytes, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(p->d_char_class, d->char_class, 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&p->ev_start));
     CREATE_TRY(hipEventCreate(&p->ev_stop));
 
-    epik_amd::PlaceParams &pp = p->params;
-    pp.offsets = p->d_offsets;
-    pp.values = p->d_values;
     pp.char_class = p->d_char_class;
     pp.kmer_size = d->kmer_size;
     pp.alphabet_size = d->alphabet_size;
@@ -207,7 +303,8 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     pp.log10_keep_factor_margin =
         d->keep_factor > 0.0 ? (float)(std::log10(d->keep_factor) - 1e-3) : -INFINITY;
     pp.n_pad = (d->num_branches + 63u) & ~63u;
-    pp.lds_wave_bytes = pp.n_pad * 8u + EPIK_AMD_TILES_PER_PASS * 64u * 8u;
+    // cells + chunk descriptors of one round + one trip of spare entries (the kernel prefetches a trip ahead)
+    pp.lds_wave_bytes = pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
     pp.ablate = 0;
 #ifdef EPIK_AMD_ABLATION
     if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
@@ -222,13 +319,13 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     while (p->waves_per_block > 1 && p->waves_per_block * pp.lds_wave_bytes > kMaxLdsPerBlock / 2)
         p->waves_per_block >>= 1;
     p->lds_block_bytes = p->waves_per_block * pp.lds_wave_bytes;
-    CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->lds_block_bytes));
+    CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, p->lds_atomic, p->lds_block_bytes));
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, d->device));
     // persistent-style grid: exactly the workgroups that are resident at once
     // (registers, LDS and the 32-waves/CU cap decide), each striding over the reads
     int per_cu = 0;
-    CREATE_TRY(epik_amd::place_reads_occupancy(p->offsets64, p->lds_atomic, (int)(p->waves_per_block * 64u),
+    CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, p->lds_atomic, (int)(p->waves_per_block * 64u),
                                                p->lds_block_bytes, &per_cu));
     if (per_cu < 1) per_cu = 1;
     p->max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
@@ -253,7 +350,7 @@ static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offs
     if (blocks > p->max_blocks) blocks = p->max_blocks;
     p->last_blocks = (uint32_t)blocks;
     if (p->timing) HIP_TRY(hipEventRecord(p->ev_start, stream));
-    HIP_TRY(epik_amd::launch_place_reads(pp, p->offsets64, p->lds_atomic, dim3((unsigned)blocks),
+    HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->lds_atomic, dim3((unsigned)blocks),
                                          dim3(p->waves_per_block * 64u), p->lds_block_bytes, stream));
     if (p->timing) {
         HIP_TRY(hipEventRecord(p->ev_stop, stream));
@@ -345,7 +442,7 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
     pp.n_reads = n;
     pp.n_rows = const_cast<uint32_t *>(static_cast<const uint32_t *>(d_n_rows));
     HIP_TRY(hipMemsetAsync(p->d_total, 0, sizeof(unsigned long long), s));
-    HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->offsets64, p->d_total, s));
+    HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->layout, p->d_total, s));
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, p->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
-"""Lints the generated ISA of place_kernel.hip for the one hazard hipcc cannot see:
-the ring's posting loads are issued from inline asm (uncounted by hipcc's s_waitcnt
-bookkeeping), so any compiler-generated instruction that READS or WRITES a ring
-register outside the consume blocks could touch it while its load is in flight.
+"""Lints the generated ISA of place_kernel.hip for the one hazard hipcc cannot see.
 
-Rule checked per kernel: every register that is the destination of an asm
-`buffer_load_dwordx2` may appear, outside ;;#ASMSTART/;;#ASMEND blocks, only
- (a) as a source of the consume instructions (v_lshlrev_b32 / ds_add_f32 / v_add_f32
-     operands that follow an asm `s_waitcnt vmcnt(N)`), or
- (b) as the destination of a ds_read_b64 / v_mov that is followed, before the next
-     asm load into the same register, by no asm wait (descriptor temporaries and the
-     zero-initialisation ahead of the loop).
-Anything else -- in particular a v_mov FROM a ring register -- fails the lint.
+The ring's posting loads are issued from inline asm (uncounted by hipcc's s_waitcnt
+bookkeeping), so a compiler-generated copy of a ring register made while its load is
+still in flight would capture stale data.  Every ring stage is, in program order,
+
+    asm: s_waitcnt vmcnt(N)        wait for slot i (the oldest load)
+    compiler code                  may copy / use slot i's registers
+    asm: buffer_load_* -> slot i   refill
+
+and the kernel moves the slot's values out INSIDE the wait statement, so between the
+first and the last asm load of the loop no compiler-generated instruction may name a
+ring register at all.  Anything that does fails the lint.
+Usage: lint_ring_asm.py place_kernel.s
 """
 import re
 import sys
 
 
 def regs_of(token):
+    token = token.strip().rstrip(",")
     m = re.fullmatch(r"v\[(\d+):(\d+)\]", token)
     if m:
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
@@ -25,63 +27,81 @@ def regs_of(token):
     return {int(m.group(1))} if m else set()
 
 
-def lint(path):
-    text = open(path).read().split("\n")
-    problems = []
-    kernel = None
-    ring = set()
-    body = []
-    for line in text:
+def kernels(lines):
+    name, body = None, []
+    for line in lines:
         m = re.match(r"^(_ZN8epik_amd18place_reads_kernel\w+):", line)
         if m:
-            kernel, ring, body = m.group(1), set(), []
+            name, body = m.group(1), []
             continue
-        if kernel and line.startswith("\t.end_amdhsa_kernel"):
-            kernel = None
-        if kernel:
+        if name:
             body.append(line)
             if line.strip().startswith("s_endpgm"):
+                yield name, body
+                name = None
+
+
+def lint(path):
+    problems = []
+    for name, body in kernels(open(path).read().split("\n")):
+        # events: (line, kind, regs) with kind in {"wait", "drain", "load"}
+        events, in_asm, ring = [], False, set()
+        for n, l in enumerate(body):
+            s = l.strip()
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif s.startswith(";;#ASMEND"):
                 in_asm = False
-                for l in body:
-                    s = l.strip()
-                    if s.startswith(";;#ASMSTART"):
-                        in_asm = True
-                    elif s.startswith(";;#ASMEND"):
-                        in_asm = False
-                    elif in_asm and s.startswith("buffer_load_dwordx2"):
-                        ring |= regs_of(s.split()[1].rstrip(","))
-                # the ring loop is contiguous in the .s: from the first asm load to a margin
-                # behind the last one (its exit blocks, which run before the vmcnt(0) drain)
-                load_lines = [n for n, l in enumerate(body) if l.strip().startswith("buffer_load_dwordx2")
-                              and n > 0 and "s_nop" in body[n - 1]]
-                lo, hi = (load_lines[0], load_lines[-1] + 60) if load_lines else (0, -1)
+            elif in_asm and s.startswith(("buffer_load_", "global_load_")):
+                dst = regs_of(s.split()[1])
+                ring |= dst
+                events.append((n, "load", dst))
+            elif in_asm and s.startswith("s_waitcnt vmcnt("):
+                events.append((n, "drain" if "vmcnt(0)" in s else "wait", set()))
+        if not ring:
+            problems.append(f"{name}: no asm ring loads found")
+            continue
+        # The ring loop is contiguous in the .s: from its first asm wait to a margin behind
+        # its last asm load (the fall-through into the tail, which still runs before the drain).  Walk it in
+        # program order with a per-register state: a slot register is IN FLIGHT from its asm
+        # load until the asm wait that moves it out (`s_waitcnt vmcnt(N)` + `v_mov_b32 x, R`);
+        # between that wait and the refill the register is dead and hipcc may reuse it.
+        # The loop is cyclic, so at its top every slot counts as in flight.
+        waits = [e[0] for e in events if e[1] == "wait"]
+        loads = [e[0] for e in events if e[1] == "load"]
+        lo, hi = min(waits[0], loads[0]), loads[-1] + 15
+        inflight = set(ring)
+        in_asm = False
+        for n, l in enumerate(body):
+            s = l.strip()
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if s.startswith(";;#ASMEND"):
                 in_asm = False
-                for n, l in enumerate(body):
-                    s = l.strip()
-                    if s.startswith(";;#ASMSTART"):
-                        in_asm = True
-                        continue
-                    if s.startswith(";;#ASMEND"):
-                        in_asm = False
-                        continue
-                    if in_asm or not s or s.startswith((";", ".")) or not (lo <= n <= hi):
-                        continue
-                    ops = s.split(None, 1)
-                    if len(ops) < 2:
-                        continue
-                    operands = [o.strip() for o in ops[1].split(",")]
-                    srcs = set()
-                    for o in operands[1:]:
-                        srcs |= regs_of(o.split()[0]) if o else set()
-                    if ops[0].startswith("v_mov") and srcs & ring:
-                        problems.append(f"{kernel}: copy FROM ring register: {s}")
-                body = []
+                continue
+            if not (lo <= n <= hi) or not s or s.startswith((";", ".")):
+                continue
+            parts = s.split(None, 1)
+            operands = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+            if in_asm:
+                if s.startswith(("buffer_load_", "global_load_")):
+                    inflight |= regs_of(operands[0])
+                elif s.startswith("v_mov_b32") and len(operands) == 2:
+                    inflight -= regs_of(operands[1])  # moved out behind the wait of this statement
+                continue
+            touched = set()
+            for o in operands:
+                if o:
+                    touched |= regs_of(o.split()[0])
+            if touched & inflight:
+                problems.append(f"{name}: line {n}: compiler code touches an in-flight ring register: {s}")
     return problems
 
 
 if __name__ == "__main__":
     out = lint(sys.argv[1])
-    for p in out:
+    for p in out[:40]:
         print("LINT:", p)
     print(f"ring-asm lint: {len(out)} problem(s)")
     sys.exit(1 if out else 0)

@@ -9,14 +9,31 @@
 #include "epik_amd.h"
 
 #define EPIK_AMD_TILES_PER_PASS 3
+#ifndef EPIK_AMD_RING
+#define EPIK_AMD_RING 8  // posting-chunk loads kept in flight per wave (power of two)
+#endif
 
 namespace epik_amd {
 
-// Kernel arguments: the database in HBM (CSR-like: code -> offsets -> postings),
-// the placer constants of place.cpp:83-96, and one batch of reads.
+// How the phylo-k-mer database is laid out in HBM (place_kernel.hip documents both).
+enum class DbLayout : int {
+    kCompact32 = 0,  // CSR, 32-bit offsets, 8-byte postings
+    kCompact64 = 1,  // CSR, 64-bit offsets
+    kSlotted16 = 2,  // 128-byte slot per k-mer code + tail region, 16-bit branch ids
+    kSlotted32 = 3,  // same with 32-bit branch ids (num_branches > 65536)
+};
+
+// Kernel arguments: the database in HBM, the placer constants of place.cpp:83-96, and
+// one batch of reads.
 struct PlaceParams {
+    // compact layout
     const void *offsets;         // OffT[num_keys + 1]
     const uint2 *values;         // {branch, float bits of log10 score}[num_entries]
+    // slotted layout
+    const uint8_t *db;           // slot table, then the tail region
+    uint64_t tail_offset;        // byte offset of the tail region = num_keys * slot_bytes
+    uint32_t slot_bytes;         // 128
+    uint32_t slot_cap;           // postings that fit a slot's payload
     const uint32_t *char_class;  // [256]
     const uint8_t *seqs;
     const uint64_t *seq_offsets; // [n_reads + 1]
@@ -37,13 +54,13 @@ struct PlaceParams {
     uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
 };
 
-hipError_t launch_place_reads(const PlaceParams &p, bool offsets64, bool lds_atomic, dim3 grid,
-                              dim3 block, size_t lds_bytes, hipStream_t stream);
-hipError_t set_place_reads_lds_limit(size_t lds_bytes);
-hipError_t place_reads_occupancy(bool offsets64, bool lds_atomic, int block_threads, size_t lds_bytes,
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool lds_atomic, dim3 grid, dim3 block,
+                              size_t lds_bytes, hipStream_t stream);
+hipError_t set_place_reads_lds_limit(DbLayout layout, bool lds_atomic, size_t lds_bytes);
+hipError_t place_reads_occupancy(DbLayout layout, bool lds_atomic, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu);
-hipError_t launch_algorithmic_bytes(const PlaceParams &p, bool offsets64,
-                                    unsigned long long *d_total, hipStream_t stream);
+hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
+                                    hipStream_t stream);
 
 }  // namespace epik_amd
 #endif

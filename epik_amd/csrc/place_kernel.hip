@@ -31,11 +31,9 @@ namespace {
 constexpr int kWave = 64;
 constexpr uint32_t kAmbSeen = 0x80000000u;  // counts[] bit: branch already scored by an ambiguous key
 constexpr int kTilesPerPass = EPIK_AMD_TILES_PER_PASS;  // 64-character tiles encoded per pass
-#ifndef EPIK_AMD_RING
-#define EPIK_AMD_RING 8
-#endif
 constexpr int kRing = EPIK_AMD_RING;  // posting-chunk loads kept in flight per wave
-constexpr int kDescLenShift = 40;   // descriptor = start (40 bits) | len << 40 (24 bits)
+static_assert((kRing & (kRing - 1)) == 0 && kRing >= 2 && kRing <= 32, "kRing: power of two, one descriptor lane per stage");
+constexpr uint32_t kChunkCap = (uint32_t)kTilesPerPass * 64u;  // chunk descriptors per round (LDS)
 
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -118,6 +116,25 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return (rl(0) + rl(16)) + (rl(32) + rl(48));
 }
 
+// Inclusive prefix sum over the 64 lanes (row_shr DPP inside rows of 16, then the row totals).
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_zero_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += dpp_zero_u32<0x111>(v);  // row_shr:1
+    v += dpp_zero_u32<0x112>(v);  // row_shr:2
+    v += dpp_zero_u32<0x114>(v);  // row_shr:4
+    v += dpp_zero_u32<0x118>(v);  // row_shr:8
+    const uint32_t r0 = __builtin_amdgcn_readlane(v, 15);
+    const uint32_t r1 = __builtin_amdgcn_readlane(v, 31);
+    const uint32_t r2 = __builtin_amdgcn_readlane(v, 47);
+    const uint32_t row = (uint32_t)__lane_id() >> 4;
+    return v + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
+}
+
 // inverse of ord_f32
 __device__ __forceinline__ float unord_f32(uint32_t o)
 {
@@ -128,15 +145,118 @@ __device__ __forceinline__ float unord_f32(uint32_t o)
 // the device routine differs from it by ulps, which is far inside the 1e-5 LWR bar.
 __device__ __forceinline__ double pow10_f64(double x) { return exp10(x); }
 
+// ---------------------------------------------------------------------------------
+// Database layouts in HBM.  Both answer phylo_kmer_db::search (place.cpp:300,311): a
+// k-mer code -> (opaque 40-bit address, list length); the wave then streams the list
+// in chunks of <= 64 postings.  `issue` puts one chunk's loads in flight from inline
+// asm (hipcc must not count them, see the ring below); `load_posting` is the plain,
+// compiler-counted access of the cold ambiguous path.
+// ---------------------------------------------------------------------------------
+
+// Compact CSR: offsets[code .. code+1] into an array of 8-byte {branch, score} postings,
+// exactly i2l::pkdb_value.  Address unit = one posting.  Used when the slot table of the
+// layout below would not fit.
 template <typename OffT>
-__device__ __forceinline__ void load_range(const OffT *__restrict__ offsets, uint32_t key,
-                                           uint64_t &start, uint32_t &len)
-{
-    const OffT b = offsets[key];
-    const OffT e = offsets[(uint64_t)key + 1];
-    start = (uint64_t)b;
-    len = (uint32_t)(e - b);
-}
+struct CompactLayout {
+    static constexpr int kLoads = 1;  // vector-memory instructions per chunk
+    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
+                                                  uint32_t &len)
+    {
+        const OffT *__restrict__ offsets = static_cast<const OffT *>(p.offsets);
+        const OffT b = offsets[key];
+        const OffT e = offsets[(uint64_t)key + 1];
+        addr = (uint64_t)b;
+        len = (uint32_t)(e - b);
+    }
+    // absolute byte address of chunk c (64 postings each) of the list at `addr`
+    __device__ static __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t addr, uint32_t c)
+    {
+        return (uint64_t)(p.values + addr + (uint64_t)c * 64u);
+    }
+    __device__ static __forceinline__ uint64_t dummy_address(const PlaceParams &p) { return (uint64_t)p.values; }
+    // Puts one chunk's load in flight: lane l reads posting min(l, cnt-1) (lanes past the end
+    // re-read the last posting: same cache lines, no exec masking, and an empty chunk still
+    // performs a real load so that vmcnt bookkeeping is exact).  base/cnt are wave-uniform.
+    __device__ static __forceinline__ void issue(uint64_t base, uint32_t cnt, int lane, uint32_t &branch,
+                                                 uint32_t &score)
+    {
+        const uint32_t last = cnt ? cnt - 1u : 0u;
+        const uint32_t off = min((uint32_t)lane, last) * 8u;
+        v2u out;
+        // s_nop 4: base comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2"
+                     : "=&v"(out)
+                     : "v"(off), "s"(base)
+                     : "memory");
+        branch = out.x;
+        score = out.y;
+    }
+    __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
+                                                         uint32_t j)
+    {
+        (void)len;
+        return p.values[addr + j];
+    }
+};
+
+// Slotted: a direct-index table of 128-byte slots, one per k-mer code, = one L2 line.
+//   slot   : u32 len | u32 tail (128-byte units into the tail region) | payload
+//   len <= cap : the whole list sits in the payload        -> ONE line per k-mer, lookup included
+//   len >  cap : the list sits in the tail region, 128-byte aligned
+// A list is stored chunk by chunk (<= 64 postings): f32 score[cnt] then BranchT branch[cnt]
+// (6 bytes per posting with 16-bit branch ids instead of 8), so a full chunk is exactly
+// three lines and no line is shared between lists.  Address unit = one byte from p.db.
+template <typename BranchT>
+struct SlottedLayout {
+    static constexpr int kLoads = 2;
+    static constexpr uint32_t kPosting = 4u + (uint32_t)sizeof(BranchT);
+    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
+                                                  uint32_t &len)
+    {
+        const uint64_t slot = (uint64_t)key * p.slot_bytes;
+        const uint2 h = *reinterpret_cast<const uint2 *>(p.db + slot);
+        len = h.x;
+        addr = (h.x <= p.slot_cap) ? slot + 8u : p.tail_offset + (uint64_t)h.y * 128u;
+    }
+    __device__ static __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t addr, uint32_t c)
+    {
+        return (uint64_t)(p.db + addr + (uint64_t)c * 64u * kPosting);
+    }
+    __device__ static __forceinline__ uint64_t dummy_address(const PlaceParams &p) { return (uint64_t)p.db; }
+    // One chunk = f32 score[cnt] then BranchT branch[cnt]: two loads, lane l reads posting
+    // min(l, cnt-1) of each (see CompactLayout::issue).  base/cnt are wave-uniform.
+    __device__ static __forceinline__ void issue(uint64_t base, uint32_t cnt, int lane, uint32_t &branch,
+                                                 uint32_t &score)
+    {
+        const uint32_t last = cnt ? cnt - 1u : 0u;
+        const uint32_t l = min((uint32_t)lane, last);
+        const uint32_t off_s = l * 4u;
+        const uint32_t off_b = cnt * 4u + l * (uint32_t)sizeof(BranchT);
+        if (sizeof(BranchT) == 2) {
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_ushort %1, %3, %4"
+                         : "=&v"(score), "=&v"(branch)
+                         : "v"(off_s), "v"(off_b), "s"(base)
+                         : "memory");
+        } else {
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4"
+                         : "=&v"(score), "=&v"(branch)
+                         : "v"(off_s), "v"(off_b), "s"(base)
+                         : "memory");
+        }
+    }
+    __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
+                                                         uint32_t j)
+    {
+        const uint32_t chunk = j >> 6, r = j & 63u;
+        const uint32_t rest = len - (chunk << 6);
+        const uint32_t cnt = rest < 64u ? rest : 64u;
+        const uint8_t *base = p.db + addr + (uint64_t)chunk * 64u * kPosting;
+        uint2 e;
+        e.y = *reinterpret_cast<const uint32_t *>(base + 4u * r);
+        e.x = (uint32_t) * reinterpret_cast<const BranchT *>(base + 4u * cnt + (uint32_t)sizeof(BranchT) * r);
+        return e;
+    }
+};
 
 // Everything a wave knows about the 64-character tile it is encoding.
 struct Tile {
@@ -207,8 +327,8 @@ __device__ __forceinline__ void accumulate_chunk(const WaveLds &lds, uint2 e, bo
 
 }  // namespace
 
-template <typename OffT, bool kLdsAtomic>
-__global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
+template <typename Layout, bool kLdsAtomic>
+__global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = lane_id();
@@ -224,14 +344,11 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
     const uint32_t N = p.num_branches;
     for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
 
-    const OffT *__restrict__ offsets = static_cast<const OffT *>(p.offsets);
-    const uint2 *__restrict__ values = p.values;
     const uint32_t k = p.kmer_size;
     const uint32_t sigma = p.alphabet_size;
     const uint32_t stride = kWave - (k - 1);  // windows per 64-character tile
     const float k_f = (float)k;
     const float log_thr = p.log_threshold;
-    const int lane8 = lane * 8;
 
     const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave_in_block;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
@@ -271,103 +388,125 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
                         exact = tl.in_range && inv_w == 0 && amb_w == 0;
                         any_amb = any_amb || (__ballot(is_amb) != 0);
                     }
-                    if (exact) load_range(offsets, tl.key, start[t], llen[t]);
+                    if (exact) Layout::lookup(p, tl.key, start[t], llen[t]);
                 }
             }
-            uint32_t n_desc = 0;
+            // (2) lists -> chunks of <= 64 postings, in read order.  Each lane knows how many
+            // chunks its k-mers need; an exclusive scan over (tile, lane) gives every chunk its
+            // position in the stream, and the lanes write the chunk descriptors
+            //     address (48 bits) | count << 48
+            // into LDS themselves.  The streaming loop below then spends only a few scalar
+            // instructions per chunk (the scalar unit is shared by the whole CU and was the
+            // bottleneck of a scalar list-walking generator).
+            uint32_t nch[kTilesPerPass], first[kTilesPerPass];
+            uint32_t total = 0, most = 0;
 #pragma unroll
             for (int t = 0; t < kTilesPerPass; ++t) {
-                const uint64_t found = __ballot(llen[t] != 0);
-                if (llen[t] != 0) {
-                    const uint32_t slot = n_desc + (uint32_t)__popcll(found & ((1ull << lane) - 1ull));
-                    lds.desc[slot] = start[t] | ((uint64_t)llen[t] << kDescLenShift);
-                }
-                n_desc += (uint32_t)__popcll(found);
+                nch[t] = (llen[t] + (uint32_t)kWave - 1u) >> 6;
+                const uint32_t incl = wave_incl_scan_u32(nch[t]);
+                first[t] = total + incl - nch[t];
+                total += __builtin_amdgcn_readlane(incl, 63);
+                most = max(most, nch[t]);
             }
-
-            // generator of (base, count<=64) chunks over the descriptor list; all state is wave-uniform
-            uint32_t di = 0;
-            uint32_t cur_rem = 0;
-            uint64_t cur_base = 0;
-            auto next_chunk = [&](uint64_t &base, uint32_t &cnt) {
-                if (cur_rem == 0 && di < n_desc) {
-                    const uint64_t d = lds.desc[di];
-                    ++di;
-                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)d);
-                    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(d >> 32));
-                    cur_base = ((uint64_t)(hi & ((1u << (kDescLenShift - 32)) - 1u)) << 32) | lo;
-                    cur_rem = hi >> (kDescLenShift - 32);
-                }
-                cnt = cur_rem < (uint32_t)kWave ? cur_rem : (uint32_t)kWave;
-                base = cur_base;
-                cur_base += cnt;
-                cur_rem -= cnt;
-            };
-            // The ring's loads are issued from inline asm so that hipcc does not count them:
-            // its own bookkeeping would drain the ring (vmcnt(0)) once per trip of the loop.
-            // Each consumer is preceded by wait_slot(): exactly kRing-1 younger ring loads
-            // exist at that point, and vmcnt retires in issue order.
-            auto issue = [&](uint64_t base, uint32_t cnt) -> v2u {
-                // buffer load with num_records = cnt postings: lanes >= cnt read nothing and get 0
-                const uint64_t addr = (uint64_t)(values + base);
-                v4i rsrc;
-                rsrc.x = (int)(uint32_t)addr;
-                rsrc.y = (int)(uint32_t)(addr >> 32);  // stride 0, no swizzle
-                rsrc.z = (int)(cnt * 8u);
-                rsrc.w = 0x00020000;
-                v2u out;
-                asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen"
-                             : "=v"(out)
-                             : "v"(lane8), "s"(rsrc)
-                             : "memory");
-                return out;
-            };
-            auto wait_slot = [&](v2u &slot) {
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "i"(kRing - 1) : "memory");
-            };
-
-            v2u ring[kRing];
-            uint32_t ring_cnt[kRing];
-#pragma unroll
-            for (int i = 0; i < kRing; ++i) {
-                ring_cnt[i] = 0;
-                ring[i] = v2u{0u, 0u};
-            }
-            // Trip 0 only fills the ring; every later trip consumes slot i (oldest load)
-            // and refills it.  One loop, one asm definition per slot register: hipcc has
-            // no reason to copy a slot while its load is in flight (checked in the .s).
-            bool primed = false;
-            bool more = n_desc != 0;
-            while (more) {
-#pragma unroll
-                for (int i = 0; i < kRing; ++i) {
-                    if (primed) {
-                        if (ring_cnt[i] == 0) {  // end of the stream (chunks are handed out in order)
-                            more = false;
-                            break;
-                        }
-                        wait_slot(ring[i]);
+            most = wave_max_u32(most);
 #ifdef EPIK_AMD_ABLATION
-                        if (p.ablate & 1u) {  // keep the load live, skip the LDS scatter-add
-                            asm volatile("" ::"v"(ring[i]));
-                        } else
+            if (p.ablate & 8u) total = 0;   // lookups done, nothing streamed
+            if (p.ablate & 16u) most = 0;   // (with 8) skip the chunk expansion too
 #endif
-                        accumulate_chunk<kLdsAtomic>(lds, make_uint2(ring[i].x, ring[i].y),
-                                                     (uint32_t)lane < ring_cnt[i]);
-                    }
-                    uint64_t base;
-                    next_chunk(base, ring_cnt[i]);
-                    ring[i] = issue(base, ring_cnt[i]);
-                }
-                primed = true;
-            }
-            // Zero-length loads behind the end of the stream are still in flight and hipcc
-            // does not know it: retire them before it may reuse their registers.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // volatile asm statements keep their order: naming every slot AFTER the wait
-            // keeps its register allocated (not reusable by hipcc) until the wait has run
+            uint64_t *chunks = lds.desc;
+            for (uint32_t w0 = 0; w0 < total; w0 += kChunkCap) {  // one round unless > kChunkCap chunks
+                const uint32_t n_round = min(total - w0, kChunkCap);
+                const uint32_t n_padded = (n_round + (uint32_t)kRing - 1u) & ~((uint32_t)kRing - 1u);
+                for (uint32_t c = 0; c < most; ++c) {
 #pragma unroll
-            for (int i = 0; i < kRing; ++i) asm volatile("" ::"v"(ring[i]));
+                    for (int t = 0; t < kTilesPerPass; ++t) {
+                        const uint32_t idx = first[t] + c - w0;  // wraps when in front of the window
+                        if (c < nch[t] && idx < kChunkCap) {
+                            const uint32_t rest = llen[t] - (c << 6);
+                            const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                            chunks[idx] = Layout::chunk_address(p, start[t], c) | (cnt << 48);
+                        }
+                    }
+                }
+                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = Layout::dummy_address(p);
+
+                // (3) stream the chunks through a ring of kRing in-flight loads.  The loads are
+                // issued from inline asm (Layout::issue): hipcc must not count them, or it would
+                // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
+                // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that point
+                // and loads retire in issue order --, takes the posting out, and refills the slot
+                // with the next chunk.  The first trip finds the slots empty (count 0).
+                uint32_t ring_b[kRing], ring_s[kRing], ring_cnt[kRing];
+#pragma unroll
+                for (int i = 0; i < kRing; ++i) ring_b[i] = ring_s[i] = ring_cnt[i] = 0;
+                auto consume = [&](uint32_t br, uint32_t sc_bits, uint32_t cnt, auto &&between) {
+                    // The LDS read of the score cells goes out first, `between` (the refill)
+                    // overlaps its latency, the add and the write-back come last.
+                    const bool active = (uint32_t)lane < cnt;
+                    const float sc = __uint_as_float(sc_bits);
+                    uint2 cv = make_uint2(0u, 0u);
+#ifdef EPIK_AMD_ABLATION
+                    const bool skip_acc = (p.ablate & 1u) != 0;
+                    if (skip_acc) asm volatile("" ::"v"(br), "v"(sc));
+#else
+                    constexpr bool skip_acc = false;
+#endif
+                    if (!kLdsAtomic && !skip_acc && active) cv = lds.cell[br];  // ds_read_b64
+                    between();
+                    asm volatile("" : "+v"(cv.x), "+v"(cv.y));  // keep the adds below the refill
+                    if (!skip_acc && active) {
+                        if (kLdsAtomic) {
+                            accumulate_chunk<true>(lds, make_uint2(br, sc_bits), true);
+                        } else {
+                            cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), sc));  // :366
+                            cv.y += 1u;                                                    // :365
+                            lds.cell[br] = cv;                                             // ds_write_b64
+                        }
+                    }
+                };
+                uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
+                for (uint32_t c0 = 0; c0 < n_padded; c0 += kRing) {
+                    const uint64_t d_cur = d_next;
+                    d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
+#pragma unroll
+                    for (int i = 0; i < kRing; ++i) {
+                        // Wait for slot i and move its posting out of the slot registers INSIDE
+                        // the asm statement, behind the wait: a copy made by hipcc could be
+                        // scheduled ahead of the wait and capture the registers too early.
+                        uint32_t br, sc_bits;
+                        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                                     : "=&v"(br), "=&v"(sc_bits)
+                                     : "v"(ring_b[i]), "v"(ring_s[i]), "i"(Layout::kLoads * (kRing - 1))
+                                     : "memory");
+                        const uint32_t cnt = ring_cnt[i];
+                        consume(br, sc_bits, cnt, [&]() {
+                            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)d_cur, i);
+                            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(d_cur >> 32), i);
+                            ring_cnt[i] = hi >> 16;
+                            Layout::issue(((uint64_t)(hi & 0xffffu) << 32) | lo, hi >> 16, lane, ring_b[i], ring_s[i]);
+                        });
+                    }
+                }
+                // tail: nothing more to issue; retire the ring and consume what it holds
+                {
+                    uint32_t br[kRing], sc_bits[kRing];
+#pragma unroll
+                    for (int i = 0; i < kRing; ++i) {
+                        if (i == 0)
+                            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                                         : "=&v"(br[i]), "=&v"(sc_bits[i])
+                                         : "v"(ring_b[i]), "v"(ring_s[i])
+                                         : "memory");
+                        else
+                            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                                         : "=&v"(br[i]), "=&v"(sc_bits[i])
+                                         : "v"(ring_b[i]), "v"(ring_s[i])
+                                         : "memory");
+                    }
+#pragma unroll
+                    for (int i = 0; i < kRing; ++i) consume(br[i], sc_bits[i], ring_cnt[i], []() {});
+                }
+            }
         }
 
         // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
@@ -394,12 +533,12 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
                     for (uint32_t st = 0; st < sigma; ++st) {
                         if (!((cls >> st) & 1u)) continue;
                         const uint32_t key = key0 + st * weight;
-                        const uint64_t b0 = (uint64_t)offsets[key];
-                        const uint32_t n = (uint32_t)((uint64_t)offsets[(uint64_t)key + 1] - b0);
-                        const uint2 *__restrict__ list = values + b0;
+                        uint64_t b0;
+                        uint32_t n;
+                        Layout::lookup(p, key, b0, n);
                         for (uint32_t off = 0; off < n; off += kWave) {
                             if (off + (uint32_t)lane < n) {
-                                const uint2 e = list[off + lane];
+                                const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);
                                 uint2 cv = lds.cell[e.x];
                                 const uint32_t c = cv.y;
                                 // Only the first ambiguous key that reaches a branch scores it:
@@ -626,13 +765,12 @@ __global__ __launch_bounds__(256) void place_reads_kernel(PlaceParams p)
 }
 
 // Algorithmic bytes of SURVEY.md 8(d): one thread per read, plain loops.
-template <typename OffT>
+template <typename Layout>
 __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *total)
 {
     const uint64_t read = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long bytes = 0;
     if (read < p.n_reads) {
-        const OffT *offsets = static_cast<const OffT *>(p.offsets);
         const uint64_t b = p.seq_offsets[read];
         const uint64_t len = p.seq_offsets[read + 1] - b;
         const uint8_t *seq = p.seqs + b;
@@ -655,15 +793,19 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
                     key = key * p.alphabet_size + st;
                 }
                 if (!ok || n_amb > 1) continue;
+                uint64_t addr;
+                uint32_t llen;
                 if (n_amb == 0) {
-                    entries += (unsigned long long)(offsets[key + 1] - offsets[key]);
+                    Layout::lookup(p, (uint32_t)key, addr, llen);
+                    entries += llen;
                 } else {
                     weight = 1;
                     for (uint32_t j = amb_pos + 1; j < k; ++j) weight *= p.alphabet_size;
                     for (uint32_t st = 0; st < p.alphabet_size; ++st)
                         if ((amb_cls >> st) & 1u) {
                             const uint64_t kk = key + (uint64_t)st * weight;
-                            entries += (unsigned long long)(offsets[kk + 1] - offsets[kk]);
+                            Layout::lookup(p, (uint32_t)kk, addr, llen);
+                            entries += llen;
                         }
                 }
             }
@@ -685,66 +827,66 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
     }
 }
 
-hipError_t launch_place_reads(const PlaceParams &p, bool offsets64, bool lds_atomic, dim3 grid,
-                              dim3 block, size_t lds_bytes, hipStream_t stream)
+namespace {
+
+// Calls f.template operator()<Layout, kLdsAtomic>() for the runtime variant.
+template <typename F>
+hipError_t dispatch(DbLayout layout, bool lds_atomic, F &&f)
 {
-    if (offsets64) {
-        if (lds_atomic)
-            hipLaunchKernelGGL((place_reads_kernel<uint64_t, true>), grid, block, lds_bytes, stream, p);
-        else
-            hipLaunchKernelGGL((place_reads_kernel<uint64_t, false>), grid, block, lds_bytes, stream, p);
-    } else {
-        if (lds_atomic)
-            hipLaunchKernelGGL((place_reads_kernel<uint32_t, true>), grid, block, lds_bytes, stream, p);
-        else
-            hipLaunchKernelGGL((place_reads_kernel<uint32_t, false>), grid, block, lds_bytes, stream, p);
+    switch (layout) {
+        case DbLayout::kCompact32:
+            return lds_atomic ? f.template operator()<CompactLayout<uint32_t>, true>()
+                              : f.template operator()<CompactLayout<uint32_t>, false>();
+        case DbLayout::kCompact64:
+            return lds_atomic ? f.template operator()<CompactLayout<uint64_t>, true>()
+                              : f.template operator()<CompactLayout<uint64_t>, false>();
+        case DbLayout::kSlotted16:
+            return lds_atomic ? f.template operator()<SlottedLayout<uint16_t>, true>()
+                              : f.template operator()<SlottedLayout<uint16_t>, false>();
+        case DbLayout::kSlotted32:
+            return lds_atomic ? f.template operator()<SlottedLayout<uint32_t>, true>()
+                              : f.template operator()<SlottedLayout<uint32_t>, false>();
     }
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
-hipError_t set_place_reads_lds_limit(size_t lds_bytes)
+}  // namespace
+
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool lds_atomic, dim3 grid, dim3 block,
+                              size_t lds_bytes, hipStream_t stream)
 {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<uint32_t, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<uint32_t, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<uint64_t, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<uint64_t, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return dispatch(layout, lds_atomic, [&]<typename L, bool A>() {
+        hipLaunchKernelGGL((place_reads_kernel<L, A>), grid, block, lds_bytes, stream, p);
+        return hipGetLastError();
+    });
 }
 
-hipError_t place_reads_occupancy(bool offsets64, bool lds_atomic, int block_threads, size_t lds_bytes,
+hipError_t set_place_reads_lds_limit(DbLayout layout, bool lds_atomic, size_t lds_bytes)
+{
+    return dispatch(layout, lds_atomic, [&]<typename L, bool A>() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<L, A>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+}
+
+hipError_t place_reads_occupancy(DbLayout layout, bool lds_atomic, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu)
 {
-    if (offsets64) {
-        if (lds_atomic)
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                blocks_per_cu, place_reads_kernel<uint64_t, true>, block_threads, lds_bytes);
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            blocks_per_cu, place_reads_kernel<uint64_t, false>, block_threads, lds_bytes);
-    }
-    if (lds_atomic)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            blocks_per_cu, place_reads_kernel<uint32_t, true>, block_threads, lds_bytes);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        blocks_per_cu, place_reads_kernel<uint32_t, false>, block_threads, lds_bytes);
+    return dispatch(layout, lds_atomic, [&]<typename L, bool A>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, place_reads_kernel<L, A>,
+                                                            block_threads, lds_bytes);
+    });
 }
 
-hipError_t launch_algorithmic_bytes(const PlaceParams &p, bool offsets64, unsigned long long *d_total,
+hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
                                     hipStream_t stream)
 {
     const dim3 block(256);
     const dim3 grid((unsigned)((p.n_reads + 255) / 256));
-    if (offsets64)
-        hipLaunchKernelGGL((algorithmic_bytes_kernel<uint64_t>), grid, block, 0, stream, p, d_total);
-    else
-        hipLaunchKernelGGL((algorithmic_bytes_kernel<uint32_t>), grid, block, 0, stream, p, d_total);
-    return hipGetLastError();
+    return dispatch(layout, false, [&]<typename L, bool A>() {
+        hipLaunchKernelGGL((algorithmic_bytes_kernel<L>), grid, block, 0, stream, p, d_total);
+        return hipGetLastError();
+    });
 }
 
 }  // namespace epik_amd

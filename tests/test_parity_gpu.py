@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+@pytest.fixture(autouse=True, params=["slotted", "compact"])
+def db_layout(request, monkeypatch):
+    """Every parity test runs on both HBM layouts of the database (the slot table with
+    inline short lists, and the plain CSR used when that table would not fit)."""
+    monkeypatch.setenv("EPIK_AMD_LAYOUT", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def placer_cls(gpu_available):
     assert gpu_available, "pytest -m gpu needs a HIP device (no CPU fallback exists)"
