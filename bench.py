@@ -67,13 +67,30 @@ def load_traffic(workload: str):
     return None
 
 
+def host_cores() -> int:
+    """Cores this process may really use: OMP_NUM_THREADS if set, else the smallest of the
+    affinity mask and the cgroup CPU quota (the GPU boxes expose every host core through
+    os.cpu_count() but schedule a one-GPU job on its 16-core share)."""
+    env = int(os.environ.get("OMP_NUM_THREADS", 0) or 0)
+    if env > 0:
+        return env
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(db, data, offs, target_seconds: float):
     """Times the oracle (kind "port") on a bounded prefix of the same read batch."""
     from oracle import oracle
     oracle.build()
     orc = oracle.Oracle.from_synth(db)
-    threads = int(os.environ.get("OMP_NUM_THREADS", 0)) or (os.cpu_count() or 1)
-    threads = min(threads, oracle.Oracle.max_threads())
+    threads = min(host_cores(), oracle.Oracle.max_threads())
     n_total = len(offs) - 1
     probe = min(4000 * threads, n_total)
     t0 = time.perf_counter()
