@@ -41,11 +41,56 @@ def kernels(lines):
                 name = None
 
 
+def lint_loop(name, body, events, problems):
+    """One ring loop: `events` are its asm statements in program order."""
+    ring = set()
+    for e in events:
+        if e[1] == "load":
+            ring |= e[2]
+    waits = [e[0] for e in events if e[1] == "wait"]
+    loads = [e[0] for e in events if e[1] == "load"]
+    if not loads or not waits:
+        return
+    # From the loop's first asm statement to a margin behind its last asm load (the
+    # fall-through into the tail, which still runs before the drain).  Walk it in program
+    # order with a per-register state: a slot register is IN FLIGHT from its asm load until
+    # the asm wait that moves it out (`s_waitcnt vmcnt(N)` + `v_mov_b32 x, R`); between that
+    # wait and the refill the register is dead and hipcc may reuse it.  The loop is cyclic,
+    # so at its top every slot counts as in flight.
+    lo, hi = max(0, min(waits[0], loads[0]) - 1), loads[-1] + 15  # -1: the ;;#ASMSTART line
+    inflight = set(ring)
+    in_asm = False
+    for n in range(lo, min(hi, len(body) - 1) + 1):
+        s = body[n].strip()
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.startswith((";", ".")):
+            continue
+        parts = s.split(None, 1)
+        operands = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        if in_asm:
+            if s.startswith(("buffer_load_", "global_load_")):
+                inflight |= regs_of(operands[0])
+            elif s.startswith("v_mov_b32") and len(operands) == 2:
+                inflight -= regs_of(operands[1])  # moved out behind the wait of this statement
+            continue
+        touched = set()
+        for o in operands:
+            if o:
+                touched |= regs_of(o.split()[0])
+        if touched & inflight:
+            problems.append(f"{name}: line {n}: compiler code touches an in-flight ring register: {s}")
+
+
 def lint(path):
     problems = []
     for name, body in kernels(open(path).read().split("\n")):
-        # events: (line, kind, regs) with kind in {"wait", "drain", "load"}
-        events, in_asm, ring = [], False, set()
+        # asm statements in program order: (line, kind, regs), kind in {"wait", "drain", "load"}
+        events, in_asm = [], False
         for n, l in enumerate(body):
             s = l.strip()
             if s.startswith(";;#ASMSTART"):
@@ -53,49 +98,22 @@ def lint(path):
             elif s.startswith(";;#ASMEND"):
                 in_asm = False
             elif in_asm and s.startswith(("buffer_load_", "global_load_")):
-                dst = regs_of(s.split()[1])
-                ring |= dst
-                events.append((n, "load", dst))
+                events.append((n, "load", regs_of(s.split()[1])))
             elif in_asm and s.startswith("s_waitcnt vmcnt("):
                 events.append((n, "drain" if "vmcnt(0)" in s else "wait", set()))
-        if not ring:
+        if not any(e[1] == "load" for e in events):
             problems.append(f"{name}: no asm ring loads found")
             continue
-        # The ring loop is contiguous in the .s: from its first asm wait to a margin behind
-        # its last asm load (the fall-through into the tail, which still runs before the drain).  Walk it in
-        # program order with a per-register state: a slot register is IN FLIGHT from its asm
-        # load until the asm wait that moves it out (`s_waitcnt vmcnt(N)` + `v_mov_b32 x, R`);
-        # between that wait and the refill the register is dead and hipcc may reuse it.
-        # The loop is cyclic, so at its top every slot counts as in flight.
-        waits = [e[0] for e in events if e[1] == "wait"]
-        loads = [e[0] for e in events if e[1] == "load"]
-        lo, hi = min(waits[0], loads[0]), loads[-1] + 15
-        inflight = set(ring)
-        in_asm = False
-        for n, l in enumerate(body):
-            s = l.strip()
-            if s.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if s.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if not (lo <= n <= hi) or not s or s.startswith((";", ".")):
-                continue
-            parts = s.split(None, 1)
-            operands = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
-            if in_asm:
-                if s.startswith(("buffer_load_", "global_load_")):
-                    inflight |= regs_of(operands[0])
-                elif s.startswith("v_mov_b32") and len(operands) == 2:
-                    inflight -= regs_of(operands[1])  # moved out behind the wait of this statement
-                continue
-            touched = set()
-            for o in operands:
-                if o:
-                    touched |= regs_of(o.split()[0])
-            if touched & inflight:
-                problems.append(f"{name}: line {n}: compiler code touches an in-flight ring register: {s}")
+        # the kernel may hold several copies of the ring loop (first pass / further passes):
+        # each ends with its tail's `s_waitcnt vmcnt(0)`
+        group = []
+        for e in events:
+            if e[1] == "drain":
+                lint_loop(name, body, group, problems)
+                group = []
+            else:
+                group.append(e)
+        lint_loop(name, body, group, problems)
     return problems
 
 
