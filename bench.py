@@ -96,12 +96,16 @@ def cpu_baseline(db, data, offs, target_seconds: float):
     t0 = time.perf_counter()
     orc.place(data[:int(offs[probe])], offs[:probe + 1], num_threads=threads)
     rate = probe / max(time.perf_counter() - t0, 1e-6)
+    # bounded sample: the step batch, repeated until about target_seconds of wall time
     n = int(min(n_total, max(probe, rate * target_seconds)))
+    reps = max(1, int(round(rate * target_seconds / n)))
     t0 = time.perf_counter()
-    orc.place(data[:int(offs[n])], offs[:n + 1], num_threads=threads)
+    for _ in range(reps):
+        orc.place(data[:int(offs[n])], offs[:n + 1], num_threads=threads)
     dt = time.perf_counter() - t0
+    n *= reps
     return {"value": n / dt, "unit": "reads/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} reads of the step batch, {dt:.1f} s wall, oracle/epik_oracle.c "
+            "sample": f"{n} reads (the step batch, repeated), {dt:.1f} s wall, oracle/epik_oracle.c "
                       f"(OpenMP dynamic schedule as place.cpp:218-230, CSR lookup)"}
 
 
@@ -116,16 +120,14 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch
-    import torch.distributed as dist
 
-    from epik_amd import capi, synth
+    from epik_amd import capi, dist as edist, synth
     from epik_amd.placer import Placer
 
     if not torch.cuda.is_available() or capi.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: epik_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = edist.init_process_group("nccl")  # RCCL; None when WORLD_SIZE == 1
 
     # ---- synthetic workload, identical DB on every rank ---------------
     tree = synth.make_tree(args.leaves, seed=42)
@@ -151,7 +153,7 @@ def main():
                             d_nrows.data_ptr(), 0, stream.cuda_stream)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -172,10 +174,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = edist.max_over_ranks(elapsed, dist, device=dev)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
 
     if rank == 0:
@@ -214,7 +213,7 @@ def main():
 
     barrier()
     placer.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

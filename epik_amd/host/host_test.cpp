@@ -1,0 +1,142 @@
+// host_test.cpp -- CPU unit checks of the host-side callers (FASTA, Newick, jplace
+// formatting, --max-ram parsing, database container).  Run by tests/test_host_cpu.py;
+// exits non-zero on the first failure.  No GPU call is made.
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "jplace.hpp"
+#include "phylo_kmer_db.hpp"
+#include "phylo_tree.hpp"
+#include "seq_record.hpp"
+
+namespace epik_amd {
+size_t parse_human_readable(const std::string&);
+void check_mu(float);
+}
+
+static int failures = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::cerr << "FAILED " << __FILE__ << ":" << __LINE__ << ": " #cond << std::endl; \
+            ++failures;                                                          \
+        }                                                                        \
+    } while (0)
+
+int main(int argc, char** argv)
+{
+    using namespace epik_amd;
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+
+    // --- FASTA batches (main.cpp:332-340) ---
+    {
+        const std::string path = tmp + "/host_test.fasta";
+        std::ofstream(path) << ">r1 first\nACGT\nAC\n\n>r2\r\nTTTT\r\n>r3\n>r4\nGG\n";
+        io::batch_fasta reader(path, 2);
+        auto b1 = reader.next_batch();
+        CHECK(b1.size() == 2 && b1[0].header() == "r1 first" && b1[0].sequence() == "ACGTAC");
+        CHECK(b1[1].header() == "r2" && b1[1].sequence() == "TTTT");
+        auto b2 = reader.next_batch();
+        CHECK(b2.size() == 2 && b2[0].header() == "r3" && b2[0].sequence().empty());
+        CHECK(b2[1].header() == "r4" && b2[1].sequence() == "GG");
+        CHECK(reader.next_batch().empty());
+        CHECK(reader.bytes_read() > 30);
+    }
+    // --- Newick: post-order ids, tree index, jplace form ---
+    {
+        const auto tree = io::parse_newick("((A:0.1,B:0.2)X:0.3,C:0.4)root;");
+        CHECK(tree.get_node_count() == 5);
+        CHECK((*tree.get_by_postorder_id(0))->get_label() == "A");
+        CHECK((*tree.get_by_postorder_id(2))->get_label() == "X");
+        CHECK((*tree.get_by_postorder_id(4))->get_label() == "root");
+        CHECK(!tree.get_by_postorder_id(5));
+        const auto index = tree.tree_index();
+        CHECK(index[2].subtree_num_nodes == 3 && std::fabs(index[2].subtree_total_length - 0.3) < 1e-12);
+        CHECK(index[4].subtree_num_nodes == 5 && std::fabs(index[4].subtree_total_length - 1.0) < 1e-12);
+        CHECK(io::to_newick(tree, true) == "((A:0.1{0},B:0.2{1})X:0.3{2},C:0.4{3})root:0{4};");
+        const auto again = io::parse_newick(io::to_newick(tree, true));
+        CHECK(again.get_node_count() == 5 && (*again.get_by_postorder_id(3))->get_branch_length() == 0.4);
+    }
+    // --- --max-ram, --mu (main.cpp:154-202) ---
+    {
+        CHECK(parse_human_readable("512") == 512);
+        CHECK(parse_human_readable("256K") == 256 * 1024);
+        CHECK(parse_human_readable("42m") == 42u * 1024 * 1024);
+        CHECK(parse_human_readable("4.2Gb") == (size_t)(4.2 * 1024 * 1024 * 1024));
+        bool threw = false;
+        try { parse_human_readable("12X"); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { check_mu(1.5f); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    }
+    // --- thresholds and class tables ---
+    {
+        CHECK(std::fabs(score_threshold(1.5f, 10, 4) - std::pow(0.375, 10)) < 1e-12);
+        const auto dna = char_class_table("DNA");
+        CHECK(dna['A'] == 1 && dna['c'] == 2 && dna['G'] == 4 && dna['U'] == 8 && dna['N'] == 15 && dna['-'] == 0);
+        const auto aa = char_class_table("Proteins");
+        CHECK(aa['R'] == 1 && aa['V'] == (1u << 19) && aa['X'] == (1u << 20) - 1 && aa['*'] == 0);
+    }
+    // --- jplace document shape (jplace.cpp) ---
+    {
+        const std::string path = tmp + "/host_test.jplace";
+        std::vector<seq_record> batch{{"q1", "ACGT"}, {"q \"2\"", "ACGT"}, {"q3", "TT"}};
+        impl::placed_collection placed;
+        placed.sequence_map[batch[0].sequence()] = {batch[0].header(), batch[1].header()};
+        placed.sequence_map[batch[2].sequence()] = {batch[2].header()};
+        placed.placed_seqs.push_back({batch[0].sequence(), {{3, -1.5f, 0.75, 2, 0.05, 0.15}, {1, -2.0f, 0.25, 1, 0.1, 0.2}}});
+        placed.placed_seqs.push_back({batch[2].sequence(), {}});
+        io::jplace_writer writer(path, "epik-dna -d x ", "(A:1{0},B:2{1}):0{2};");
+        writer.start();
+        writer << placed;
+        writer.end();
+        std::stringstream ss;
+        ss << std::ifstream(path).rdbuf();
+        const std::string doc = ss.str();
+        CHECK(doc.find("\"version\": 3") != std::string::npos);
+        CHECK(doc.find("[\"edge_num\", \"likelihood\", \"like_weight_ratio\", \"distal_length\", \"pendant_length\"]") !=
+              std::string::npos);
+        CHECK(doc.find("[3, -1.5, 0.75, 0.05, 0.15]") != std::string::npos);
+        CHECK(doc.find("[\"q \\\"2\\\"\", 1]") != std::string::npos);
+        CHECK(io::json_double(1.0) == "1.0" && io::json_double(-4.2596874237060547) == "-4.259687423706055");
+    }
+    // --- database container: mu / omega / max-ram filtering ---
+    {
+        const std::string path = tmp + "/host_test.ekdb";
+        {
+            std::ofstream out(path, std::ios::binary);
+            const std::string newick = "((A:0.1,B:0.2)X:0.3,C:0.4)root;";
+            auto w32 = [&](uint32_t v) { out.write(reinterpret_cast<const char*>(&v), 4); };
+            auto w64 = [&](uint64_t v) { out.write(reinterpret_cast<const char*>(&v), 8); };
+            auto wf = [&](float v) { out.write(reinterpret_cast<const char*>(&v), 4); };
+            out.write("EPIKAMD1", 8);
+            w32(1); w32(0); w32(2); wf(1.0f);            // version, DNA, k=2, omega
+            w64(3); w64(5); w64(newick.size());          // k-mers, postings, tree
+            out << newick;
+            w32(5); w32(2); w32(0); wf(-0.1f); w32(2); wf(-0.5f);   // k-mer 5: branches 0, 2
+            w32(1); w32(2); w32(1); wf(-0.2f); w32(3); wf(-1.0f);   // k-mer 1: branch 3 is below omega 1.5
+            w32(9); w32(1); w32(4); wf(-0.3f);                      // k-mer 9
+        }
+        auto db = load(path, 1.0f, 1.0f);  // log10((1/4)^2) = -1.20: everything passes
+        CHECK(db.kmer_size() == 2 && db.num_keys() == 16 && db.get_num_entries_loaded() == 5);
+        CHECK(db.offsets()[1] == 0 && db.offsets()[2] == 2 && db.offsets()[6] == 4 && db.offsets()[16] == 5);
+        CHECK(db.values()[db.offsets()[5]].branch == 0 && db.values()[db.offsets()[9]].branch == 4);
+        db = load(path, 1.0f, 1.5f);   // log10((1.5/4)^2) = -0.85: the -1.0 posting goes
+        CHECK(db.get_num_entries_loaded() == 4 && db.get_num_entries_total() == 5 && db.omega() == 1.5f);
+        db = load(path, 0.5f, 1.0f);   // best half of the k-mers: ceil(1.5) = 2 records
+        CHECK(db.get_num_entries_loaded() == 4);
+        db = load(path, 1.0f, 1.0f, 3);  // --max-ram: stops in front of the k-mer that does not fit
+        CHECK(db.get_num_entries_loaded() == 2);
+        bool threw = false;
+        try { load(tmp + "/host_test.fasta"); } catch (const std::runtime_error& e) {
+            threw = std::string(e.what()).find("EPIKAMD1") != std::string::npos;
+        }
+        CHECK(threw);
+    }
+    if (failures == 0) std::cout << "host tests ok" << std::endl;
+    return failures ? 1 : 0;
+}

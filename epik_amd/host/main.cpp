@@ -1,0 +1,334 @@
+// main.cpp -- the `epik-dna` / `epik-aa` drivers over the MI355X placer.
+//
+// Keeps the command line of the reference driver (epik/src/epik/main.cpp:209-222):
+//   -d/--database  -q/--query  -j/--jobs  --batch-size  --omega  --mu  --max-ram
+//   -o/--output-dir  --keep-at-most  --keep-factor  -h/--help
+// with the same defaults (1, 2000, 1.5, 1.0, -, -, 7, 0.01), the same exit codes
+// (0 / -1 on error, main.cpp:272,282,387,390), the same output file name
+// (main.cpp:34-37) and the same final report lines (main.cpp:368-382).  Not reproduced:
+// the progress bar and colours (indicators/termcolor).  Added: --gpus N | --devices a,b,c.
+// The two binaries differ as the reference's do (epik/CMakeLists.txt:72,124): epik-dna
+// accepts DNA databases, epik-aa protein ones.
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "jplace.hpp"
+#include "phylo_kmer_db.hpp"
+#include "phylo_tree.hpp"
+#include "placer.hpp"
+#include "seq_record.hpp"
+
+#ifndef EPIK_AMD_NO_MAIN
+namespace {
+
+#ifdef EPIK_AMD_AA
+constexpr const char* kSequenceType = "Proteins";
+#else
+constexpr const char* kSequenceType = "DNA";
+#endif
+
+/// main.cpp:22-32
+std::string make_invocation(int argc, char** argv)
+{
+    std::string invocation;
+    for (int i = 0; i < argc; ++i) invocation += std::string(argv[i]) + " ";
+    return invocation;
+}
+
+/// main.cpp:34-37: <output_dir>/placements_<basename(query)>.jplace
+std::string make_output_filename(const std::string& input_file, const std::string& output_dir)
+{
+    const auto slash = input_file.find_last_of('/');
+    const std::string base = slash == std::string::npos ? input_file : input_file.substr(slash + 1);
+    std::string dir = output_dir;
+    if (!dir.empty() && dir.back() != '/') dir.push_back('/');
+    return dir + "placements_" + base + ".jplace";
+}
+
+/// main.cpp:66-112
+template <typename T>
+std::string to_human_readable(T num)
+{
+    std::ostringstream oss;
+    if (num < 1024) {
+        oss << std::fixed << num;
+    } else {
+        double value;
+        std::string suffix;
+        if (num < 1024 * 1024) {
+            value = num / 1024.0;
+            suffix = "K";
+        } else if (num < 1024.0 * 1024 * 1024) {
+            value = num / (1024.0 * 1024.0);
+            suffix = "M";
+        } else {
+            value = num / (1024.0 * 1024.0 * 1024.0);
+            suffix = "B";
+        }
+        double int_part;
+        if (std::modf(value, &int_part) == 0.0) {
+            oss << static_cast<long long>(int_part) << suffix;
+        } else {
+            oss.precision(1);
+            oss << std::fixed << value << suffix;
+        }
+    }
+    return oss.str();
+}
+
+/// main.cpp:115-151
+std::string humanize_time(size_t milliseconds)
+{
+    const size_t ms_per_sec = 1000, ms_per_min = 60 * ms_per_sec, ms_per_hour = 60 * ms_per_min;
+    const size_t ms_per_day = 24 * ms_per_hour;
+    const size_t days = milliseconds / ms_per_day;
+    milliseconds %= ms_per_day;
+    const size_t hours = milliseconds / ms_per_hour;
+    milliseconds %= ms_per_hour;
+    const size_t minutes = milliseconds / ms_per_min;
+    milliseconds %= ms_per_min;
+    const size_t seconds = milliseconds / ms_per_sec;
+    std::ostringstream oss;
+    if (days > 0) oss << days << " day" << (days > 1 ? "s" : "") << ", ";
+    if (hours > 0 || days > 0) oss << std::setw(2) << std::setfill('0') << hours << ":";
+    oss << std::setw(2) << std::setfill('0') << minutes << ":" << std::setw(2) << std::setfill('0') << seconds;
+    return oss.str();
+}
+
+}  // namespace
+#endif  // EPIK_AMD_NO_MAIN
+
+namespace epik_amd {
+
+/// main.cpp:154-194: "128K", "50M", "4.2Gb", bare number = bytes; 1024-based, first letter only
+size_t parse_human_readable(const std::string& max_ram)
+{
+    double value;
+    char unit = 0;
+    std::stringstream ss(max_ram);
+    ss >> value;
+    if (ss.fail()) throw std::runtime_error("Could not parse --max-ram parameter: wrong numerical part");
+    if (!ss.eof()) {
+        ss >> unit;
+        if (ss.fail()) throw std::runtime_error("Could not parse --max-ram parameter: wrong unit");
+    }
+    switch (std::toupper(unit)) {
+        case 0:
+        case 'B': return static_cast<size_t>(value);
+        case 'K': return static_cast<size_t>(value * 1024);
+        case 'M': return static_cast<size_t>(value * 1024 * 1024);
+        case 'G': return static_cast<size_t>(value * 1024 * 1024 * 1024);
+        default: throw std::runtime_error("Unknown memory unit.");
+    }
+}
+
+/// main.cpp:196-202
+void check_mu(float mu)
+{
+    if ((mu < 0.0) || (mu > 1.0)) throw std::runtime_error("Mu has to a value in [0, 1]");
+}
+
+}  // namespace epik_amd
+
+#ifndef EPIK_AMD_NO_MAIN
+
+namespace {
+
+const char* kHelp =
+    "Evolutionary Placement with Informative K-mers (MI355X placer)\n"
+    "Usage:\n"
+    "  epik-dna|epik-aa [OPTION...]\n\n"
+    "  -d, --database arg      IPK database\n"
+    "  -q, --query arg         Input query file (.fasta)\n"
+    "  -j, --jobs arg          Num threads (default: 1)\n"
+    "      --batch-size arg    Batch size (default: 2000)\n"
+    "      --omega arg         Determines the threshold value (default: 1.5)\n"
+    "      --mu arg            Proportion of the database to load (default: 1.0)\n"
+    "      --max-ram arg       Approximate database size to load, MB\n"
+    "  -o, --output-dir arg    Output directory\n"
+    "      --keep-at-most arg  Number of branches to report (default: 7)\n"
+    "      --keep-factor arg   Minimum LWR to report (default: 0.01)\n"
+    "      --gpus arg          Number of MI355X devices to use (default: 1)\n"
+    "      --devices arg       Comma-separated HIP device ordinals (overrides --gpus)\n"
+    "  -h, --help              Print usage\n";
+
+struct options {
+    std::map<std::string, std::string> values;
+    bool has(const std::string& k) const { return values.count(k) != 0; }
+    std::string get(const std::string& k, const std::string& def) const
+    {
+        const auto it = values.find(k);
+        return it == values.end() ? def : it->second;
+    }
+    std::string require(const std::string& k) const
+    {
+        const auto it = values.find(k);
+        if (it == values.end()) throw std::runtime_error("Option '" + k + "' has no value");
+        return it->second;
+    }
+};
+
+options parse_args(int argc, char** argv)
+{
+    const std::map<std::string, std::string> short_names{
+        {"-d", "database"}, {"-q", "query"}, {"-j", "jobs"}, {"-o", "output-dir"}, {"-h", "help"}};
+    options opt;
+    for (int i = 1; i < argc; ++i) {
+        std::string arg = argv[i];
+        std::string name, value;
+        bool have_value = false;
+        if (arg.rfind("--", 0) == 0) {
+            name = arg.substr(2);
+            const auto eq = name.find('=');
+            if (eq != std::string::npos) {
+                value = name.substr(eq + 1);
+                name = name.substr(0, eq);
+                have_value = true;
+            }
+        } else if (short_names.count(arg)) {
+            name = short_names.at(arg);
+        } else {
+            continue;  // positional arguments are ignored (epik.py passes the query twice, epik.py:88,96)
+        }
+        if (name == "help") {
+            opt.values[name] = "1";
+            continue;
+        }
+        if (!have_value) {
+            if (i + 1 >= argc) throw std::runtime_error("Option '" + name + "' is missing an argument");
+            value = argv[++i];
+        }
+        opt.values[name] = value;
+    }
+    return opt;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::ios::sync_with_stdio(false);
+    if (argc == 1) {
+        std::cout << kHelp << std::endl;
+        return 0;
+    }
+    try {
+        const options parsed = parse_args(argc, argv);
+        if (parsed.has("help")) {
+            std::cout << kHelp << std::endl;
+            return 0;
+        }
+        const auto db_file = parsed.require("database");
+        const auto query_file = parsed.require("query");
+        const auto num_threads = (size_t)std::stoul(parsed.get("jobs", "1"));
+        const auto batch_size = (size_t)std::stoul(parsed.get("batch-size", "2000"));
+        const auto user_omega = std::stof(parsed.get("omega", "1.5"));
+        const auto user_mu = std::stof(parsed.get("mu", "1.0"));
+        const auto keep_at_most = (size_t)std::stoul(parsed.get("keep-at-most", "7"));
+        const auto keep_factor = std::stod(parsed.get("keep-factor", "0.01"));
+        const auto output_dir = parsed.require("output-dir");
+        epik_amd::check_mu(user_mu);
+
+        size_t max_entries = std::numeric_limits<size_t>::max();
+        if (parsed.has("max-ram")) {
+            const auto max_ram = epik_amd::parse_human_readable(parsed.require("max-ram"));
+            max_entries = static_cast<size_t>(max_ram / sizeof(epik_amd::pkdb_value));
+            if (max_entries == 0) throw std::runtime_error("Memory limit is too low");
+            std::cout << "Max-RAM provided: will be loaded not more than " << to_human_readable(max_entries)
+                      << " phylo-k-mers." << std::endl;
+        }
+
+        std::vector<int> devices;
+        if (parsed.has("devices")) {
+            std::stringstream ss(parsed.require("devices"));
+            for (std::string item; std::getline(ss, item, ',');) devices.push_back(std::stoi(item));
+        } else {
+            const int n = std::stoi(parsed.get("gpus", "1"));
+            for (int i = 0; i < n; ++i) devices.push_back(i);
+        }
+        if (devices.empty() || epik_amd_device_count() < (int)devices.size())
+            throw std::runtime_error("Not enough HIP devices: " + std::to_string(epik_amd_device_count()) +
+                                     " visible (this placer has no CPU fallback)");
+
+        std::cout << "Loading database with mu=" << user_mu << " and omega=" << user_omega << "..." << std::endl;
+        const auto db = epik_amd::load(db_file, user_mu, user_omega, max_entries);
+        if (db.version() < epik_amd::protocol::EARLIEST_INDEX) {
+            std::cerr << "The serialization protocol version is too old (v" << db.version() << ").\n";
+            return -1;
+        }
+        if (db.sequence_type() != kSequenceType)
+            throw std::runtime_error(std::string("This binary places ") + kSequenceType + " databases, the file holds " +
+                                     db.sequence_type());
+
+        std::cout << "Database parameters:" << std::endl
+                  << "\tSequence type: " << db.sequence_type() << std::endl
+                  << "\tk: " << db.kmer_size() << std::endl
+                  << "\tomega: " << db.omega() << std::endl
+                  << "\tPositions loaded: " << (db.positions_loaded() ? "true" : "false") << std::endl
+                  << std::endl;
+        std::cout << "Loaded " << to_human_readable(db.get_num_entries_loaded()) << " of "
+                  << to_human_readable(db.get_num_entries_total()) << " phylo-k-mers. " << std::endl
+                  << std::endl;
+
+        const auto tree = epik_amd::io::parse_newick(db.tree());
+        epik_amd::placer placer(db, tree, keep_at_most, keep_factor, num_threads, devices);
+        const auto tree_as_newick = epik_amd::io::to_newick(tree, true);
+        const auto jplace_filename = make_output_filename(query_file, output_dir);
+        const auto invocation = make_invocation(argc, argv);
+
+        epik_amd::io::jplace_writer jplace(jplace_filename, invocation, tree_as_newick);
+        jplace.start();
+
+        std::cout << "Instruction set: gfx950 (" << placer.device_count() << " device(s))" << std::endl;
+        std::cout << "Placing " << query_file << "..." << std::endl;
+        const auto begin = std::chrono::steady_clock::now();
+        size_t num_seq_placed = 0;
+        double average_speed = 0.0;
+        size_t num_iterations = 0;
+
+        epik_amd::io::batch_fasta reader(query_file, batch_size);
+        while (true) {
+            const auto batch = reader.next_batch();
+            if (batch.empty()) break;
+            const auto begin_batch = std::chrono::steady_clock::now();
+            const auto placed_batch = placer.place(batch, num_threads);
+            const auto end_batch = std::chrono::steady_clock::now();
+            auto ms_diff = (float)std::chrono::duration_cast<std::chrono::milliseconds>(end_batch - begin_batch).count();
+            if (ms_diff == 0) ms_diff = 1;
+            average_speed += 1000.0 * (double)batch_size / ms_diff;  // main.cpp:351-352 (nominal batch size)
+            jplace << placed_batch;
+            num_seq_placed += batch.size();
+            ++num_iterations;
+        }
+        jplace.end();
+        if (num_iterations) average_speed /= (double)num_iterations;
+        std::cout << std::endl
+                  << "Placed " << num_seq_placed << " sequences.\nAverage speed: " << to_human_readable(average_speed)
+                  << " seq/s.\n";
+        std::cout << "Output: " << jplace_filename << std::endl;
+        const auto placement_time =
+            (size_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - begin).count();
+        std::cout << "Placement time: " << humanize_time(placement_time) << " (" << placement_time << " ms)"
+                  << std::endl;
+        std::cout << "Done." << '\n' << std::flush;
+    } catch (const std::runtime_error& error) {
+        std::cerr << "Error: " << error.what() << std::endl;
+        return -1;
+    } catch (const std::exception& error) {  // std::stoul etc.
+        std::cerr << "Error: " << error.what() << std::endl;
+        return -1;
+    }
+    return 0;
+}
+
+#endif  // EPIK_AMD_NO_MAIN

@@ -1,0 +1,139 @@
+#include "placer.hpp"
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <thread>
+
+namespace epik_amd {
+
+using impl::placed_collection;
+using impl::placed_sequence;
+using impl::placement;
+using impl::sequence_map_t;
+
+placer::placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t keep_at_most, double keep_factor,
+               size_t /*max_threads*/, std::vector<int> devices)
+    : _db{db}
+    , _original_tree{original_tree}
+    , _threshold{score_threshold(db.omega(), db.kmer_size(), alphabet_size(db.sequence_type()))}  // place.cpp:87
+    , _log_threshold{std::log10(_threshold)}                                                      // place.cpp:88
+    , _keep_at_most{keep_at_most}
+    , _keep_factor{keep_factor}
+{
+    // pendant lengths (place.cpp:99-125)
+    const auto& index = _db.tree_index();
+    for (uint32_t i = 0; i < original_tree.get_node_count(); ++i) {
+        const auto node = _original_tree.get_by_postorder_id(i);
+        if (!node || i >= index.size())
+            throw std::runtime_error("Could not find node by post-order id: " + std::to_string(i));
+        const auto distal_length = (*node)->get_branch_length() / 2;
+        auto mean_subtree_branch_length = 0.0;
+        if (index[i].subtree_num_nodes > 1)
+            mean_subtree_branch_length = index[i].subtree_total_length / (double)index[i].subtree_num_nodes;
+        _pendant_lengths.push_back(mean_subtree_branch_length + distal_length);
+    }
+
+    const auto char_class = char_class_table(db.sequence_type());
+    epik_amd_placer_desc desc{};
+    desc.abi_version = EPIK_AMD_ABI_VERSION;
+    desc.kmer_size = (uint32_t)db.kmer_size();
+    desc.alphabet_size = alphabet_size(db.sequence_type());
+    desc.num_branches = (uint32_t)original_tree.get_node_count();
+    desc.keep_at_most = (uint32_t)keep_at_most;
+    desc.offset_bits = 64;
+    desc.keep_factor = keep_factor;
+    desc.threshold = _threshold;
+    desc.log_threshold = _log_threshold;
+    desc.num_keys = db.num_keys();
+    desc.num_entries = db.values().size();
+    desc.offsets = db.offsets().data();
+    desc.values = db.values().data();
+    desc.char_class = char_class.data();
+    if (devices.empty()) devices.push_back(0);
+    for (int device : devices) {
+        desc.device = device;
+        epik_amd_placer* handle = nullptr;
+        if (epik_amd_placer_create(&desc, &handle) != EPIK_AMD_OK) {
+            const std::string message = epik_amd_last_error();
+            for (auto* h : _handles) epik_amd_placer_destroy(h);
+            throw std::runtime_error("GPU placer: " + message);
+        }
+        _handles.push_back(handle);
+    }
+}
+
+placer::~placer() noexcept
+{
+    for (auto* h : _handles) epik_amd_placer_destroy(h);
+}
+
+placed_collection placer::place(const std::vector<seq_record>& seq_records, size_t /*num_threads*/)
+{
+    // identical sequences are placed once (place.cpp:73-81, 207-212)
+    sequence_map_t sequence_map;
+    std::vector<std::string_view> unique_sequences;
+    for (const auto& rec : seq_records) {
+        auto [it, inserted] = sequence_map.try_emplace(rec.sequence());
+        if (inserted) unique_sequences.push_back(rec.sequence());
+        it->second.push_back(rec.header());
+    }
+    const size_t n = unique_sequences.size();
+    std::vector<placed_sequence> placed_seqs(n);
+    if (n == 0) return {std::move(sequence_map), std::move(placed_seqs)};
+
+    // one contiguous shard of the unique reads per device
+    const size_t n_dev = _handles.size();
+    std::vector<std::string> errors(n_dev);
+    auto run_shard = [&](size_t d) {
+        const size_t begin = n * d / n_dev, end = n * (d + 1) / n_dev;
+        if (begin == end) return;
+        std::string bytes;
+        std::vector<uint64_t> offsets{0};
+        for (size_t i = begin; i < end; ++i) {
+            bytes.append(unique_sequences[i]);
+            offsets.push_back(bytes.size());
+        }
+        const size_t m = end - begin;
+        std::vector<epik_amd_placement> rows(m * _keep_at_most);
+        std::vector<uint32_t> n_rows(m), counts(m * _keep_at_most);
+        if (epik_amd_placer_place(_handles[d], bytes.data(), offsets.data(), m, rows.data(), n_rows.data(),
+                                  counts.data()) != EPIK_AMD_OK) {
+            errors[d] = epik_amd_last_error();
+            return;
+        }
+        for (size_t i = 0; i < m; ++i) {
+            auto& out = placed_seqs[begin + i];
+            out.sequence = unique_sequences[begin + i];
+            out.placements.reserve(n_rows[i]);
+            for (uint32_t r = 0; r < n_rows[i]; ++r) {
+                const auto& row = rows[i * _keep_at_most + r];
+                const size_t count = counts[i * _keep_at_most + r];
+                // rows fabricated for a read without hits carry 0.0 lengths (place.cpp:150)
+                double distal = 0.0, pendant = 0.0;
+                if (count != 0) {
+                    const auto node = _original_tree.get_by_postorder_id(row.branch);
+                    if (!node) {
+                        errors[d] = "Could not find node by post-order id: " + std::to_string(row.branch);
+                        return;
+                    }
+                    distal = (*node)->get_branch_length() / 2;  // place.cpp:435
+                    pendant = _pendant_lengths[row.branch];
+                }
+                out.placements.push_back({row.branch, row.score, row.lwr, count, distal, pendant});
+            }
+        }
+    };
+    if (n_dev == 1) {
+        run_shard(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t d = 0; d < n_dev; ++d) threads.emplace_back(run_shard, d);
+        for (auto& t : threads) t.join();
+    }
+    for (const auto& e : errors)
+        if (!e.empty()) throw std::runtime_error("GPU placer: " + e);
+    return {std::move(sequence_map), std::move(placed_seqs)};
+}
+
+}  // namespace epik_amd

@@ -1,0 +1,81 @@
+// placer.hpp -- host-side mirror of `epik::placer` over the C ABI of libepik_amd.so.
+//
+// Same names, arguments and error behaviour as the reference class
+// (epik/include/epik/place.h:39-140): construct with (db, tree, keep_at_most, keep_factor,
+// max_threads), call place(seq_records, num_threads) per FASTA batch, get a
+// placed_collection whose string_views point into the caller's batch.
+// Extra, MI355X-specific: a list of HIP devices; the unique reads of a batch are split
+// across them (database replicated, no collective).
+#ifndef EPIK_AMD_HOST_PLACER_HPP
+#define EPIK_AMD_HOST_PLACER_HPP
+
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "epik_amd.h"
+#include "phylo_kmer_db.hpp"
+#include "phylo_tree.hpp"
+#include "seq_record.hpp"
+
+namespace epik_amd::impl {
+
+/// "sequence content -> list of headers" (place.h:42)
+using sequence_map_t = std::unordered_map<std::string_view, std::vector<std::string_view>>;
+
+/// A placement of one sequence (place.h:45-56)
+struct placement {
+    using weight_ratio_type = double;
+    uint32_t branch_id;
+    float score;
+    weight_ratio_type weight_ratio;
+    size_t count;
+    phylo_node::branch_length_type distal_length;
+    phylo_node::branch_length_type pendant_length;
+};
+
+/// place.h:59-68
+struct placed_sequence {
+    std::string_view sequence;
+    std::vector<placement> placements;
+};
+
+/// place.h:72-75.  placed_seqs follow the first occurrence of each sequence in the batch
+/// (the reference: std::unordered_map iteration order, place.cpp:57-61).
+struct placed_collection {
+    sequence_map_t sequence_map;
+    std::vector<placed_sequence> placed_seqs;
+};
+
+}  // namespace epik_amd::impl
+
+namespace epik_amd {
+
+class placer {
+public:
+    using placed_collection = impl::placed_collection;
+
+    /// WARNING (as place.h:91-93): db and tree are kept by reference.
+    placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t keep_at_most, double keep_factor,
+           size_t max_threads, std::vector<int> devices = {0});
+    placer(const placer&) = delete;
+    placer& operator=(const placer&) = delete;
+    ~placer() noexcept;
+
+    placed_collection place(const std::vector<seq_record>& seq_records, size_t num_threads);
+
+    size_t device_count() const noexcept { return _handles.size(); }
+
+private:
+    const phylo_kmer_db& _db;
+    const phylo_tree& _original_tree;
+    const float _threshold;
+    const float _log_threshold;
+    const size_t _keep_at_most;
+    const double _keep_factor;
+    std::vector<double> _pendant_lengths;
+    std::vector<epik_amd_placer*> _handles;  // one per device
+};
+
+}  // namespace epik_amd
+#endif

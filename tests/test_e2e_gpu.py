@@ -1,0 +1,77 @@
+"""End to end through the native driver: EPIKAMD1 database + FASTA -> `epik.py place`
+-> epik-dna -> jplace, compared (strict differ: edge order, |dLWR| <= 1e-5) with a
+jplace assembled from the CPU oracle's rows."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from epik_amd import dbfile, jplace, jplace_diff, synth
+from epik_amd.placer import PlacedCollection, PlacedSequence, Placement, pendant_lengths
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_jplace(path, oracle_lib, db, tree, records):
+    seq_map = {}
+    for h, s in records:
+        seq_map.setdefault(s, []).append(h)
+    unique = list(seq_map)
+    data, offs = synth.pack_reads(unique)
+    rows, n_rows, counts = oracle_lib.Oracle.from_synth(db).place(data, offs)
+    distal, pendant = pendant_lengths(tree.branch_length, tree.subtree_num_nodes, tree.subtree_total_length)
+    placed = []
+    for i, s in enumerate(unique):
+        pl = []
+        for r in range(n_rows[i]):
+            b, c = int(rows[i, r]["branch"]), int(counts[i, r])
+            pl.append(Placement(b, float(rows[i, r]["score"]), float(rows[i, r]["lwr"]), c,
+                                float(distal[b]) if c else 0.0, float(pendant[b]) if c else 0.0))
+        placed.append(PlacedSequence(s, pl))
+    jplace.write_jplace(path, PlacedCollection(seq_map, placed), "oracle", tree.newick(jplace=True))
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0"])
+def test_epik_py_place_matches_oracle(tmp_path, oracle_lib, devices):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "epik_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    tree = synth.make_tree(60, seed=11)
+    db = synth.make_db(tree.num_nodes, kmer_size=8, seed=12, p_present=0.5)
+    db_path = str(tmp_path / "db.ekdb")
+    dbfile.write_db(db_path, db, tree.newick())
+    rng = np.random.default_rng(4)
+    records = []
+    for i in range(5000):
+        alpha = "ACGT" if i % 5 else "ACGTN"
+        records.append((f"read_{i}", "".join(rng.choice(list(alpha), size=int(rng.integers(5, 250))))))
+    records += [("dup_a", records[0][1]), ("dup_b", records[0][1]), ("short", "ACG")]
+    fasta = str(tmp_path / "q.fasta")
+    with open(fasta, "w") as fh:
+        for h, s in records:
+            fh.write(f">{h}\n")
+            for j in range(0, len(s), 70):
+                fh.write(s[j:j + 70] + "\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    if devices == "0":
+        cmd = [sys.executable, os.path.join(ROOT, "epik.py"), "place", "-i", db_path, "-o", str(out_dir), fasta]
+    else:  # two handles on the one GPU: exercises the multi-device sharding of the driver
+        cmd = [os.path.join(ROOT, "epik_amd", "bin", "epik-dna"), "-d", db_path, "-q", fasta, "-o", str(out_dir),
+               "--devices", devices, "--batch-size", "777"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "Placed 5003 sequences." in run.stdout and "Placement time:" in run.stdout
+    got_path = str(out_dir / "placements_q.fasta.jplace")
+    ref_path = str(tmp_path / "ref.jplace")
+    _oracle_jplace(ref_path, oracle_lib, db, tree, records)
+    got, ref = jplace.read_jplace(got_path), jplace.read_jplace(ref_path)
+    assert set(got) == set(ref) == {h for h, _ in records}
+    assert jplace_diff.diff_strict(got, ref) == []
+    # lengths are joined per branch on the host (place.cpp:110-123, 435-437)
+    for name in ("read_1", "dup_b"):
+        for x, y in zip(got[name], ref[name]):
+            assert x["distal_length"] == pytest.approx(y["distal_length"], rel=1e-9)
+            assert x["pendant_length"] == pytest.approx(y["pendant_length"], rel=1e-9)
+    assert got["short"] == []
