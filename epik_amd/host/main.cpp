@@ -256,9 +256,11 @@ int main(int argc, char** argv)
             const int n = std::stoi(parsed.get("gpus", "1"));
             for (int i = 0; i < n; ++i) devices.push_back(i);
         }
-        if (devices.empty() || epik_amd_device_count() < (int)devices.size())
-            throw std::runtime_error("Not enough HIP devices: " + std::to_string(epik_amd_device_count()) +
-                                     " visible (this placer has no CPU fallback)");
+        for (int device : devices)
+            if (device < 0 || device >= epik_amd_device_count())
+                throw std::runtime_error("HIP device " + std::to_string(device) + " is not available: " +
+                                         std::to_string(epik_amd_device_count()) +
+                                         " visible (this placer has no CPU fallback)");
 
         std::cout << "Loading database with mu=" << user_mu << " and omega=" << user_omega << "..." << std::endl;
         const auto db = epik_amd::load(db_file, user_mu, user_omega, max_entries);

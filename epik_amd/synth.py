@@ -49,7 +49,7 @@ class SynthTree:
         out = []
 
         def fmt(i: int) -> str:
-            s = f"{self.labels[i]}:{self.branch_length[i]:.6g}"
+            s = f"{self.labels[i]}:{self.branch_length[i]:.17g}"
             if jplace:
                 s += "{%d}" % i
             return s
