@@ -91,6 +91,21 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
+#ifdef EPIK_AMD_ABLATION
+    if (p->params.dbg) {  // diagnostic build: where the waves spent their cycles, by phase
+        unsigned long long t[8] = {0};
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(t, p->params.dbg, sizeof t, hipMemcpyDeviceToHost);
+        double sum = 0;
+        for (double x : t) sum += x;
+        const char *names[8] = {"front-issue", "lookup-wait+scan", "expand+stream", "correction", "rows-out+reset",
+                                "tau-rounds", "candidate-sweep", "score_sum+rank"};
+        std::fprintf(stderr, "phase shares of wave cycles:");
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, "  %s %.1f%%", names[i], 100 * t[i] / sum);
+        std::fprintf(stderr, "\n");
+        (void)hipFree(p->params.dbg);
+    }
+#endif
     (void)hipFree(p->d_offsets);
     (void)hipFree(p->d_values);
     (void)hipFree(p->d_db);
@@ -192,15 +207,19 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     // overrides the default.
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
-    const uint64_t slot_bytes = 128;
+    uint64_t slot_bytes = 128;
+    const char *lay = std::getenv("EPIK_AMD_LAYOUT");
+    // "packed" = the slotted machinery with 8-byte slots {len, tail}: no inline lists, a
+    // table as small as the CSR offsets, every list 128-byte aligned with 6-byte postings
+    if (lay && std::strcmp(lay, "packed") == 0) slot_bytes = 8;
     const bool narrow = d->num_branches <= 65536u;
     const uint32_t posting_bytes = narrow ? 6u : 8u;
     const uint32_t slot_cap = (uint32_t)((slot_bytes - 8u) / posting_bytes);
     const bool slotted_fits = d->num_keys * slot_bytes <= free_mem / 4;
     bool slotted = false;  // measured: the compact CSR is the faster of the two today
-    if (const char *lay = std::getenv("EPIK_AMD_LAYOUT")) {
+    if (lay) {
         if (std::strcmp(lay, "compact") == 0) slotted = false;
-        else if (std::strcmp(lay, "slotted") == 0) slotted = slotted_fits;
+        else if (std::strcmp(lay, "slotted") == 0 || std::strcmp(lay, "packed") == 0) slotted = slotted_fits;
     }
     auto offset_at = [&](uint64_t key) -> uint64_t {
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
@@ -230,7 +249,8 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_UNSUPPORTED, "tail region of 512 GiB or more");
         }
-        p->db_bytes = table_bytes + tail_units * 128u + 256u;  // +256: the kernel's loads stay inside
+        const uint64_t table_padded = (table_bytes + 127u) & ~127ull;  // the tail starts on a line
+        p->db_bytes = table_padded + tail_units * 128u + 256u;  // +256: the kernel's loads stay inside
         std::vector<uint8_t> host;
         try {
             host.assign(p->db_bytes, 0);
@@ -261,7 +281,7 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
             uint32_t hdr[2] = {(uint32_t)len, 0u};
             if (len > slot_cap) {
                 hdr[1] = (uint32_t)unit;
-                write_list(host.data() + table_bytes + unit * 128u, d->values + b, len);
+                write_list(host.data() + table_padded + unit * 128u, d->values + b, len);
                 unit += (len * posting_bytes + 127u) / 128u;
             } else if (len) {
                 write_list(slot + 8, d->values + b, len);
@@ -271,7 +291,7 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
         CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_db), p->db_bytes));
         CREATE_TRY(hipMemcpy(p->d_db, host.data(), p->db_bytes, hipMemcpyHostToDevice));
         pp.db = p->d_db;
-        pp.tail_offset = table_bytes;
+        pp.tail_offset = table_padded;
         pp.slot_bytes = (uint32_t)slot_bytes;
         pp.slot_cap = slot_cap;
     } else {
@@ -306,8 +326,13 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     // cells + chunk descriptors of one round + one trip of spare entries (the kernel prefetches a trip ahead)
     pp.lds_wave_bytes = pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
     pp.ablate = 0;
+    pp.dbg = nullptr;
 #ifdef EPIK_AMD_ABLATION
     if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
+    if (const char *st = std::getenv("EPIK_AMD_STAMPS"); st && st[0] == '1') {
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), 8 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(pp.dbg, 0, 8 * sizeof(unsigned long long)));
+    }
 #endif
 
     // geometry: as many waves per workgroup (<= 4) as fit the 160 KiB of LDS

@@ -52,6 +52,7 @@ struct PlaceParams {
     uint32_t n_pad;                  // num_branches rounded up to 64
     uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + pass descriptors)
     uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
+    unsigned long long *dbg;         // phase cycle sums (-DEPIK_AMD_ABLATION builds, EPIK_AMD_STAMPS=1)
 };
 
 hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool lds_atomic, dim3 grid, dim3 block,

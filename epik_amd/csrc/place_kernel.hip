@@ -174,14 +174,26 @@ struct CompactLayout {
         return (uint64_t)(p.values + addr + (uint64_t)c * 64u);
     }
     __device__ static __forceinline__ uint64_t dummy_address(const PlaceParams &p) { return (uint64_t)p.values; }
+    // A chunk descriptor {address (48 bits) | count << 48} is unpacked by every lane at once,
+    // once per trip of the ring (vector work), into kFields words; a stage then pulls its
+    // chunk's words out with v_readlane: the CU's single scalar unit does no unpacking.
+    static constexpr int kFields = 4;  // address lo, address hi, count, byte offset of the last posting
+    __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
+    {
+        const uint32_t hi = (uint32_t)(d >> 32);
+        f[0] = (uint32_t)d;
+        f[1] = hi & 0xffffu;
+        f[2] = hi >> 16;
+        f[3] = (f[2] ? f[2] - 1u : 0u) * 8u;
+    }
     // Puts one chunk's load in flight: lane l reads posting min(l, cnt-1) (lanes past the end
     // re-read the last posting: same cache lines, no exec masking, and an empty chunk still
-    // performs a real load so that vmcnt bookkeeping is exact).  base/cnt are wave-uniform.
-    __device__ static __forceinline__ void issue(uint64_t base, uint32_t cnt, int lane, uint32_t &branch,
+    // performs a real load so that vmcnt bookkeeping is exact).  f[] is wave-uniform.
+    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], int lane, uint32_t &branch,
                                                  uint32_t &score)
     {
-        const uint32_t last = cnt ? cnt - 1u : 0u;
-        const uint32_t off = min((uint32_t)lane, last) * 8u;
+        const uint64_t base = ((uint64_t)f[1] << 32) | f[0];
+        const uint32_t off = min((uint32_t)lane * 8u, f[3]);
         v2u out;
         // s_nop 4: base comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
         asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2"
@@ -223,15 +235,28 @@ struct SlottedLayout {
         return (uint64_t)(p.db + addr + (uint64_t)c * 64u * kPosting);
     }
     __device__ static __forceinline__ uint64_t dummy_address(const PlaceParams &p) { return (uint64_t)p.db; }
+    // see CompactLayout: address lo, address hi, count, offset of the last score,
+    // offset of the last branch id, offset of the branch array (= 4 * count)
+    static constexpr int kFields = 6;
+    __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
+    {
+        const uint32_t hi = (uint32_t)(d >> 32);
+        f[0] = (uint32_t)d;
+        f[1] = hi & 0xffffu;
+        f[2] = hi >> 16;
+        const uint32_t last = f[2] ? f[2] - 1u : 0u;
+        f[3] = last * 4u;
+        f[4] = last * (uint32_t)sizeof(BranchT);
+        f[5] = f[2] * 4u;
+    }
     // One chunk = f32 score[cnt] then BranchT branch[cnt]: two loads, lane l reads posting
-    // min(l, cnt-1) of each (see CompactLayout::issue).  base/cnt are wave-uniform.
-    __device__ static __forceinline__ void issue(uint64_t base, uint32_t cnt, int lane, uint32_t &branch,
+    // min(l, cnt-1) of each (see CompactLayout::issue).  f[] is wave-uniform.
+    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], int lane, uint32_t &branch,
                                                  uint32_t &score)
     {
-        const uint32_t last = cnt ? cnt - 1u : 0u;
-        const uint32_t l = min((uint32_t)lane, last);
-        const uint32_t off_s = l * 4u;
-        const uint32_t off_b = cnt * 4u + l * (uint32_t)sizeof(BranchT);
+        const uint64_t base = ((uint64_t)f[1] << 32) | f[0];
+        const uint32_t off_s = min((uint32_t)lane * 4u, f[3]);
+        const uint32_t off_b = min((uint32_t)lane * (uint32_t)sizeof(BranchT), f[4]) + f[5];
         if (sizeof(BranchT) == 2) {
             asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_ushort %1, %3, %4"
                          : "=&v"(score), "=&v"(branch)
@@ -327,6 +352,307 @@ __device__ __forceinline__ void accumulate_chunk(const WaveLds &lds, uint2 e, bo
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------
+// The two parts of a read's placement that need many registers -- the cold ambiguous-k-mer
+// sweep (double-precision pow) and the epilogue (double-precision exp10, unrolled sweeps) --
+// are real functions, not inlined: inlined, they set the register allocation of the whole
+// kernel (~125 VGPRs) although the streaming loop itself needs ~70.  `kp` points at the
+// kernel's own argument block.
+// ---------------------------------------------------------------------------------
+template <typename Layout>
+__device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__restrict__ kp, WaveLds lds,
+                                                          const uint8_t *__restrict__ seq, uint64_t len,
+                                                          uint64_t n_kmers)
+{
+    const PlaceParams &p = *kp;
+    const int lane = lane_id();
+    const uint32_t k = p.kmer_size;
+    const uint32_t sigma = p.alphabet_size;
+    const uint32_t stride = kWave - (k - 1);
+    const float k_f = (float)k;
+    // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
+    {
+        const float thr = p.threshold;
+        for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
+            const Tile t = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
+            if (t.amb_mask == 0) continue;
+            const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+            const uint64_t inv_w = (t.inv_mask >> lane) & wmask;
+            const uint64_t amb_w = (t.amb_mask >> lane) & wmask;
+            const bool is_amb = t.in_range && inv_w == 0 && __popcll(amb_w) == 1;
+            uint64_t todo = __ballot(is_amb);
+            while (todo) {
+                const int m = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint64_t amb_w_m = (t.amb_mask >> m) & wmask;
+                const int j = __builtin_ctzll(amb_w_m);          // ambiguous position in the window
+                const uint32_t cls = __builtin_amdgcn_readlane(t.cls, m + j);
+                const uint32_t key0 = __builtin_amdgcn_readlane(t.key, m);
+                uint32_t weight = 1;
+                for (uint32_t q = (uint32_t)j + 1; q < k; ++q) weight *= sigma;
+                // every resolved key, ascending state order, is searched on its own (:308-312)
+                for (uint32_t st = 0; st < sigma; ++st) {
+                    if (!((cls >> st) & 1u)) continue;
+                    const uint32_t key = key0 + st * weight;
+                    uint64_t b0;
+                    uint32_t n;
+                    Layout::lookup(p, key, b0, n);
+                    for (uint32_t off = 0; off < n; off += kWave) {
+                        if (off + (uint32_t)lane < n) {
+                            const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);
+                            uint2 cv = lds.cell[e.x];
+                            const uint32_t c = cv.y;
+                            // Only the first ambiguous key that reaches a branch scores it:
+                            // later ones find counts_amb[b] != 0 and stay out of l_amb (:385-388).
+                            if (!(c & kAmbSeen)) {
+                                // counts_amb[b] == 1, scores_amb[b] == float(pow(10, score)) (:390-391)
+                                const float prob = (float)pow(10.0, (double)__uint_as_float(e.y));
+                                const float avg = __fdiv_rn(
+                                    __fadd_rn(prob, __fmul_rn((float)(k - 1u), thr)), k_f);  // :400-402
+                                cv.y = (c | kAmbSeen) + 1u;                                    // :409
+                                cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), avg)); // :410
+                                lds.cell[e.x] = cv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+}
+
+template <typename Layout>
+__device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds lds,
+                                                         uint64_t read, uint64_t n_kmers)
+{
+    const PlaceParams &p = *kp;
+    const int lane = lane_id();
+    const uint32_t N = p.num_branches;
+    const float k_f = (float)p.kmer_size;
+    const float log_thr = p.log_threshold;
+    // ---- score correction (:418-422), dense over N --------------------------------------
+    // cell[i].x becomes the corrected score (-inf = "not an edge"), cell[i].y the count.
+    const float nk_f = (float)n_kmers;
+    const uint32_t nk_u = (uint32_t)n_kmers;  // the host rejects reads of 2^32 characters or more
+    uint32_t touched = 0;
+    uint32_t lane_best = 0;  // ord key of this lane's best score; 0 = none
+    // Four rows per lane and trip: the four LDS reads go out together (one latency, not
+    // four); with 4 waves per SIMD there is little else to hide it behind.
+    constexpr int kUnroll = 4;
+    for (uint32_t base = 0; base < N; base += kUnroll * kWave) {
+        uint2 cv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
+            cv[u] = i < N ? lds.cell[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
+            const uint32_t c = cv[u].y & ~kAmbSeen;
+            float s = -INFINITY;
+            if (c != 0) {
+                s = __uint_as_float(cv[u].x);
+                s = __fadd_rn(s, __fmul_rn((float)(nk_u - c), log_thr));  // :420
+                s = __fdiv_rn(s, k_f);                                    // :421
+                ++touched;
+                lane_best = max(lane_best, ord_f32(s));
+            }
+            if (i < N) lds.cell[i] = make_uint2(__float_as_uint(s), c);
+        }
+    }
+    touched = wave_sum_u32(touched);
+    const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
+
+    // ---- select_best_placements (:134-159) + sum_scores (:164-184) --------------------
+    // Candidates = every edge whose score reaches tau, the n_sel-th largest of the 64
+    // per-lane maxima: at least n_sel edges qualify, usually only a few more.  They are
+    // compacted into LDS and ranked by counting, rank = final row (score desc, branch asc).
+    // The same sweep accumulates sum_scores relative to the largest term, 10^ref_score:
+    //   score_sum = 10^ref_score * (sum_i 10^(score_i - ref_score) + (N - n) * 10^(thr - ref_score))
+    // with the relative terms in float32 (v_exp_f32): ~1e-7 relative on score_sum, i.e. on
+    // every like_weight_ratio (bar: 1e-5).  Row scores and 10^ref_score stay in double, and
+    // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
+    const uint32_t keep = p.keep_at_most;
+    uint2 *cand = reinterpret_cast<uint2 *>(lds.desc);  // {ord(score), branch}
+    constexpr uint32_t kCandCap = (uint32_t)kTilesPerPass * kWave;
+    constexpr float kLog2Of10 = 3.32192809488736f;
+    uint32_t n_sel, n_cand;
+    float best_score;
+    float rel_sum = 0.0f;          // this lane's share of sum_i 10^(score_i - ref_score)
+    bool ranked_in_place = false;  // cand[] already sorted: rank == index
+    uint32_t tau = 1;
+    if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
+        n_sel = n_cand = keep;
+        best_score = thr_score;
+        if ((uint32_t)lane < keep) cand[lane] = make_uint2(ord_f32(thr_score), (uint32_t)lane);
+        ranked_in_place = true;
+    } else {
+        n_sel = keep < touched ? keep : touched;  // :137
+        uint32_t cur = lane_best, got = 0, top = 0;
+        while (got < n_sel) {
+            const uint32_t m = wave_max_u32(cur);
+            if (m == 0) {  // fewer lanes hold edges than rows wanted: every edge is a candidate
+                tau = 1;
+                break;
+            }
+            if (got == 0) top = m;
+            got += (uint32_t)__popcll(__ballot(cur == m));
+            tau = m;
+            if (cur == m) cur = 0;
+        }
+        best_score = unord_f32(top);
+    }
+    const float ref_score = fmaxf(best_score, thr_score);
+    const bool relative_sum = ref_score > -280.0f;  // wave-uniform
+    if (touched != 0) {
+        n_cand = 0;
+        for (uint32_t base = 0; base < N; base += kUnroll * kWave) {
+            uint2 cv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
+                cv[u] = i < N ? lds.cell[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
+                uint32_t key = 0;
+                if (cv[u].y != 0) {  // rows past N were read as {0, 0}
+                    const float sc = __uint_as_float(cv[u].x);
+                    key = ord_f32(sc);
+                    rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
+                }
+                const bool is_cand = key >= tau;  // tau >= 1, key 0 = not an edge
+                const uint64_t m = __ballot(is_cand);
+                if (m) {
+                    const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (is_cand && slot < kCandCap) cand[slot] = make_uint2(key, i);
+                    n_cand += (uint32_t)__popcll(m);
+                }
+            }
+        }
+        if (n_cand > kCandCap) {
+            // Too many ties at tau for the candidate buffer: repeated selection over all
+            // edges instead (slow, rare).  Leaves cand[0..n_sel) sorted.
+            uint64_t prev = ~0ull;
+            for (uint32_t r = 0; r < n_sel; ++r) {
+                uint64_t best = 0;
+                for (uint32_t i = lane; i < N; i += kWave) {
+                    const uint2 cv = lds.cell[i];
+                    const uint64_t key = ((uint64_t)ord_f32(__uint_as_float(cv.x)) << 32) | (uint64_t)(~i);
+                    if (cv.y != 0 && key < prev && key > best) best = key;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const uint64_t o = shfl_xor_u64(best, m);
+                    best = o > best ? o : best;
+                }
+                if (lane == 0) cand[r] = make_uint2((uint32_t)(best >> 32), ~(uint32_t)best);
+                prev = best;
+            }
+            n_cand = n_sel;
+            ranked_in_place = true;
+        }
+    }
+    double score_sum;
+    {
+        const float not_placed = (float)N - (float)touched;  // :174
+        if (relative_sum) {
+            double rel = wave_sum_f64((double)rel_sum);
+            if (not_placed != 0.0f)
+                rel += (double)(not_placed *
+                                __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
+            score_sum = pow10_f64((double)ref_score) * rel;
+        } else {
+            // everything in double, term by term, as place.cpp:174-183
+            double sum_placed = 0.0;
+            for (uint32_t i = lane; i < N; i += kWave) {
+                const uint2 cv = lds.cell[i];
+                if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
+            }
+            sum_placed = wave_sum_f64(sum_placed);
+            score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
+        }
+    }
+    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
+
+    // ---- rank, LWR (:241-264), filter_by_ratio (:188-199); <= 3 candidates per lane ------
+    const double best_power = pow10_f64((double)best_score);
+    const double best_ratio =
+        (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
+    const double ratio_threshold = best_ratio * keep_factor;                      // :192
+    const uint32_t n_q = (n_cand + kWave - 1) / kWave;
+    uint64_t my_key[kTilesPerPass];
+    uint32_t my_rank[kTilesPerPass];
+    double my_lwr[kTilesPerPass];
+#pragma unroll
+    for (int q = 0; q < kTilesPerPass; ++q) {
+        const uint32_t idx = (uint32_t)q * kWave + (uint32_t)lane;
+        my_key[q] = 0;
+        my_rank[q] = ranked_in_place ? idx : 0u;
+        my_lwr[q] = 0.0;
+        if ((uint32_t)q < n_q && idx < n_cand) {
+            const uint2 c = cand[idx];
+            my_key[q] = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
+        }
+    }
+    if (!ranked_in_place) {
+        // cand[j] is read at the same address by every lane (LDS broadcast); four per trip.
+        // Entries past n_cand are stale: their key is forced to 0, which outranks nothing.
+        for (uint32_t j0 = 0; j0 < n_cand; j0 += kUnroll) {
+            uint2 c[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) c[u] = cand[j0 + (uint32_t)u];  // < kCandCap + kUnroll: spare entries exist
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const uint64_t kj =
+                    (j0 + (uint32_t)u < n_cand) ? (((uint64_t)c[u].x << 32) | (uint64_t)(~c[u].y)) : 0ull;
+                my_rank[0] += kj > my_key[0] ? 1u : 0u;
+                if (n_q > 1) {
+#pragma unroll
+                    for (int q = 1; q < kTilesPerPass; ++q) my_rank[q] += kj > my_key[q] ? 1u : 0u;
+                }
+            }
+        }
+    }
+    uint64_t kept_ranks = 0;  // bit r set <=> the row of rank r passes the filter
+#pragma unroll
+    for (int q = 0; q < kTilesPerPass; ++q) {
+        if ((uint32_t)q < n_q) {
+            const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
+            if (has_row && score_sum != 0.0) {
+                const double power = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));  // :254
+                my_lwr[q] = (power == 0.0) ? 0.0 : power / score_sum;                             // :255-262
+            }
+            if (has_row && my_lwr[q] >= ratio_threshold) kept_ranks |= 1ull << my_rank[q];      // :197
+        }
+    }
+    kept_ranks = wave_or_u64(kept_ranks);
+#pragma unroll
+    for (int q = 0; q < kTilesPerPass; ++q) {
+        if ((uint32_t)q < n_q) {
+            const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
+            if (has_row && ((kept_ranks >> my_rank[q]) & 1ull)) {
+                const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << my_rank[q]) - 1ull));
+                const uint32_t branch = ~(uint32_t)my_key[q];
+                epik_amd_placement out;
+                out.branch = branch;
+                out.score = unord_f32((uint32_t)(my_key[q] >> 32));
+                out.lwr = my_lwr[q];
+                p.rows[read * keep + slot] = out;
+                if (p.kmer_counts)
+                    p.kmer_counts[read * keep + slot] = (touched && branch < N) ? lds.cell[branch].y : 0u;
+            }
+        }
+    }
+    if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
+
+    // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
+    for (uint32_t i = lane; i < N; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+}
+
 template <typename Layout, bool kLdsAtomic>
 __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
 {
@@ -341,18 +667,29 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
         lds.cell = reinterpret_cast<uint2 *>(base);
         lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * 8);
     }
+    // the argument block itself, for the out-of-line parts (no private copy of `p`)
+    const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t N = p.num_branches;
     for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
 
     const uint32_t k = p.kmer_size;
     const uint32_t sigma = p.alphabet_size;
     const uint32_t stride = kWave - (k - 1);  // windows per 64-character tile
-    const float k_f = (float)k;
-    const float log_thr = p.log_threshold;
-
     const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave_in_block;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
 
+#ifdef EPIK_AMD_ABLATION
+    unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define EPIK_STAMP(k)                                                        \
+    if (p.dbg) {                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        dbg_t[k] += now_ - dbg_last;                                         \
+        dbg_last = now_;                                                     \
+    }
+    unsigned long long dbg_last = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#else
+#define EPIK_STAMP(k)
+#endif
     for (uint64_t read = wave_global; read < p.n_reads; read += total_waves) {
         const uint64_t seq_begin = p.seq_offsets[read];
         const uint64_t len = p.seq_offsets[read + 1] - seq_begin;
@@ -391,6 +728,7 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
                     if (exact) Layout::lookup(p, tl.key, start[t], llen[t]);
                 }
             }
+            EPIK_STAMP(0)  // front end: encode + lookups issued
             // (2) lists -> chunks of <= 64 postings, in read order.  Each lane knows how many
             // chunks its k-mers need; an exclusive scan over (tile, lane) gives every chunk its
             // position in the stream, and the lanes write the chunk descriptors
@@ -414,6 +752,7 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
             if (p.ablate & 16u) most = 0;   // (with 8) skip the chunk expansion too
 #endif
             uint64_t *chunks = lds.desc;
+            EPIK_STAMP(1)  // lookups landed, scan done
             for (uint32_t w0 = 0; w0 < total; w0 += kChunkCap) {  // one round unless > kChunkCap chunks
                 const uint32_t n_round = min(total - w0, kChunkCap);
                 const uint32_t n_padded = (n_round + (uint32_t)kRing - 1u) & ~((uint32_t)kRing - 1u);
@@ -440,33 +779,36 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
 #pragma unroll
                 for (int i = 0; i < kRing; ++i) ring_b[i] = ring_s[i] = ring_cnt[i] = 0;
                 auto consume = [&](uint32_t br, uint32_t sc_bits, uint32_t cnt, auto &&between) {
-                    // The LDS read of the score cells goes out first, `between` (the refill)
-                    // overlaps its latency, the add and the write-back come last.
-                    const bool active = (uint32_t)lane < cnt;
+                    // Every lane reads its cell (lanes past the chunk's end hold a copy of the
+                    // last posting: a valid address, a broadcast read); `between` (the refill)
+                    // overlaps the LDS latency; the add and the write-back come last and only
+                    // the chunk's own lanes write.
                     const float sc = __uint_as_float(sc_bits);
-                    uint2 cv = make_uint2(0u, 0u);
 #ifdef EPIK_AMD_ABLATION
                     const bool skip_acc = (p.ablate & 1u) != 0;
                     if (skip_acc) asm volatile("" ::"v"(br), "v"(sc));
 #else
                     constexpr bool skip_acc = false;
 #endif
-                    if (!kLdsAtomic && !skip_acc && active) cv = lds.cell[br];  // ds_read_b64
+                    uint2 *cell = &lds.cell[br];
+                    uint2 cv = make_uint2(0u, 0u);
+                    if (!kLdsAtomic && !skip_acc) cv = *cell;  // ds_read_b64, all lanes
                     between();
                     asm volatile("" : "+v"(cv.x), "+v"(cv.y));  // keep the adds below the refill
-                    if (!skip_acc && active) {
+                    if (!skip_acc && (uint32_t)lane < cnt) {
                         if (kLdsAtomic) {
                             accumulate_chunk<true>(lds, make_uint2(br, sc_bits), true);
                         } else {
                             cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), sc));  // :366
                             cv.y += 1u;                                                    // :365
-                            lds.cell[br] = cv;                                             // ds_write_b64
+                            *cell = cv;                                                    // ds_write_b64
                         }
                     }
                 };
                 uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
                 for (uint32_t c0 = 0; c0 < n_padded; c0 += kRing) {
-                    const uint64_t d_cur = d_next;
+                    uint32_t field[Layout::kFields];
+                    Layout::prepare(d_next, field);
                     d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
 #pragma unroll
                     for (int i = 0; i < kRing; ++i) {
@@ -480,10 +822,11 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
                                      : "memory");
                         const uint32_t cnt = ring_cnt[i];
                         consume(br, sc_bits, cnt, [&]() {
-                            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)d_cur, i);
-                            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(d_cur >> 32), i);
-                            ring_cnt[i] = hi >> 16;
-                            Layout::issue(((uint64_t)(hi & 0xffffu) << 32) | lo, hi >> 16, lane, ring_b[i], ring_s[i]);
+                            uint32_t f[Layout::kFields];
+#pragma unroll
+                            for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
+                            ring_cnt[i] = f[2];
+                            Layout::issue(f, lane, ring_b[i], ring_s[i]);
                         });
                     }
                 }
@@ -509,55 +852,9 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
             }
         }
 
+        EPIK_STAMP(2)  // expansion + stream
         // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
-        if (any_amb) {
-            const float thr = p.threshold;
-            for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
-                const Tile t = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
-                if (t.amb_mask == 0) continue;
-                const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-                const uint64_t inv_w = (t.inv_mask >> lane) & wmask;
-                const uint64_t amb_w = (t.amb_mask >> lane) & wmask;
-                const bool is_amb = t.in_range && inv_w == 0 && __popcll(amb_w) == 1;
-                uint64_t todo = __ballot(is_amb);
-                while (todo) {
-                    const int m = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const uint64_t amb_w_m = (t.amb_mask >> m) & wmask;
-                    const int j = __builtin_ctzll(amb_w_m);          // ambiguous position in the window
-                    const uint32_t cls = __builtin_amdgcn_readlane(t.cls, m + j);
-                    const uint32_t key0 = __builtin_amdgcn_readlane(t.key, m);
-                    uint32_t weight = 1;
-                    for (uint32_t q = (uint32_t)j + 1; q < k; ++q) weight *= sigma;
-                    // every resolved key, ascending state order, is searched on its own (:308-312)
-                    for (uint32_t st = 0; st < sigma; ++st) {
-                        if (!((cls >> st) & 1u)) continue;
-                        const uint32_t key = key0 + st * weight;
-                        uint64_t b0;
-                        uint32_t n;
-                        Layout::lookup(p, key, b0, n);
-                        for (uint32_t off = 0; off < n; off += kWave) {
-                            if (off + (uint32_t)lane < n) {
-                                const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);
-                                uint2 cv = lds.cell[e.x];
-                                const uint32_t c = cv.y;
-                                // Only the first ambiguous key that reaches a branch scores it:
-                                // later ones find counts_amb[b] != 0 and stay out of l_amb (:385-388).
-                                if (!(c & kAmbSeen)) {
-                                    // counts_amb[b] == 1, scores_amb[b] == float(pow(10, score)) (:390-391)
-                                    const float prob = (float)pow(10.0, (double)__uint_as_float(e.y));
-                                    const float avg = __fdiv_rn(
-                                        __fadd_rn(prob, __fmul_rn((float)(k - 1u), thr)), k_f);  // :400-402
-                                    cv.y = (c | kAmbSeen) + 1u;                                    // :409
-                                    cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), avg)); // :410
-                                    lds.cell[e.x] = cv;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        if (any_amb) place_ambiguous<Layout>(kp, lds, seq, len, n_kmers);
 
 #ifdef EPIK_AMD_ABLATION
         if (p.ablate & 2u) {  // skip the whole epilogue
@@ -567,201 +864,14 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
             continue;
         }
 #endif
-        // ---- score correction (:418-422), dense over N --------------------------------------
-        // cell[i].x becomes the corrected score (-inf = "not an edge"), cell[i].y the count.
-        const float nk_f = (float)n_kmers;
-        const uint32_t nk_u = (uint32_t)n_kmers;  // the host rejects reads of 2^32 characters or more
-        uint32_t touched = 0;
-        uint32_t lane_best = 0;  // ord key of this lane's best score; 0 = none
-        for (uint32_t i = lane; i < N; i += kWave) {
-            uint2 cv = lds.cell[i];
-            const uint32_t c = cv.y & ~kAmbSeen;
-            float s = -INFINITY;
-            if (c != 0) {
-                s = __uint_as_float(cv.x);
-                s = __fadd_rn(s, __fmul_rn((float)(nk_u - c), log_thr));  // :420
-                s = __fdiv_rn(s, k_f);                                    // :421
-                ++touched;
-                lane_best = max(lane_best, ord_f32(s));
-            }
-            lds.cell[i] = make_uint2(__float_as_uint(s), c);
-        }
-        touched = wave_sum_u32(touched);
-        const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
-
-        // ---- select_best_placements (:134-159) + sum_scores (:164-184) --------------------
-        // Candidates = every edge whose score reaches tau, the n_sel-th largest of the 64
-        // per-lane maxima: at least n_sel edges qualify, usually only a few more.  They are
-        // compacted into LDS and ranked by counting, rank = final row (score desc, branch asc).
-        // The same sweep accumulates sum_scores relative to the largest term, 10^ref_score:
-        //   score_sum = 10^ref_score * (sum_i 10^(score_i - ref_score) + (N - n) * 10^(thr - ref_score))
-        // with the relative terms in float32 (v_exp_f32): ~1e-7 relative on score_sum, i.e. on
-        // every like_weight_ratio (bar: 1e-5).  Row scores and 10^ref_score stay in double, and
-        // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
-        const uint32_t keep = p.keep_at_most;
-        uint2 *cand = reinterpret_cast<uint2 *>(lds.desc);  // {ord(score), branch}
-        constexpr uint32_t kCandCap = (uint32_t)kTilesPerPass * kWave;
-        constexpr float kLog2Of10 = 3.32192809488736f;
-        uint32_t n_sel, n_cand;
-        float best_score;
-        float rel_sum = 0.0f;          // this lane's share of sum_i 10^(score_i - ref_score)
-        bool ranked_in_place = false;  // cand[] already sorted: rank == index
-        uint32_t tau = 1;
-        if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
-            n_sel = n_cand = keep;
-            best_score = thr_score;
-            if ((uint32_t)lane < keep) cand[lane] = make_uint2(ord_f32(thr_score), (uint32_t)lane);
-            ranked_in_place = true;
-        } else {
-            n_sel = keep < touched ? keep : touched;  // :137
-            uint32_t cur = lane_best, got = 0, top = 0;
-            while (got < n_sel) {
-                const uint32_t m = wave_max_u32(cur);
-                if (m == 0) {  // fewer lanes hold edges than rows wanted: every edge is a candidate
-                    tau = 1;
-                    break;
-                }
-                if (got == 0) top = m;
-                got += (uint32_t)__popcll(__ballot(cur == m));
-                tau = m;
-                if (cur == m) cur = 0;
-            }
-            best_score = unord_f32(top);
-        }
-        const float ref_score = fmaxf(best_score, thr_score);
-        const bool relative_sum = ref_score > -280.0f;  // wave-uniform
-        if (touched != 0) {
-            n_cand = 0;
-            for (uint32_t base = 0; base < N; base += kWave) {
-                const uint32_t i = base + (uint32_t)lane;
-                uint32_t key = 0;
-                if (i < N) {
-                    const uint2 cv = lds.cell[i];
-                    if (cv.y != 0) {
-                        const float sc = __uint_as_float(cv.x);
-                        key = ord_f32(sc);
-                        rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
-                    }
-                }
-                const bool is_cand = key >= tau;  // tau >= 1, key 0 = not an edge
-                const uint64_t m = __ballot(is_cand);
-                if (m) {
-                    const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (is_cand && slot < kCandCap) cand[slot] = make_uint2(key, i);
-                    n_cand += (uint32_t)__popcll(m);
-                }
-            }
-            if (n_cand > kCandCap) {
-                // Too many ties at tau for the candidate buffer: repeated selection over all
-                // edges instead (slow, rare).  Leaves cand[0..n_sel) sorted.
-                uint64_t prev = ~0ull;
-                for (uint32_t r = 0; r < n_sel; ++r) {
-                    uint64_t best = 0;
-                    for (uint32_t i = lane; i < N; i += kWave) {
-                        const uint2 cv = lds.cell[i];
-                        const uint64_t key = ((uint64_t)ord_f32(__uint_as_float(cv.x)) << 32) | (uint64_t)(~i);
-                        if (cv.y != 0 && key < prev && key > best) best = key;
-                    }
-#pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) {
-                        const uint64_t o = shfl_xor_u64(best, m);
-                        best = o > best ? o : best;
-                    }
-                    if (lane == 0) cand[r] = make_uint2((uint32_t)(best >> 32), ~(uint32_t)best);
-                    prev = best;
-                }
-                n_cand = n_sel;
-                ranked_in_place = true;
-            }
-        }
-        double score_sum;
-        {
-            const float not_placed = (float)N - (float)touched;  // :174
-            if (relative_sum) {
-                double rel = wave_sum_f64((double)rel_sum);
-                if (not_placed != 0.0f)
-                    rel += (double)(not_placed *
-                                    __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
-                score_sum = pow10_f64((double)ref_score) * rel;
-            } else {
-                // everything in double, term by term, as place.cpp:174-183
-                double sum_placed = 0.0;
-                for (uint32_t i = lane; i < N; i += kWave) {
-                    const uint2 cv = lds.cell[i];
-                    if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
-                }
-                sum_placed = wave_sum_f64(sum_placed);
-                score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
-            }
-        }
-        const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
-
-        // ---- rank, LWR (:241-264), filter_by_ratio (:188-199); <= 3 candidates per lane ------
-        const double best_power = pow10_f64((double)best_score);
-        const double best_ratio =
-            (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
-        const double ratio_threshold = best_ratio * keep_factor;                      // :192
-        const uint32_t n_q = (n_cand + kWave - 1) / kWave;
-        uint64_t my_key[kTilesPerPass];
-        uint32_t my_rank[kTilesPerPass];
-        double my_lwr[kTilesPerPass];
-#pragma unroll
-        for (int q = 0; q < kTilesPerPass; ++q) {
-            const uint32_t idx = (uint32_t)q * kWave + (uint32_t)lane;
-            my_key[q] = 0;
-            my_rank[q] = ranked_in_place ? idx : 0u;
-            my_lwr[q] = 0.0;
-            if ((uint32_t)q < n_q && idx < n_cand) {
-                const uint2 c = cand[idx];
-                my_key[q] = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
-            }
-        }
-        if (!ranked_in_place) {
-            for (uint32_t j = 0; j < n_cand; ++j) {
-                const uint2 c = cand[j];  // same address in every lane: LDS broadcast
-                const uint64_t kj = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
-                my_rank[0] += kj > my_key[0] ? 1u : 0u;
-                if (n_q > 1) {
-#pragma unroll
-                    for (int q = 1; q < kTilesPerPass; ++q) my_rank[q] += kj > my_key[q] ? 1u : 0u;
-                }
-            }
-        }
-        uint64_t kept_ranks = 0;  // bit r set <=> the row of rank r passes the filter
-#pragma unroll
-        for (int q = 0; q < kTilesPerPass; ++q) {
-            if ((uint32_t)q < n_q) {
-                const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-                if (has_row && score_sum != 0.0) {
-                    const double power = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));  // :254
-                    my_lwr[q] = (power == 0.0) ? 0.0 : power / score_sum;                             // :255-262
-                }
-                if (has_row && my_lwr[q] >= ratio_threshold) kept_ranks |= 1ull << my_rank[q];      // :197
-            }
-        }
-        kept_ranks = wave_or_u64(kept_ranks);
-#pragma unroll
-        for (int q = 0; q < kTilesPerPass; ++q) {
-            if ((uint32_t)q < n_q) {
-                const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-                if (has_row && ((kept_ranks >> my_rank[q]) & 1ull)) {
-                    const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << my_rank[q]) - 1ull));
-                    const uint32_t branch = ~(uint32_t)my_key[q];
-                    epik_amd_placement out;
-                    out.branch = branch;
-                    out.score = unord_f32((uint32_t)(my_key[q] >> 32));
-                    out.lwr = my_lwr[q];
-                    p.rows[read * keep + slot] = out;
-                    if (p.kmer_counts)
-                        p.kmer_counts[read * keep + slot] = (touched && branch < N) ? lds.cell[branch].y : 0u;
-                }
-            }
-        }
-        if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
-
-        // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
-        for (uint32_t i = lane; i < N; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+        // ---- correction, sum_scores, top-k, LWR, rows out, reset of the wave's vectors ----------
+        place_epilogue<Layout>(kp, lds, read, n_kmers);
+        EPIK_STAMP(4)  // top-k, LWR, rows out, reset
     }
+#ifdef EPIK_AMD_ABLATION
+    if (p.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg[i], dbg_t[i]);
+#endif
 }
 
 // Algorithmic bytes of SURVEY.md 8(d): one thread per read, plain loops.

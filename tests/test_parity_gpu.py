@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["slotted", "compact"])
+@pytest.fixture(autouse=True, params=["packed", "slotted", "compact"])
 def db_layout(request, monkeypatch):
     """Every parity test runs on both HBM layouts of the database (the slot table with
     inline short lists, and the plain CSR used when that table would not fit)."""

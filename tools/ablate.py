@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
-"""Timing experiments on the placement kernel (developer tool, not product):
-runs the bench workload through variants of the kernel selected by environment
-variables read at placer creation (EPIK_AMD_LDS_ATOMIC, and -- with the
-`make -C epik_amd/csrc ablate` library -- EPIK_AMD_ABLATE)."""
+"""Timing experiments on the placement kernel (developer tool, not product).
+
+Runs the bench workload through several variants IN ONE PROCESS, interleaved over
+rounds (devices differ by several percent: never compare across runs).  A variant is a
+comma-separated list of key=value:
+    lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
+    layout=compact|packed|slotted, atomic=0|1, ablate=<bitmask>, stamps=1   (env read at placer creation)
+Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
+"""
+import ctypes
 import os
 import sys
 import time
@@ -15,10 +21,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     import torch
-    from epik_amd import synth
-    from epik_amd.placer import Placer
+    from epik_amd import alphabet, capi, synth
 
     n = int(os.environ.get("N_READS", 1_000_000))
+    rounds = int(os.environ.get("ROUNDS", 3))
     tree = synth.make_tree(500, seed=42)
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
     data, offs = synth.make_reads(n, 150, seed=44)
@@ -27,26 +33,51 @@ def main():
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
     d_rows = torch.zeros(n * 7 * 2, dtype=torch.float64, device=dev)
     d_nrows = torch.zeros(n, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
-    variants = [v.split(",") for v in sys.argv[1:]] or [["atomic=1", "ablate=0"]]
-    for var in variants:
-        kv = dict(x.split("=") for x in var)
-        os.environ["EPIK_AMD_LDS_ATOMIC"] = kv.get("atomic", "1")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    off32 = np.ascontiguousarray(db.offsets, dtype=np.uint32)
+    cls = alphabet.char_class_table("nucl")
+    variants = [dict(x.split("=") for x in v.split(",")) for v in sys.argv[1:]] or [{}]
+    placers = []
+    for kv in variants:
+        os.environ["EPIK_AMD_LDS_ATOMIC"] = kv.get("atomic", "0")
         os.environ["EPIK_AMD_ABLATE"] = kv.get("ablate", "0")
-        pl = Placer.from_synth(db)
-        for _ in range(2):
-            pl.place_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, d_rows.data_ptr(),
-                            d_nrows.data_ptr(), 0, stream.cuda_stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        steps = 5
+        os.environ["EPIK_AMD_STAMPS"] = kv.get("stamps", "0")
+        os.environ["EPIK_AMD_LAYOUT"] = kv.get("layout", "compact")
+        lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
+        desc = capi.PlacerDesc(
+            abi_version=1, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
+            offset_bits=32, keep_factor=0.01, threshold=float(db.threshold), log_threshold=float(db.log_threshold),
+            num_keys=db.num_keys, num_entries=db.num_entries, offsets=off32.ctypes.data,
+            values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, reserved=0)
+        h = ctypes.c_void_p()
+        lib.epik_amd_placer_create.argtypes = [ctypes.POINTER(capi.PlacerDesc), ctypes.POINTER(ctypes.c_void_p)]
+        rc = lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(h))
+        assert rc == 0, rc
+        lib.epik_amd_placer_place_device.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4
+        lib.epik_amd_placer_destroy.argtypes = [ctypes.c_void_p]
+        placers.append((lib, h))
+
+    def run(lib, h, steps):
         for _ in range(steps):
-            pl.place_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, d_rows.data_ptr(),
-                            d_nrows.data_ptr(), 0, stream.cuda_stream)
+            lib.epik_amd_placer_place_device(h, d_seqs.data_ptr(), d_offs.data_ptr(), n, d_rows.data_ptr(),
+                                             d_nrows.data_ptr(), None, stream)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        print(f"{','.join(var):40s} {ms:8.3f} ms/step  {n / ms / 1e3:8.2f} M reads/s  {pl.launch_info()}", flush=True)
-        pl.close()
+
+    times = [[] for _ in placers]
+    for lib, h in placers:
+        run(lib, h, 2)
+    for _ in range(rounds):
+        for i, (lib, h) in enumerate(placers):
+            t0 = time.perf_counter()
+            run(lib, h, 4)
+            times[i].append((time.perf_counter() - t0) / 4 * 1e3)
+    for kv, t in zip(variants, times):
+        name = ",".join(f"{k}={v}" for k, v in kv.items())
+        print(f"{name:48s} min {min(t):7.3f}  median {sorted(t)[len(t) // 2]:7.3f} ms/step  "
+              f"{n / min(t) / 1e3:7.2f} M reads/s", flush=True)
+    for lib, h in placers:
+        lib.epik_amd_placer_destroy(h)
 
 
 if __name__ == "__main__":
