@@ -52,6 +52,7 @@ struct epik_amd_placer {
     void *d_offsets = nullptr;   // compact layout
     uint2 *d_values = nullptr;
     uint8_t *d_db = nullptr;     // slotted layout: slot table + tail region
+    uint8_t *d_null = nullptr;   // the null posting padding chunks point at
     uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
     epik_amd::PlaceParams params{};  // batch fields are filled per call
@@ -109,6 +110,7 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_offsets);
     (void)hipFree(p->d_values);
     (void)hipFree(p->d_db);
+    (void)hipFree(p->d_null);
     (void)hipFree(p->d_char_class);
     (void)hipFree(p->d_seqs);
     (void)hipFree(p->d_seq_offsets);
@@ -201,26 +203,23 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
 
 
     // ---- choose the HBM layout ---------------------------------------------------------
-    // Slotted (one 128-byte line per k-mer code, short lists inline, 6-byte postings) moves
-    // ~25 % fewer bytes per read but costs num_keys * 128 bytes of table; it is eligible when
-    // that is at most a quarter of the device's free memory.  EPIK_AMD_LAYOUT=compact|slotted
-    // overrides the default.
+    //  packed  (default): an 8-byte {len, tail} entry per k-mer code + every list 128-byte
+    //          aligned with 6-byte postings (8 with 32-bit branch ids): ~17 % fewer bytes
+    //          fetched per read than the CSR, measured the fastest;
+    //  slotted: 128-byte slots with short lists inline (one line per k-mer, lookup included);
+    //  compact: the plain CSR, 4-byte offsets + 8-byte postings, the smallest.
+    // packed / slotted are eligible when their table is at most a quarter of the device's
+    // free memory; EPIK_AMD_LAYOUT=compact|packed|slotted overrides the default.
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
-    uint64_t slot_bytes = 128;
     const char *lay = std::getenv("EPIK_AMD_LAYOUT");
-    // "packed" = the slotted machinery with 8-byte slots {len, tail}: no inline lists, a
-    // table as small as the CSR offsets, every list 128-byte aligned with 6-byte postings
-    if (lay && std::strcmp(lay, "packed") == 0) slot_bytes = 8;
+    const bool want_compact = lay && std::strcmp(lay, "compact") == 0;
+    const bool want_slotted = lay && std::strcmp(lay, "slotted") == 0;
+    const uint64_t slot_bytes = want_slotted ? 128 : 8;
     const bool narrow = d->num_branches <= 65536u;
     const uint32_t posting_bytes = narrow ? 6u : 8u;
     const uint32_t slot_cap = (uint32_t)((slot_bytes - 8u) / posting_bytes);
-    const bool slotted_fits = d->num_keys * slot_bytes <= free_mem / 4;
-    bool slotted = false;  // measured: the compact CSR is the faster of the two today
-    if (lay) {
-        if (std::strcmp(lay, "compact") == 0) slotted = false;
-        else if (std::strcmp(lay, "slotted") == 0 || std::strcmp(lay, "packed") == 0) slotted = slotted_fits;
-    }
+    const bool slotted = !want_compact && d->num_keys * slot_bytes <= free_mem / 4;
     auto offset_at = [&](uint64_t key) -> uint64_t {
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
                             : static_cast<const uint32_t *>(d->offsets)[key];
@@ -322,7 +321,21 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     pp.log_threshold = d->log_threshold;
     pp.log10_keep_factor_margin =
         d->keep_factor > 0.0 ? (float)(std::log10(d->keep_factor) - 1e-3) : -INFINITY;
-    pp.n_pad = (d->num_branches + 63u) & ~63u;
+    // + the dummy cell the null posting adds +0.0 to; a multiple of 4 rows of 64 (the epilogue's sweeps)
+    pp.n_pad = (d->num_branches + 1u + 255u) & ~255u;
+    {
+        const uint32_t dummy_cell = pp.n_pad - 1u;
+        const float zero = 0.0f;
+        uint8_t null_host[16] = {0};
+        std::memcpy(null_host + 0, &dummy_cell, 4);   // compact: {branch, score}
+        std::memcpy(null_host + 4, &zero, 4);
+        std::memcpy(null_host + 8, &zero, 4);         // slotted / packed: score[1] then branch[1]
+        std::memcpy(null_host + 12, &dummy_cell, 4);
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_null), 256));
+        CREATE_TRY(hipMemset(p->d_null, 0, 256));
+        CREATE_TRY(hipMemcpy(p->d_null, null_host, sizeof null_host, hipMemcpyHostToDevice));
+        pp.null_posting = p->d_null;
+    }
     // cells + chunk descriptors of one round + one trip of spare entries (the kernel prefetches a trip ahead)
     pp.lds_wave_bytes = pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
     pp.ablate = 0;

@@ -5,13 +5,12 @@ The ring's posting loads are issued from inline asm (uncounted by hipcc's s_wait
 bookkeeping), so a compiler-generated copy of a ring register made while its load is
 still in flight would capture stale data.  Every ring stage is, in program order,
 
-    asm: s_waitcnt vmcnt(N)        wait for slot i (the oldest load)
-    compiler code                  may copy / use slot i's registers
-    asm: buffer_load_* -> slot i   refill
+    asm: s_waitcnt vmcnt(N) ; slot vA vB   wait for slot i (its registers named in the text)
+    compiler code                          consumes slot i in place
+    asm: global_load_* -> slot i-1         refill of the slot the previous stage consumed
 
-and the kernel moves the slot's values out INSIDE the wait statement, so between the
-first and the last asm load of the loop no compiler-generated instruction may name a
-ring register at all.  Anything that does fails the lint.
+so a compiler-generated instruction may name a ring register only between the wait that
+names it and the next asm load into it.  Anything else fails the lint.
 Usage: lint_ring_asm.py place_kernel.s
 """
 import re
@@ -54,9 +53,9 @@ def lint_loop(name, body, events, problems):
     # From the loop's first asm statement to a margin behind its last asm load (the
     # fall-through into the tail, which still runs before the drain).  Walk it in program
     # order with a per-register state: a slot register is IN FLIGHT from its asm load until
-    # the asm wait that moves it out (`s_waitcnt vmcnt(N)` + `v_mov_b32 x, R`); between that
-    # wait and the refill the register is dead and hipcc may reuse it.  The loop is cyclic,
-    # so at its top every slot counts as in flight.
+    # the asm wait that names it (`s_waitcnt vmcnt(N) ; slot vA vB`); from that wait to the
+    # refill the compiler may read it (the consume) or reuse it.  The loop is cyclic, so at
+    # its top every slot counts as in flight.
     lo, hi = max(0, min(waits[0], loads[0]) - 1), loads[-1] + 15  # -1: the ;;#ASMSTART line
     inflight = set(ring)
     in_asm = False
@@ -82,6 +81,11 @@ def lint_loop(name, body, events, problems):
         for o in operands:
             if o:
                 touched |= regs_of(o.split()[0])
+        # `v_mov vX, <constant>` is how hipcc initialises the empty ring on the path that skips
+        # the loop (laid out behind it): it reads no register, and nothing is in flight there
+        if parts[0].startswith("v_mov_b32") and len(operands) == 2 and not regs_of(operands[1]) \
+                and not operands[1].startswith(("s", "v")):
+            continue
         if touched & inflight:
             problems.append(f"{name}: line {n}: compiler code touches an in-flight ring register: {s}")
 

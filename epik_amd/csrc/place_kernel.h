@@ -34,6 +34,7 @@ struct PlaceParams {
     uint64_t tail_offset;        // byte offset of the tail region = num_keys * slot_bytes
     uint32_t slot_bytes;         // 128
     uint32_t slot_cap;           // postings that fit a slot's payload
+    const uint8_t *null_posting; // 16 bytes: {u32 dummy cell, f32 +0.0} then {f32 +0.0, u16/u32 dummy cell}
     const uint32_t *char_class;  // [256]
     const uint8_t *seqs;
     const uint64_t *seq_offsets; // [n_reads + 1]

@@ -32,7 +32,7 @@ constexpr int kWave = 64;
 constexpr uint32_t kAmbSeen = 0x80000000u;  // counts[] bit: branch already scored by an ambiguous key
 constexpr int kTilesPerPass = EPIK_AMD_TILES_PER_PASS;  // 64-character tiles encoded per pass
 constexpr int kRing = EPIK_AMD_RING;  // posting-chunk loads kept in flight per wave
-static_assert((kRing & (kRing - 1)) == 0 && kRing >= 2 && kRing <= 32, "kRing: power of two, one descriptor lane per stage");
+static_assert((kRing & (kRing - 1)) == 0 && kRing >= 4 && kRing <= 32, "kRing: power of two, one descriptor lane per stage");
 constexpr uint32_t kChunkCap = (uint32_t)kTilesPerPass * 64u;  // chunk descriptors per round (LDS)
 
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
@@ -173,27 +173,26 @@ struct CompactLayout {
     {
         return (uint64_t)(p.values + addr + (uint64_t)c * 64u);
     }
-    __device__ static __forceinline__ uint64_t dummy_address(const PlaceParams &p) { return (uint64_t)p.values; }
     // A chunk descriptor {address (48 bits) | count << 48} is unpacked by every lane at once,
     // once per trip of the ring (vector work), into kFields words; a stage then pulls its
     // chunk's words out with v_readlane: the CU's single scalar unit does no unpacking.
-    static constexpr int kFields = 4;  // address lo, address hi, count, byte offset of the last posting
+    // Every chunk holds at least one posting (padding chunks point at a null posting).
+    static constexpr int kFields = 3;      // address lo, address hi, byte offset of the last posting
+    static constexpr uint32_t kLaneStep = 8;  // bytes per lane in `last`
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
         const uint32_t hi = (uint32_t)(d >> 32);
         f[0] = (uint32_t)d;
         f[1] = hi & 0xffffu;
-        f[2] = hi >> 16;
-        f[3] = (f[2] ? f[2] - 1u : 0u) * 8u;
+        f[2] = ((hi >> 16) - 1u) * 8u;
     }
-    // Puts one chunk's load in flight: lane l reads posting min(l, cnt-1) (lanes past the end
-    // re-read the last posting: same cache lines, no exec masking, and an empty chunk still
-    // performs a real load so that vmcnt bookkeeping is exact).  f[] is wave-uniform.
-    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], int lane, uint32_t &branch,
+    // Puts one chunk's load in flight: lane l reads posting min(l, cnt-1); lanes past the end
+    // re-read the last posting (same cache lines, no exec masking).  f[] is wave-uniform.
+    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane_off, uint32_t &branch,
                                                  uint32_t &score)
     {
         const uint64_t base = ((uint64_t)f[1] << 32) | f[0];
-        const uint32_t off = min((uint32_t)lane * 8u, f[3]);
+        const uint32_t off = min(lane_off, f[2]);
         v2u out;
         // s_nop 4: base comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
         asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2"
@@ -203,6 +202,8 @@ struct CompactLayout {
         branch = out.x;
         score = out.y;
     }
+    // the null posting padding chunks point at: {branch = dummy cell, score = +0.0}
+    __device__ static __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return (uint64_t)p.null_posting | (1ull << 48); }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
                                                          uint32_t j)
     {
@@ -234,29 +235,24 @@ struct SlottedLayout {
     {
         return (uint64_t)(p.db + addr + (uint64_t)c * 64u * kPosting);
     }
-    __device__ static __forceinline__ uint64_t dummy_address(const PlaceParams &p) { return (uint64_t)p.db; }
-    // see CompactLayout: address lo, address hi, count, offset of the last score,
-    // offset of the last branch id, offset of the branch array (= 4 * count)
-    static constexpr int kFields = 6;
+    // see CompactLayout: address lo, address hi, byte offset of the last score
+    static constexpr int kFields = 3;
+    static constexpr uint32_t kLaneStep = 4;
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
         const uint32_t hi = (uint32_t)(d >> 32);
         f[0] = (uint32_t)d;
         f[1] = hi & 0xffffu;
-        f[2] = hi >> 16;
-        const uint32_t last = f[2] ? f[2] - 1u : 0u;
-        f[3] = last * 4u;
-        f[4] = last * (uint32_t)sizeof(BranchT);
-        f[5] = f[2] * 4u;
+        f[2] = ((hi >> 16) - 1u) * 4u;
     }
     // One chunk = f32 score[cnt] then BranchT branch[cnt]: two loads, lane l reads posting
-    // min(l, cnt-1) of each (see CompactLayout::issue).  f[] is wave-uniform.
-    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], int lane, uint32_t &branch,
+    // min(l, cnt-1) of each.  The branch array starts at 4*cnt = last + 4.  f[] is wave-uniform.
+    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane_off, uint32_t &branch,
                                                  uint32_t &score)
     {
         const uint64_t base = ((uint64_t)f[1] << 32) | f[0];
-        const uint32_t off_s = min((uint32_t)lane * 4u, f[3]);
-        const uint32_t off_b = min((uint32_t)lane * (uint32_t)sizeof(BranchT), f[4]) + f[5];
+        const uint32_t off_s = min(lane_off, f[2]);
+        const uint32_t off_b = (sizeof(BranchT) == 2 ? (off_s >> 1) : off_s) + f[2] + 4u;
         if (sizeof(BranchT) == 2) {
             asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_ushort %1, %3, %4"
                          : "=&v"(score), "=&v"(branch)
@@ -269,6 +265,7 @@ struct SlottedLayout {
                          : "memory");
         }
     }
+    __device__ static __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return ((uint64_t)p.null_posting + 8u) | (1ull << 48); }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
                                                          uint32_t j)
     {
@@ -435,33 +432,52 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     // cell[i].x becomes the corrected score (-inf = "not an edge"), cell[i].y the count.
     const float nk_f = (float)n_kmers;
     const uint32_t nk_u = (uint32_t)n_kmers;  // the host rejects reads of 2^32 characters or more
+    const float inv_k = __fdiv_rn(1.0f, k_f);
+    // x / k in three instructions: y = RN(1/k); q = RN(x*y); r = fma(-q, k, x) (exact);
+    // q' = fma(r, y, q).  Bit-identical to the IEEE quotient for every k <= 32 and every
+    // finite x with |x| >= 2^-102 (tools/test_div.hip sweeps all 2^32 floats); a trip that
+    // meets a smaller |x| (or a database with k > 32) is redone with v_div.
+    auto div_k = [&](float x) {
+        const float q = __fmul_rn(x, inv_k);
+        const float r = __fmaf_rn(-q, k_f, x);
+        return __fmaf_rn(r, inv_k, q);
+    };
+    const bool fast_div = p.kmer_size <= 32u;
     uint32_t touched = 0;
-    uint32_t lane_best = 0;  // ord key of this lane's best score; 0 = none
-    // Four rows per lane and trip: the four LDS reads go out together (one latency, not
-    // four); with 4 waves per SIMD there is little else to hide it behind.
+    float lane_best_f = -INFINITY;  // this lane's best score
+    // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 4 * 64: cells
+    // behind N hold no count (the dummy cell of the null posting was cleared by the caller),
+    // so there is no bounds test.  Four rows per lane and trip: the four LDS reads go out
+    // together, and the arithmetic is branch-free.
     constexpr int kUnroll = 4;
-    for (uint32_t base = 0; base < N; base += kUnroll * kWave) {
+    const uint32_t n_rows_pad = p.n_pad;
+    for (uint32_t base = 0; base < n_rows_pad; base += kUnroll * kWave) {
         uint2 cv[kUnroll];
+        float pre[kUnroll], s[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) cv[u] = lds.cell[base + (uint32_t)u * kWave + (uint32_t)lane];
+        float smallest = INFINITY;
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
-            cv[u] = i < N ? lds.cell[i] : make_uint2(0u, 0u);
+            const uint32_t c = cv[u].y & ~kAmbSeen;
+            pre[u] = __fadd_rn(__uint_as_float(cv[u].x), __fmul_rn((float)(nk_u - c), log_thr));  // :420
+            s[u] = div_k(pre[u]);                                                                 // :421
+            smallest = fminf(smallest, c ? fabsf(pre[u]) : INFINITY);
+        }
+        if (!fast_div || __ballot(smallest < 0x1p-100f) != 0) {  // wave-uniform, practically never
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) s[u] = __fdiv_rn(pre[u], k_f);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
             const uint32_t c = cv[u].y & ~kAmbSeen;
-            float s = -INFINITY;
-            if (c != 0) {
-                s = __uint_as_float(cv[u].x);
-                s = __fadd_rn(s, __fmul_rn((float)(nk_u - c), log_thr));  // :420
-                s = __fdiv_rn(s, k_f);                                    // :421
-                ++touched;
-                lane_best = max(lane_best, ord_f32(s));
-            }
-            if (i < N) lds.cell[i] = make_uint2(__float_as_uint(s), c);
+            const float sc = c ? s[u] : -INFINITY;  // -inf = "not an edge"
+            touched += c ? 1u : 0u;
+            lane_best_f = fmaxf(lane_best_f, sc);
+            lds.cell[base + (uint32_t)u * kWave + (uint32_t)lane] = make_uint2(__float_as_uint(sc), c);
         }
     }
+    const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
     touched = wave_sum_u32(touched);
     const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
 
@@ -508,27 +524,23 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const bool relative_sum = ref_score > -280.0f;  // wave-uniform
     if (touched != 0) {
         n_cand = 0;
-        for (uint32_t base = 0; base < N; base += kUnroll * kWave) {
+        const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
+        for (uint32_t base = 0; base < n_rows_pad; base += kUnroll * kWave) {
             uint2 cv[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
-                cv[u] = i < N ? lds.cell[i] : make_uint2(0u, 0u);
-            }
+            for (int u = 0; u < kUnroll; ++u) cv[u] = lds.cell[base + (uint32_t)u * kWave + (uint32_t)lane];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
-                uint32_t key = 0;
-                if (cv[u].y != 0) {  // rows past N were read as {0, 0}
-                    const float sc = __uint_as_float(cv[u].x);
-                    key = ord_f32(sc);
-                    rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
-                }
-                const bool is_cand = key >= tau;  // tau >= 1, key 0 = not an edge
+                const float sc = __uint_as_float(cv[u].x);  // -inf where there is no edge
+                const bool edge = cv[u].y != 0;
+                // exp2(-inf) = 0: rows without an edge add nothing
+                rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
+                const bool is_cand = edge && sc >= tau_f;
                 const uint64_t m = __ballot(is_cand);
                 if (m) {
                     const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (is_cand && slot < kCandCap) cand[slot] = make_uint2(key, i);
+                    if (is_cand && slot < kCandCap) cand[slot] = make_uint2(ord_f32(sc), i);
                     n_cand += (uint32_t)__popcll(m);
                 }
             }
@@ -556,7 +568,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             ranked_in_place = true;
         }
     }
-    double score_sum;
+    double score_sum, ref_power = 0.0;
     {
         const float not_placed = (float)N - (float)touched;  // :174
         if (relative_sum) {
@@ -564,7 +576,8 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             if (not_placed != 0.0f)
                 rel += (double)(not_placed *
                                 __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
-            score_sum = pow10_f64((double)ref_score) * rel;
+            ref_power = pow10_f64((double)ref_score);
+            score_sum = ref_power * rel;
         } else {
             // everything in double, term by term, as place.cpp:174-183
             double sum_placed = 0.0;
@@ -579,7 +592,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
 
     // ---- rank, LWR (:241-264), filter_by_ratio (:188-199); <= 3 candidates per lane ------
-    const double best_power = pow10_f64((double)best_score);
+    const double best_power = (relative_sum && ref_score == best_score) ? ref_power : pow10_f64((double)best_score);
     const double best_ratio =
         (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
     const double ratio_threshold = best_ratio * keep_factor;                      // :192
@@ -650,7 +663,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
 
     // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
-    for (uint32_t i = lane; i < N; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+    for (uint32_t i = lane; i < n_rows_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
 }
 
 template <typename Layout, bool kLdsAtomic>
@@ -669,7 +682,6 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
     }
     // the argument block itself, for the out-of-line parts (no private copy of `p`)
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t N = p.num_branches;
     for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
 
     const uint32_t k = p.kmer_size;
@@ -737,48 +749,76 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
             // instructions per chunk (the scalar unit is shared by the whole CU and was the
             // bottleneck of a scalar list-walking generator).
             uint32_t nch[kTilesPerPass], first[kTilesPerPass];
-            uint32_t total = 0, most = 0;
+            uint32_t total = 0;
 #pragma unroll
             for (int t = 0; t < kTilesPerPass; ++t) {
                 nch[t] = (llen[t] + (uint32_t)kWave - 1u) >> 6;
                 const uint32_t incl = wave_incl_scan_u32(nch[t]);
                 first[t] = total + incl - nch[t];
                 total += __builtin_amdgcn_readlane(incl, 63);
-                most = max(most, nch[t]);
             }
-            most = wave_max_u32(most);
 #ifdef EPIK_AMD_ABLATION
             if (p.ablate & 8u) total = 0;   // lookups done, nothing streamed
-            if (p.ablate & 16u) most = 0;   // (with 8) skip the chunk expansion too
 #endif
             uint64_t *chunks = lds.desc;
             EPIK_STAMP(1)  // lookups landed, scan done
             for (uint32_t w0 = 0; w0 < total; w0 += kChunkCap) {  // one round unless > kChunkCap chunks
                 const uint32_t n_round = min(total - w0, kChunkCap);
                 const uint32_t n_padded = (n_round + (uint32_t)kRing - 1u) & ~((uint32_t)kRing - 1u);
-                for (uint32_t c = 0; c < most; ++c) {
+                // Every lane writes the first chunk of its own lists; the further chunks of a
+                // long list (> 64 postings, about a fifth of the lists) are written by the whole
+                // wave at once, lane j writing chunk j, one list at a time.
 #pragma unroll
-                    for (int t = 0; t < kTilesPerPass; ++t) {
-                        const uint32_t idx = first[t] + c - w0;  // wraps when in front of the window
-                        if (c < nch[t] && idx < kChunkCap) {
-                            const uint32_t rest = llen[t] - (c << 6);
+                for (int t = 0; t < kTilesPerPass; ++t) {
+                    const uint32_t idx = first[t] - w0;  // wraps when in front of the window
+                    if (nch[t] != 0 && idx < kChunkCap) {
+                        const uint64_t cnt = llen[t] < (uint32_t)kWave ? llen[t] : (uint32_t)kWave;
+                        chunks[idx] = Layout::chunk_address(p, start[t], 0) | (cnt << 48);
+                    }
+                    uint64_t long_lists = __ballot(nch[t] > 1u);
+                    while (long_lists) {
+                        const int m = __builtin_ctzll(long_lists);
+                        long_lists &= long_lists - 1;
+                        const uint32_t l_first = __builtin_amdgcn_readlane(first[t], m);
+                        const uint32_t l_len = __builtin_amdgcn_readlane(llen[t], m);
+                        const uint64_t l_start = readlane_u64(start[t], m);
+                        const uint32_t c = (uint32_t)lane;  // chunk index inside the list
+                        const uint32_t idx2 = l_first + c - w0;
+                        if (c >= 1u && (c << 6) < l_len && idx2 < kChunkCap) {
+                            const uint32_t rest = l_len - (c << 6);
                             const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                            chunks[idx] = Layout::chunk_address(p, start[t], c) | (cnt << 48);
+                            chunks[idx2] = Layout::chunk_address(p, l_start, c) | (cnt << 48);
+                        }
+                        // lists of more than 64 chunks (> 4096 postings): the lanes take further turns
+                        for (uint32_t c2 = c + (uint32_t)kWave; (c2 << 6) < l_len; c2 += kWave) {
+                            const uint32_t idx3 = l_first + c2 - w0;
+                            if (idx3 < kChunkCap) {
+                                const uint32_t rest = l_len - (c2 << 6);
+                                const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                                chunks[idx3] = Layout::chunk_address(p, l_start, c2) | (cnt << 48);
+                            }
                         }
                     }
                 }
-                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = Layout::dummy_address(p);
+                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = Layout::null_chunk(p);
 
                 // (3) stream the chunks through a ring of kRing in-flight loads.  The loads are
                 // issued from inline asm (Layout::issue): hipcc must not count them, or it would
                 // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
                 // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that point
-                // and loads retire in issue order --, takes the posting out, and refills the slot
-                // with the next chunk.  The first trip finds the slots empty (count 0).
-                uint32_t ring_b[kRing], ring_s[kRing], ring_cnt[kRing];
+                // and loads retire in issue order --, moves the posting out of the slot registers
+                // inside that same asm statement, and refills the slot with the next chunk.
+                // (Letting hipcc read the slot registers itself, even behind a "+v" wait, is not
+                // safe: it is free to copy them into other registers AHEAD of the wait.)
+                uint32_t ring_b[kRing], ring_s[kRing];
+                int32_t ring_last[kRing];  // byte offset of the slot's last posting, -1 step = empty slot
 #pragma unroll
-                for (int i = 0; i < kRing; ++i) ring_b[i] = ring_s[i] = ring_cnt[i] = 0;
-                auto consume = [&](uint32_t br, uint32_t sc_bits, uint32_t cnt, auto &&between) {
+                for (int i = 0; i < kRing; ++i) {
+                    ring_b[i] = ring_s[i] = 0;
+                    ring_last[i] = -(int32_t)Layout::kLaneStep;
+                }
+                const uint32_t lane_off = (uint32_t)lane * Layout::kLaneStep;
+                auto consume = [&](uint32_t br, uint32_t sc_bits, int32_t last, auto &&between) {
                     // Every lane reads its cell (lanes past the chunk's end hold a copy of the
                     // last posting: a valid address, a broadcast read); `between` (the refill)
                     // overlaps the LDS latency; the add and the write-back come last and only
@@ -794,8 +834,8 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
                     uint2 cv = make_uint2(0u, 0u);
                     if (!kLdsAtomic && !skip_acc) cv = *cell;  // ds_read_b64, all lanes
                     between();
-                    asm volatile("" : "+v"(cv.x), "+v"(cv.y));  // keep the adds below the refill
-                    if (!skip_acc && (uint32_t)lane < cnt) {
+                    __builtin_amdgcn_sched_barrier(0);  // keep the adds (and their LDS wait) below the refill
+                    if (!skip_acc && (int32_t)lane_off <= last) {
                         if (kLdsAtomic) {
                             accumulate_chunk<true>(lds, make_uint2(br, sc_bits), true);
                         } else {
@@ -812,21 +852,17 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
                     d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
 #pragma unroll
                     for (int i = 0; i < kRing; ++i) {
-                        // Wait for slot i and move its posting out of the slot registers INSIDE
-                        // the asm statement, behind the wait: a copy made by hipcc could be
-                        // scheduled ahead of the wait and capture the registers too early.
                         uint32_t br, sc_bits;
                         asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
                                      : "=&v"(br), "=&v"(sc_bits)
                                      : "v"(ring_b[i]), "v"(ring_s[i]), "i"(Layout::kLoads * (kRing - 1))
                                      : "memory");
-                        const uint32_t cnt = ring_cnt[i];
-                        consume(br, sc_bits, cnt, [&]() {
+                        consume(br, sc_bits, ring_last[i], [&]() {
                             uint32_t f[Layout::kFields];
 #pragma unroll
                             for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
-                            ring_cnt[i] = f[2];
-                            Layout::issue(f, lane, ring_b[i], ring_s[i]);
+                            ring_last[i] = (int32_t)f[2];
+                            Layout::issue(f, lane_off, ring_b[i], ring_s[i]);
                         });
                     }
                 }
@@ -847,7 +883,7 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
                                          : "memory");
                     }
 #pragma unroll
-                    for (int i = 0; i < kRing; ++i) consume(br[i], sc_bits[i], ring_cnt[i], []() {});
+                    for (int i = 0; i < kRing; ++i) consume(br[i], sc_bits[i], ring_last[i], []() {});
                 }
             }
         }
@@ -860,11 +896,12 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
         if (p.ablate & 2u) {  // skip the whole epilogue
             if (lane == 0) p.n_rows[read] = 0;
             if (!(p.ablate & 4u))
-                for (uint32_t i = lane; i < N; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+                for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
             continue;
         }
 #endif
         // ---- correction, sum_scores, top-k, LWR, rows out, reset of the wave's vectors ----------
+        if (lane == 0) lds.cell[p.n_pad - 1u] = make_uint2(0u, 0u);  // the null posting's dummy cell
         place_epilogue<Layout>(kp, lds, read, n_kmers);
         EPIK_STAMP(4)  // top-k, LWR, rows out, reset
     }
