@@ -33,6 +33,7 @@ EXPORTS = (
     "epik_amd_placer_place",
     "epik_amd_placer_place_device",
     "epik_amd_placer_algorithmic_bytes",
+    "epik_amd_placer_set_wide_counts",
     "epik_amd_placer_launch_info",
     "epik_amd_placer_set_timing",
     "epik_amd_placer_last_kernel_ms",
@@ -100,6 +101,8 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_placer_launch_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32),
                                                 ctypes.POINTER(ctypes.c_uint32),
                                                 ctypes.POINTER(ctypes.c_uint32)]
+    lib.epik_amd_placer_set_wide_counts.restype = i32
+    lib.epik_amd_placer_set_wide_counts.argtypes = [vp, i32]
     lib.epik_amd_placer_set_timing.restype = i32
     lib.epik_amd_placer_set_timing.argtypes = [vp, i32]
     lib.epik_amd_placer_last_kernel_ms.restype = i32

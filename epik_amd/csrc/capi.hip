@@ -7,6 +7,7 @@
 // point fails with EPIK_AMD_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,7 +48,7 @@ struct epik_amd_placer {
     int device = 0;
     bool offsets64 = false;
     epik_amd::DbLayout layout = epik_amd::DbLayout::kCompact32;
-    bool lds_atomic = false;
+    bool wide_counts = false;  // 32-bit per-branch counts (reads of 32768 k-mers or more)
     bool timing = false;
     void *d_offsets = nullptr;   // compact layout
     uint2 *d_values = nullptr;
@@ -58,11 +59,15 @@ struct epik_amd_placer {
     epik_amd::PlaceParams params{};  // batch fields are filled per call
     uint64_t num_keys = 0;
     uint64_t num_entries = 0;
-    // launch geometry
-    uint32_t waves_per_block = 4;
-    uint32_t lds_block_bytes = 0;
-    uint32_t max_blocks = 0;
+    // launch geometry, [0] = 16-bit counts (default), [1] = 32-bit counts
+    struct geometry {
+        uint32_t waves_per_block = 4;
+        uint32_t lds_wave_bytes = 0;
+        uint32_t lds_block_bytes = 0;
+        uint32_t max_blocks = 0;
+    } geo[2];
     uint32_t last_blocks = 0;
+    uint32_t last_geo = 0;
     // staging buffers for the host-pointer entry point (grown on demand)
     uint8_t *d_seqs = nullptr;
     size_t d_seqs_cap = 0;
@@ -190,8 +195,6 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     p->offsets64 = d->offset_bits == 64;
     p->num_keys = d->num_keys;
     p->num_entries = d->num_entries;
-    const char *env = std::getenv("EPIK_AMD_LDS_ATOMIC");
-    p->lds_atomic = env && env[0] == '1';  // default: 64-bit LDS read-add-write (faster than ds_add_f32)
 
     // every posting's branch must index the LDS score vector
     for (uint64_t i = 0; i < d->num_entries; ++i) {
@@ -336,37 +339,31 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
         CREATE_TRY(hipMemcpy(p->d_null, null_host, sizeof null_host, hipMemcpyHostToDevice));
         pp.null_posting = p->d_null;
     }
-    // cells + chunk descriptors of one round + one trip of spare entries (the kernel prefetches a trip ahead)
-    pp.lds_wave_bytes = pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
-    pp.ablate = 0;
-    pp.dbg = nullptr;
-#ifdef EPIK_AMD_ABLATION
-    if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
-    if (const char *st = std::getenv("EPIK_AMD_STAMPS"); st && st[0] == '1') {
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), 8 * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemset(pp.dbg, 0, 8 * sizeof(unsigned long long)));
-    }
-#endif
-
-    // geometry: as many waves per workgroup (<= 4) as fit the 160 KiB of LDS
-    if (pp.lds_wave_bytes > kMaxLdsPerBlock) {
-        epik_amd_placer_destroy(p);
-        return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector (max 20480)");
-    }
-    p->waves_per_block = 4;
-    while (p->waves_per_block > 1 && p->waves_per_block * pp.lds_wave_bytes > kMaxLdsPerBlock / 2)
-        p->waves_per_block >>= 1;
-    p->lds_block_bytes = p->waves_per_block * pp.lds_wave_bytes;
-    CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, p->lds_atomic, p->lds_block_bytes));
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, d->device));
-    // persistent-style grid: exactly the workgroups that are resident at once
-    // (registers, LDS and the 32-waves/CU cap decide), each striding over the reads
-    int per_cu = 0;
-    CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, p->lds_atomic, (int)(p->waves_per_block * 64u),
-                                               p->lds_block_bytes, &per_cu));
-    if (per_cu < 1) per_cu = 1;
-    p->max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    for (int wide = 0; wide < 2; ++wide) {
+        auto &g = p->geo[wide];
+        // per wave: float32 scores + 16/32-bit counts + the chunk descriptors of one round
+        // + one trip of spare entries (the kernel prefetches a trip ahead)
+        g.lds_wave_bytes = pp.n_pad * (wide ? 8u : 6u) + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
+        if (g.lds_wave_bytes > kMaxLdsPerBlock) {
+            epik_amd_placer_destroy(p);
+            return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
+        }
+        // as many waves per workgroup (<= 4) as fit half of the 160 KiB of LDS
+        g.waves_per_block = 4;
+        while (g.waves_per_block > 1 && g.waves_per_block * g.lds_wave_bytes > kMaxLdsPerBlock / 2) g.waves_per_block >>= 1;
+        g.lds_block_bytes = g.waves_per_block * g.lds_wave_bytes;
+        CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, wide != 0, g.lds_block_bytes));
+        // persistent-style grid: exactly the workgroups that are resident at once
+        // (registers, LDS and the 32-waves/CU cap decide), each striding over the reads
+        int per_cu = 0;
+        CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, wide != 0, (int)(g.waves_per_block * 64u),
+                                                   g.lds_block_bytes, &per_cu));
+        if (per_cu < 1) per_cu = 1;
+        g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    }
+    if (const char *w = std::getenv("EPIK_AMD_WIDE_COUNTS")) p->wide_counts = w[0] == '1';
 #undef CREATE_TRY
 
     *out = p;
@@ -384,12 +381,15 @@ static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offs
     pp.rows = static_cast<epik_amd_placement *>(d_rows);
     pp.n_rows = static_cast<uint32_t *>(d_n_rows);
     pp.kmer_counts = static_cast<uint32_t *>(d_counts);
-    uint64_t blocks = (n + p->waves_per_block - 1) / p->waves_per_block;
-    if (blocks > p->max_blocks) blocks = p->max_blocks;
+    const auto &g = p->geo[p->wide_counts ? 1 : 0];
+    pp.lds_wave_bytes = g.lds_wave_bytes;
+    uint64_t blocks = (n + g.waves_per_block - 1) / g.waves_per_block;
+    if (blocks > g.max_blocks) blocks = g.max_blocks;
     p->last_blocks = (uint32_t)blocks;
+    p->last_geo = p->wide_counts ? 1 : 0;
     if (p->timing) HIP_TRY(hipEventRecord(p->ev_start, stream));
-    HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->lds_atomic, dim3((unsigned)blocks),
-                                         dim3(p->waves_per_block * 64u), p->lds_block_bytes, stream));
+    HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->wide_counts, dim3((unsigned)blocks),
+                                         dim3(g.waves_per_block * 64u), g.lds_block_bytes, stream));
     if (p->timing) {
         HIP_TRY(hipEventRecord(p->ev_stop, stream));
         p->ev_recorded = true;
@@ -421,6 +421,16 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
         if (seq_offsets[i + 1] < seq_offsets[i] || seq_offsets[i + 1] - seq_offsets[i] > 0xffffffffull)
             return fail(EPIK_AMD_ERR_INVALID, "seq_offsets not monotone, or a read of 2^32 characters or more");
     HIP_TRY(hipSetDevice(p->device));
+    // 16-bit per-branch counts unless a read has 32768 k-mers or more
+    uint64_t longest = 0;
+    for (uint64_t i = 0; i < n; ++i) longest = std::max<uint64_t>(longest, seq_offsets[i + 1] - seq_offsets[i]);
+    const bool saved_wide = p->wide_counts;
+    if (longest >= p->params.kmer_size && longest - p->params.kmer_size + 1 >= 32768u) p->wide_counts = true;
+    struct restore_wide {
+        epik_amd_placer *p;
+        bool v;
+        ~restore_wide() { p->wide_counts = v; }
+    } restore{p, saved_wide};
     const size_t seq_bytes = (size_t)seq_offsets[n];
     if (seq_bytes + 64 > p->d_seqs_cap) {
         (void)hipFree(p->d_seqs);
@@ -492,9 +502,17 @@ int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_bl
                                 uint32_t *blocks, uint32_t *lds_bytes)
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
-    if (waves_per_block) *waves_per_block = p->waves_per_block;
-    if (blocks) *blocks = p->last_blocks ? p->last_blocks : p->max_blocks;
-    if (lds_bytes) *lds_bytes = p->lds_block_bytes;
+    const auto &g = p->geo[p->last_geo];
+    if (waves_per_block) *waves_per_block = g.waves_per_block;
+    if (blocks) *blocks = p->last_blocks ? p->last_blocks : g.max_blocks;
+    if (lds_bytes) *lds_bytes = g.lds_block_bytes;
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    p->wide_counts = enabled != 0;
     return EPIK_AMD_OK;
 }
 

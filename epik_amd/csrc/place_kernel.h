@@ -51,15 +51,15 @@ struct PlaceParams {
     float log_threshold;
     float log10_keep_factor_margin;  // log10(keep_factor) - 1e-3: early exit of the top-k rounds
     uint32_t n_pad;                  // num_branches rounded up to 64
-    uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + pass descriptors)
+    uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + chunk descriptors)
     uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
     unsigned long long *dbg;         // phase cycle sums (-DEPIK_AMD_ABLATION builds, EPIK_AMD_STAMPS=1)
 };
 
-hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool lds_atomic, dim3 grid, dim3 block,
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool wide_counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream);
-hipError_t set_place_reads_lds_limit(DbLayout layout, bool lds_atomic, size_t lds_bytes);
-hipError_t place_reads_occupancy(DbLayout layout, bool lds_atomic, int block_threads, size_t lds_bytes,
+hipError_t set_place_reads_lds_limit(DbLayout layout, bool wide_counts, size_t lds_bytes);
+hipError_t place_reads_occupancy(DbLayout layout, bool wide_counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu);
 hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
                                     hipStream_t stream);

@@ -29,7 +29,6 @@ namespace epik_amd {
 namespace {
 
 constexpr int kWave = 64;
-constexpr uint32_t kAmbSeen = 0x80000000u;  // counts[] bit: branch already scored by an ambiguous key
 constexpr int kTilesPerPass = EPIK_AMD_TILES_PER_PASS;  // 64-character tiles encoded per pass
 constexpr int kRing = EPIK_AMD_RING;  // posting-chunk loads kept in flight per wave
 static_assert((kRing & (kRing - 1)) == 0 && kRing >= 4 && kRing <= 32, "kRing: power of two, one descriptor lane per stage");
@@ -316,38 +315,28 @@ __device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uin
     return t;
 }
 
-// Wave-private LDS.  cell[b] = {float bits of _scores[thread][b], _counts[thread][b]}
-// (place.h:126-131) side by side, so one 8-byte LDS access serves both; bit 31 of the
-// count is kAmbSeen.  `desc` holds the found posting lists of the current pass in read
-// order and is reused by the epilogue for its top-k candidates.
+// Wave-private LDS: score[b] = _scores[thread][b] (float32), count[b] = _counts[thread][b]
+// (place.h:126-131) in two arrays -- counts are 16-bit by default (reads of up to 32767
+// k-mers; 6 bytes per branch let 20 waves share a CU's 160 KiB), 32-bit in the "wide"
+// kernels the host selects for longer reads.  The top bit of a count is the
+// "already scored by an ambiguous key" flag.  `desc` holds the chunk descriptors of the
+// current round and is reused by the epilogue for its top-k candidates.
+template <typename CountT>
 struct WaveLds {
-    uint2 *cell;     // [n_pad]
-    uint64_t *desc;  // [kTilesPerPass * 64]
-};
-
-// One chunk of one posting list: lanes [0, cnt) each take one posting and add it
-// to the wave's score/count vectors (place.cpp:358-367).
-template <bool kLdsAtomic>
-__device__ __forceinline__ void accumulate_chunk(const WaveLds &lds, uint2 e, bool active)
-{
-    if (active) {
-        uint2 *c = &lds.cell[e.x];
-        const float sc = __uint_as_float(e.y);
-        if (kLdsAtomic) {
-            // ds_add_f32 / ds_add_u32, no return (bit-exact too, but ~2x slower on gfx950)
-            __hip_atomic_fetch_add(reinterpret_cast<float *>(&c->x), sc, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(&c->y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        } else {
-            uint2 v = *c;                                                      // ds_read_b64
-            v.x = __float_as_uint(__fadd_rn(__uint_as_float(v.x), sc));        // :366
-            v.y += 1u;                                                         // :365
-            *c = v;                                                            // ds_write_b64
-        }
+    static constexpr uint32_t kSeen = 1u << (8 * sizeof(CountT) - 1);
+    float *score;    // [n_pad]
+    CountT *count;   // [n_pad]
+    uint64_t *desc;  // [kTilesPerPass * 64 + kRing]
+    __device__ __forceinline__ uint2 load(uint32_t i) const
+    {
+        return make_uint2(__float_as_uint(score[i]), (uint32_t)count[i]);
     }
-}
-
-}  // namespace
+    __device__ __forceinline__ void store(uint32_t i, uint32_t score_bits, uint32_t c) const
+    {
+        score[i] = __uint_as_float(score_bits);
+        count[i] = (CountT)c;
+    }
+};
 
 // ---------------------------------------------------------------------------------
 // The two parts of a read's placement that need many registers -- the cold ambiguous-k-mer
@@ -356,8 +345,8 @@ __device__ __forceinline__ void accumulate_chunk(const WaveLds &lds, uint2 e, bo
 // kernel (~125 VGPRs) although the streaming loop itself needs ~70.  `kp` points at the
 // kernel's own argument block.
 // ---------------------------------------------------------------------------------
-template <typename Layout>
-__device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__restrict__ kp, WaveLds lds,
+template <typename Layout, typename CountT>
+__device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
                                                           const uint8_t *__restrict__ seq, uint64_t len,
                                                           uint64_t n_kmers)
 {
@@ -397,18 +386,18 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
                     for (uint32_t off = 0; off < n; off += kWave) {
                         if (off + (uint32_t)lane < n) {
                             const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);
-                            uint2 cv = lds.cell[e.x];
+                            uint2 cv = lds.load(e.x);
                             const uint32_t c = cv.y;
                             // Only the first ambiguous key that reaches a branch scores it:
                             // later ones find counts_amb[b] != 0 and stay out of l_amb (:385-388).
-                            if (!(c & kAmbSeen)) {
+                            if (!(c & lds.kSeen)) {
                                 // counts_amb[b] == 1, scores_amb[b] == float(pow(10, score)) (:390-391)
                                 const float prob = (float)pow(10.0, (double)__uint_as_float(e.y));
                                 const float avg = __fdiv_rn(
                                     __fadd_rn(prob, __fmul_rn((float)(k - 1u), thr)), k_f);  // :400-402
-                                cv.y = (c | kAmbSeen) + 1u;                                    // :409
+                                cv.y = (c | lds.kSeen) + 1u;                                   // :409
                                 cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), avg)); // :410
-                                lds.cell[e.x] = cv;
+                                lds.store(e.x, cv.x, cv.y);
                             }
                         }
                     }
@@ -419,8 +408,8 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
 
 }
 
-template <typename Layout>
-__device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds lds,
+template <typename Layout, typename CountT>
+__device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
                                                          uint64_t read, uint64_t n_kmers)
 {
     const PlaceParams &p = *kp;
@@ -455,11 +444,11 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         uint2 cv[kUnroll];
         float pre[kUnroll], s[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) cv[u] = lds.cell[base + (uint32_t)u * kWave + (uint32_t)lane];
+        for (int u = 0; u < kUnroll; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
         float smallest = INFINITY;
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const uint32_t c = cv[u].y & ~kAmbSeen;
+            const uint32_t c = cv[u].y & ~lds.kSeen;
             pre[u] = __fadd_rn(__uint_as_float(cv[u].x), __fmul_rn((float)(nk_u - c), log_thr));  // :420
             s[u] = div_k(pre[u]);                                                                 // :421
             smallest = fminf(smallest, c ? fabsf(pre[u]) : INFINITY);
@@ -470,11 +459,11 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const uint32_t c = cv[u].y & ~kAmbSeen;
+            const uint32_t c = cv[u].y & ~lds.kSeen;
             const float sc = c ? s[u] : -INFINITY;  // -inf = "not an edge"
             touched += c ? 1u : 0u;
             lane_best_f = fmaxf(lane_best_f, sc);
-            lds.cell[base + (uint32_t)u * kWave + (uint32_t)lane] = make_uint2(__float_as_uint(sc), c);
+            lds.store(base + (uint32_t)u * kWave + (uint32_t)lane, __float_as_uint(sc), c);
         }
     }
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
@@ -528,7 +517,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         for (uint32_t base = 0; base < n_rows_pad; base += kUnroll * kWave) {
             uint2 cv[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) cv[u] = lds.cell[base + (uint32_t)u * kWave + (uint32_t)lane];
+            for (int u = 0; u < kUnroll; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
@@ -552,7 +541,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             for (uint32_t r = 0; r < n_sel; ++r) {
                 uint64_t best = 0;
                 for (uint32_t i = lane; i < N; i += kWave) {
-                    const uint2 cv = lds.cell[i];
+                    const uint2 cv = lds.load(i);
                     const uint64_t key = ((uint64_t)ord_f32(__uint_as_float(cv.x)) << 32) | (uint64_t)(~i);
                     if (cv.y != 0 && key < prev && key > best) best = key;
                 }
@@ -582,7 +571,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             // everything in double, term by term, as place.cpp:174-183
             double sum_placed = 0.0;
             for (uint32_t i = lane; i < N; i += kWave) {
-                const uint2 cv = lds.cell[i];
+                const uint2 cv = lds.load(i);
                 if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
             }
             sum_placed = wave_sum_f64(sum_placed);
@@ -656,33 +645,36 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
                 out.lwr = my_lwr[q];
                 p.rows[read * keep + slot] = out;
                 if (p.kmer_counts)
-                    p.kmer_counts[read * keep + slot] = (touched && branch < N) ? lds.cell[branch].y : 0u;
+                    p.kmer_counts[read * keep + slot] = (touched && branch < N) ? (uint32_t)lds.count[branch] : 0u;
             }
         }
     }
     if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
 
     // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
-    for (uint32_t i = lane; i < n_rows_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+    for (uint32_t i = lane; i < n_rows_pad; i += kWave) lds.store(i, 0u, 0u);
 }
 
-template <typename Layout, bool kLdsAtomic>
-__global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
+}  // namespace
+
+template <typename Layout, typename CountT>
+__global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = lane_id();
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t waves_per_block = blockDim.x >> 6;
 
-    WaveLds lds;
+    WaveLds<CountT> lds;
     {
         unsigned char *base = lds_raw + (size_t)wave_in_block * p.lds_wave_bytes;
-        lds.cell = reinterpret_cast<uint2 *>(base);
-        lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * 8);
+        lds.score = reinterpret_cast<float *>(base);
+        lds.count = reinterpret_cast<CountT *>(base + (size_t)p.n_pad * 4);
+        lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * (4 + sizeof(CountT)));  // n_pad % 256 == 0
     }
     // the argument block itself, for the out-of-line parts (no private copy of `p`)
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+    for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.store(i, 0u, 0u);
 
     const uint32_t k = p.kmer_size;
     const uint32_t sigma = p.alphabet_size;
@@ -706,7 +698,9 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
         const uint64_t seq_begin = p.seq_offsets[read];
         const uint64_t len = p.seq_offsets[read + 1] - seq_begin;
         const uint8_t *__restrict__ seq = p.seqs + seq_begin;
-        if (len < k || len > 0xffffffffull) {  // place.cpp:322 underflows for len < k; we report "no placement"
+        // place.cpp:322 underflows for len < k; we report "no placement" -- also for a read whose
+        // k-mers could overflow this kernel's count type (the host then uses the wide kernel)
+        if (len < k || len - k + 1 >= (uint64_t)WaveLds<CountT>::kSeen) {
             if (lane == 0) p.n_rows[read] = 0;
             continue;
         }
@@ -830,19 +824,19 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
 #else
                     constexpr bool skip_acc = false;
 #endif
-                    uint2 *cell = &lds.cell[br];
-                    uint2 cv = make_uint2(0u, 0u);
-                    if (!kLdsAtomic && !skip_acc) cv = *cell;  // ds_read_b64, all lanes
+                    float *score_cell = &lds.score[br];
+                    CountT *count_cell = &lds.count[br];
+                    float old_score = 0.0f;
+                    uint32_t old_count = 0;
+                    if (!skip_acc) {  // both LDS reads go out for all lanes
+                        old_score = *score_cell;
+                        old_count = (uint32_t)*count_cell;
+                    }
                     between();
                     __builtin_amdgcn_sched_barrier(0);  // keep the adds (and their LDS wait) below the refill
                     if (!skip_acc && (int32_t)lane_off <= last) {
-                        if (kLdsAtomic) {
-                            accumulate_chunk<true>(lds, make_uint2(br, sc_bits), true);
-                        } else {
-                            cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), sc));  // :366
-                            cv.y += 1u;                                                    // :365
-                            *cell = cv;                                                    // ds_write_b64
-                        }
+                        *score_cell = __fadd_rn(old_score, sc);       // :366
+                        *count_cell = (CountT)(old_count + 1u);       // :365
                     }
                 };
                 uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
@@ -890,19 +884,19 @@ __global__ __launch_bounds__(256, 4) void place_reads_kernel(PlaceParams p)
 
         EPIK_STAMP(2)  // expansion + stream
         // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
-        if (any_amb) place_ambiguous<Layout>(kp, lds, seq, len, n_kmers);
+        if (any_amb) place_ambiguous<Layout, CountT>(kp, lds, seq, len, n_kmers);
 
 #ifdef EPIK_AMD_ABLATION
         if (p.ablate & 2u) {  // skip the whole epilogue
             if (lane == 0) p.n_rows[read] = 0;
             if (!(p.ablate & 4u))
-                for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.cell[i] = make_uint2(0u, 0u);
+                for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.store(i, 0u, 0u);
             continue;
         }
 #endif
         // ---- correction, sum_scores, top-k, LWR, rows out, reset of the wave's vectors ----------
-        if (lane == 0) lds.cell[p.n_pad - 1u] = make_uint2(0u, 0u);  // the null posting's dummy cell
-        place_epilogue<Layout>(kp, lds, read, n_kmers);
+        if (lane == 0) lds.store(p.n_pad - 1u, 0u, 0u);  // the null posting's dummy cell
+        place_epilogue<Layout, CountT>(kp, lds, read, n_kmers);
         EPIK_STAMP(4)  // top-k, LWR, rows out, reset
     }
 #ifdef EPIK_AMD_ABLATION
@@ -976,51 +970,51 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
 
 namespace {
 
-// Calls f.template operator()<Layout, kLdsAtomic>() for the runtime variant.
+// Calls f.template operator()<Layout, CountT>() for the runtime variant.
 template <typename F>
-hipError_t dispatch(DbLayout layout, bool lds_atomic, F &&f)
+hipError_t dispatch(DbLayout layout, bool wide_counts, F &&f)
 {
     switch (layout) {
         case DbLayout::kCompact32:
-            return lds_atomic ? f.template operator()<CompactLayout<uint32_t>, true>()
-                              : f.template operator()<CompactLayout<uint32_t>, false>();
+            return wide_counts ? f.template operator()<CompactLayout<uint32_t>, uint32_t>()
+                               : f.template operator()<CompactLayout<uint32_t>, uint16_t>();
         case DbLayout::kCompact64:
-            return lds_atomic ? f.template operator()<CompactLayout<uint64_t>, true>()
-                              : f.template operator()<CompactLayout<uint64_t>, false>();
+            return wide_counts ? f.template operator()<CompactLayout<uint64_t>, uint32_t>()
+                               : f.template operator()<CompactLayout<uint64_t>, uint16_t>();
         case DbLayout::kSlotted16:
-            return lds_atomic ? f.template operator()<SlottedLayout<uint16_t>, true>()
-                              : f.template operator()<SlottedLayout<uint16_t>, false>();
+            return wide_counts ? f.template operator()<SlottedLayout<uint16_t>, uint32_t>()
+                               : f.template operator()<SlottedLayout<uint16_t>, uint16_t>();
         case DbLayout::kSlotted32:
-            return lds_atomic ? f.template operator()<SlottedLayout<uint32_t>, true>()
-                              : f.template operator()<SlottedLayout<uint32_t>, false>();
+            return wide_counts ? f.template operator()<SlottedLayout<uint32_t>, uint32_t>()
+                               : f.template operator()<SlottedLayout<uint32_t>, uint16_t>();
     }
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool lds_atomic, dim3 grid, dim3 block,
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool wide_counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream)
 {
-    return dispatch(layout, lds_atomic, [&]<typename L, bool A>() {
-        hipLaunchKernelGGL((place_reads_kernel<L, A>), grid, block, lds_bytes, stream, p);
+    return dispatch(layout, wide_counts, [&]<typename L, typename C>() {
+        hipLaunchKernelGGL((place_reads_kernel<L, C>), grid, block, lds_bytes, stream, p);
         return hipGetLastError();
     });
 }
 
-hipError_t set_place_reads_lds_limit(DbLayout layout, bool lds_atomic, size_t lds_bytes)
+hipError_t set_place_reads_lds_limit(DbLayout layout, bool wide_counts, size_t lds_bytes)
 {
-    return dispatch(layout, lds_atomic, [&]<typename L, bool A>() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<L, A>),
+    return dispatch(layout, wide_counts, [&]<typename L, typename C>() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<L, C>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
 }
 
-hipError_t place_reads_occupancy(DbLayout layout, bool lds_atomic, int block_threads, size_t lds_bytes,
+hipError_t place_reads_occupancy(DbLayout layout, bool wide_counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu)
 {
-    return dispatch(layout, lds_atomic, [&]<typename L, bool A>() {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, place_reads_kernel<L, A>,
+    return dispatch(layout, wide_counts, [&]<typename L, typename C>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, place_reads_kernel<L, C>,
                                                             block_threads, lds_bytes);
     });
 }
@@ -1030,7 +1024,7 @@ hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsig
 {
     const dim3 block(256);
     const dim3 grid((unsigned)((p.n_reads + 255) / 256));
-    return dispatch(layout, false, [&]<typename L, bool A>() {
+    return dispatch(layout, false, [&]<typename L, typename C>() {
         hipLaunchKernelGGL((algorithmic_bytes_kernel<L>), grid, block, 0, stream, p, d_total);
         return hipGetLastError();
     });

@@ -135,6 +135,16 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
                                       const void *d_seq_offsets, uint64_t n, const void *d_n_rows,
                                       void *stream, uint64_t *bytes_out);
 
+/*
+ * The kernel keeps one count per branch in LDS: 16 bits by default (a read may have up
+ * to 32767 k-mers), which lets 20 wavefronts share a CU.  epik_amd_placer_place() switches
+ * to the 32-bit kernel by itself when a batch holds a longer read; for the device-pointer
+ * entry point the caller selects it here (enabled != 0).  With 16-bit counts a longer read
+ * gets n_rows == 0, like a read shorter than k.  (The reference counts in size_t,
+ * place.h:86.)
+ */
+int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled);
+
 /* Launch geometry actually used (for reports): waves per workgroup, workgroups
  * of the last launch, dynamic LDS bytes per workgroup. */
 int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,

@@ -66,12 +66,12 @@ def test_golden_fixture(placer_cls):
             assert int(counts[i, j]) == c
 
 
-@pytest.mark.parametrize("lds_atomic", ["1", "0"])
-def test_config1_shape_k10(placer_cls, oracle_lib, lds_atomic, monkeypatch):
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_config1_shape_k10(placer_cls, oracle_lib, wide, monkeypatch):
     """BASELINE configs[0]/[1] shape at a size the oracle finishes in seconds:
     nucl k=10, N=1303 (652 leaves, the D652 substitute), 150 bp reads.  Both the
-    LDS-atomic accumulate and the read-add-write one must be bit-exact."""
-    monkeypatch.setenv("EPIK_AMD_LDS_ATOMIC", lds_atomic)
+    16-bit-count kernels (default) and the 32-bit ("wide") ones must be bit-exact."""
+    monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", wide)
     tree = synth.make_tree(652, seed=42)
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
     data, offs = synth.make_reads(20000, 150, seed=44)
@@ -104,11 +104,12 @@ def test_keep_parameters(placer_cls, oracle_lib, small_case):
 
 def test_underflowing_scores_zero_lwr(placer_cls, oracle_lib):
     """Very long reads: 10^score underflows double -> score_sum == 0 -> every LWR is 0
-    and nothing is filtered (place.cpp:243-251)."""
+    and nothing is filtered (place.cpp:243-251).  The 40000-base read has more k-mers than
+    a 16-bit count holds: place() must switch to the wide kernel by itself."""
     tree = synth.make_tree(40, seed=4)
     db = synth.make_db(tree.num_nodes, kmer_size=6, seed=6, p_present=0.3)
     rng = np.random.default_rng(1)
-    reads = ["".join(rng.choice(list("ACGT"), size=n)) for n in (4000, 9000, 20000)]
+    reads = ["".join(rng.choice(list("ACGT"), size=n)) for n in (4000, 9000, 20000, 40000)]
     data, offs = synth.pack_reads(reads)
     orc = oracle_lib.Oracle.from_synth(db)
     ref = orc.place(data, offs)
