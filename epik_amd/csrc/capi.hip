@@ -8,12 +8,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "epik_amd.h"
@@ -77,7 +79,9 @@ struct epik_amd_placer {
     uint32_t *d_counts = nullptr;
     size_t d_reads_cap = 0;
     unsigned long long *d_total = nullptr;
-    hipStream_t stream = nullptr;  // owned, for the synchronous entry point
+    hipStream_t stream = nullptr;  // owned, for the synchronous entry point: kernels
+    hipStream_t stream_in = nullptr, stream_out = nullptr;  // ... its copies in and out
+    std::vector<hipEvent_t> ev_in, ev_kernel;               // per chunk of that entry point
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_recorded = false;
 };
@@ -125,7 +129,11 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_total);
     if (p->ev_start) (void)hipEventDestroy(p->ev_start);
     if (p->ev_stop) (void)hipEventDestroy(p->ev_stop);
+    for (hipEvent_t e : p->ev_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_kernel) (void)hipEventDestroy(e);
     if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->stream_in) (void)hipStreamDestroy(p->stream_in);
+    if (p->stream_out) (void)hipStreamDestroy(p->stream_out);
     delete p;
 }
 
@@ -311,6 +319,8 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_total), sizeof(unsigned long long)));
     CREATE_TRY(hipMemcpy(p->d_char_class, d->char_class, 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream_in, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream_out, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&p->ev_start));
     CREATE_TRY(hipEventCreate(&p->ev_stop));
 
@@ -409,6 +419,16 @@ int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const v
                   static_cast<hipStream_t>(stream));
 }
 
+// Reads per chunk of the host-buffer entry point: about 16 MB of sequence each, so that
+// the copy-in of chunk c+1 and the copy-out of chunk c-1 run under the kernel of chunk c.
+static uint64_t host_chunk_reads(uint64_t n, size_t seq_bytes)
+{
+    uint64_t chunks = (seq_bytes + (16u << 20) - 1) / (16u << 20);
+    if (const char *e = std::getenv("EPIK_AMD_HOST_CHUNKS")) chunks = std::strtoull(e, nullptr, 10);
+    chunks = std::min<uint64_t>(std::max<uint64_t>(chunks, 1), 256);
+    return std::max<uint64_t>((n + chunks - 1) / chunks, 1);
+}
+
 int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *seq_offsets,
                           uint64_t n, epik_amd_placement *rows, uint32_t *n_rows,
                           uint32_t *kmer_counts)
@@ -417,13 +437,14 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
     if (n == 0) return EPIK_AMD_OK;
     if (!seqs || !seq_offsets || !rows || !n_rows) return fail(EPIK_AMD_ERR_INVALID, "null host buffer");
     if (seq_offsets[0] != 0) return fail(EPIK_AMD_ERR_INVALID, "seq_offsets[0] must be 0");
-    for (uint64_t i = 0; i < n; ++i)
+    uint64_t longest = 0;
+    for (uint64_t i = 0; i < n; ++i) {
         if (seq_offsets[i + 1] < seq_offsets[i] || seq_offsets[i + 1] - seq_offsets[i] > 0xffffffffull)
             return fail(EPIK_AMD_ERR_INVALID, "seq_offsets not monotone, or a read of 2^32 characters or more");
+        longest = std::max<uint64_t>(longest, seq_offsets[i + 1] - seq_offsets[i]);
+    }
     HIP_TRY(hipSetDevice(p->device));
     // 16-bit per-branch counts unless a read has 32768 k-mers or more
-    uint64_t longest = 0;
-    for (uint64_t i = 0; i < n; ++i) longest = std::max<uint64_t>(longest, seq_offsets[i + 1] - seq_offsets[i]);
     const bool saved_wide = p->wide_counts;
     if (longest >= p->params.kmer_size && longest - p->params.kmer_size + 1 >= 32768u) p->wide_counts = true;
     struct restore_wide {
@@ -458,20 +479,88 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_counts), cap * keep * sizeof(uint32_t)));
         p->d_reads_cap = cap;
     }
+
+    // Chunked pipeline over three streams: this thread copies chunk c in (stream_in) and
+    // launches its kernel (stream); a helper thread copies finished chunks out (stream_out),
+    // so the two directions of the host link and the kernel all overlap.  Device buffers hold
+    // the whole batch (offsets stay absolute), only the transfers are chunked.
     const size_t keep = p->params.keep_at_most;
-    hipStream_t s = p->stream;
-    if (seq_bytes) HIP_TRY(hipMemcpyAsync(p->d_seqs, seqs, seq_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(p->d_seq_offsets, seq_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    // rows beyond n_rows[i] are never written by the kernel: give them a defined value
-    HIP_TRY(hipMemsetAsync(p->d_rows, 0, n * keep * sizeof(epik_amd_placement), s));
-    HIP_TRY(hipMemsetAsync(p->d_counts, 0, n * keep * sizeof(uint32_t), s));
-    const int rc = launch(p, p->d_seqs, p->d_seq_offsets, n, p->d_rows, p->d_n_rows, p->d_counts, s);
+    const uint64_t per_chunk = host_chunk_reads(n, seq_bytes);
+    const uint64_t n_chunks = (n + per_chunk - 1) / per_chunk;
+    while (p->ev_in.size() < n_chunks) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        p->ev_in.push_back(a);
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p->ev_kernel.push_back(b);
+    }
+    std::atomic<uint64_t> launched{0};
+    std::atomic<bool> abort_out{false};
+    hipError_t out_err = hipSuccess;
+    const auto copy_out_fn = [&] {
+        hipError_t e = hipSetDevice(p->device);
+        for (uint64_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+            while (launched.load(std::memory_order_acquire) <= c) {
+                if (abort_out.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            const uint64_t r0 = c * per_chunk, cnt = std::min(per_chunk, n - r0);
+            e = hipStreamWaitEvent(p->stream_out, p->ev_kernel[c], 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(rows + r0 * keep, p->d_rows + r0 * keep, cnt * keep * sizeof(epik_amd_placement),
+                                   hipMemcpyDeviceToHost, p->stream_out);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(n_rows + r0, p->d_n_rows + r0, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   p->stream_out);
+            if (e == hipSuccess && kmer_counts)
+                e = hipMemcpyAsync(kmer_counts + r0 * keep, p->d_counts + r0 * keep, cnt * keep * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, p->stream_out);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream_out);
+        out_err = e;
+    };
+    std::thread copy_out;  // a single chunk has nothing to overlap: no helper thread then
+    if (n_chunks > 1) copy_out = std::thread(copy_out_fn);
+    int rc = EPIK_AMD_OK;
+    hipError_t in_err = hipSuccess;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const uint64_t r0 = c * per_chunk, cnt = std::min(per_chunk, n - r0);
+        const uint64_t b0 = seq_offsets[r0], b1 = seq_offsets[r0 + cnt];
+        hipError_t e = hipSuccess;
+        if (b1 > b0) e = hipMemcpyAsync(p->d_seqs + b0, seqs + b0, b1 - b0, hipMemcpyHostToDevice, p->stream_in);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(p->d_seq_offsets + r0, seq_offsets + r0, (cnt + 1) * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, p->stream_in);
+        if (e == hipSuccess) e = hipEventRecord(p->ev_in[c], p->stream_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, p->ev_in[c], 0);
+        // rows beyond n_rows[i] are never written by the kernel: give them a defined value
+        if (e == hipSuccess)
+            e = hipMemsetAsync(p->d_rows + r0 * keep, 0, cnt * keep * sizeof(epik_amd_placement), p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(p->d_counts + r0 * keep, 0, cnt * keep * sizeof(uint32_t), p->stream);
+        if (e != hipSuccess) {
+            in_err = e;
+            break;
+        }
+        rc = launch(p, p->d_seqs, p->d_seq_offsets + r0, cnt, p->d_rows + r0 * keep, p->d_n_rows + r0,
+                    p->d_counts + r0 * keep, p->stream);
+        if (rc != EPIK_AMD_OK) break;
+        e = hipEventRecord(p->ev_kernel[c], p->stream);
+        if (e != hipSuccess) {
+            in_err = e;
+            break;
+        }
+        launched.store(c + 1, std::memory_order_release);
+    }
+    if (rc != EPIK_AMD_OK || in_err != hipSuccess) abort_out.store(true, std::memory_order_release);
+    if (copy_out.joinable())
+        copy_out.join();
+    else
+        copy_out_fn();
+    (void)hipStreamSynchronize(p->stream_in);
+    (void)hipStreamSynchronize(p->stream);
     if (rc != EPIK_AMD_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(rows, p->d_rows, n * keep * sizeof(epik_amd_placement), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(n_rows, p->d_n_rows, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (kmer_counts)
-        HIP_TRY(hipMemcpyAsync(kmer_counts, p->d_counts, n * keep * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (in_err != hipSuccess) return fail_hip(in_err, "copy-in / launch of the host-buffer pipeline");
+    if (out_err != hipSuccess) return fail_hip(out_err, "copy-out of the host-buffer pipeline");
     return EPIK_AMD_OK;
 }
 

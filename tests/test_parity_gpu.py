@@ -47,6 +47,21 @@ def test_small_db_mixed_reads(placer_cls, oracle_lib, small_case):
     _compare(placer_cls, oracle_lib, db, data, offs)
 
 
+@pytest.mark.parametrize("chunks", ["1", "7", "256"])
+def test_host_buffer_pipeline_chunks(placer_cls, oracle_lib, small_case, chunks, monkeypatch):
+    """`epik_amd_placer_place` copies in, computes and copies out in chunks on three streams;
+    the rows must not depend on how the batch was cut (ragged reads, empty reads at chunk
+    edges, more chunks than the 256 it caps at)."""
+    _, db = small_case
+    monkeypatch.setenv("EPIK_AMD_HOST_CHUNKS", chunks)
+    rng = np.random.default_rng(5)
+    reads = mixed_reads(rng, 3001, db.kmer_size, max_len=400)
+    for i in range(0, len(reads), 429):
+        reads[i] = ""
+    data, offs = synth.pack_reads(reads)
+    _compare(placer_cls, oracle_lib, db, data, offs)
+
+
 def test_golden_fixture(placer_cls):
     """Committed vectors (tests/golden/make_golden.py)."""
     with open(os.path.join(GOLDEN, "synth_k6.json")) as fh:
