@@ -5,6 +5,8 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r01}
+mkdir -p $R/tools/scratch
+[ -x $R/tools/scratch/calib_fetch ] || hipcc -O2 --offload-arch=gfx950 -o $R/tools/scratch/calib_fetch $R/tools/calib_fetch.hip
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
