@@ -52,10 +52,8 @@ struct epik_amd_placer {
     epik_amd::DbLayout layout = epik_amd::DbLayout::kCompact32;
     bool wide_counts = false;  // 32-bit per-branch counts (reads of 32768 k-mers or more)
     bool timing = false;
-    void *d_offsets = nullptr;   // compact layout
-    uint2 *d_values = nullptr;
-    uint8_t *d_db = nullptr;     // slotted layout: slot table + tail region
-    uint8_t *d_null = nullptr;   // the null posting padding chunks point at
+    void *d_table = nullptr;       // offsets (compact) or {len, line} entries (packed)
+    uint8_t *d_postings = nullptr; // 6-byte postings
     uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
     epik_amd::PlaceParams params{};  // batch fields are filled per call
@@ -116,10 +114,8 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
         (void)hipFree(p->params.dbg);
     }
 #endif
-    (void)hipFree(p->d_offsets);
-    (void)hipFree(p->d_values);
-    (void)hipFree(p->d_db);
-    (void)hipFree(p->d_null);
+    (void)hipFree(p->d_table);
+    (void)hipFree(p->d_postings);
     (void)hipFree(p->d_char_class);
     (void)hipFree(p->d_seqs);
     (void)hipFree(p->d_seq_offsets);
@@ -213,107 +209,103 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     }
 
 
+    // LDS rows per wave: the branches + the dummy row that out-of-range lanes of the posting
+    // loads fall on; a multiple of 4 rows of 64 (the epilogue's sweeps).  Postings carry a
+    // 16-bit cell = n_pad - 1 - branch.
+    epik_amd::PlaceParams &pp = p->params;
+    pp.n_pad = (d->num_branches + 1u + 255u) & ~255u;
+    if (pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u > kMaxLdsPerBlock) {  // the 32-bit-count kernels
+        epik_amd_placer_destroy(p);
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
+    }
+
     // ---- choose the HBM layout ---------------------------------------------------------
-    //  packed  (default): an 8-byte {len, tail} entry per k-mer code + every list 128-byte
-    //          aligned with 6-byte postings (8 with 32-bit branch ids): ~17 % fewer bytes
-    //          fetched per read than the CSR, measured the fastest;
-    //  slotted: 128-byte slots with short lists inline (one line per k-mer, lookup included);
-    //  compact: the plain CSR, 4-byte offsets + 8-byte postings, the smallest.
-    // packed / slotted are eligible when their table is at most a quarter of the device's
-    // free memory; EPIK_AMD_LAYOUT=compact|packed|slotted overrides the default.
+    //  packed  (default): an 8-byte {len, line} entry per k-mer code + every list on 128-byte
+    //          lines of its own: measured the fastest;
+    //  compact: the CSR (4- or 8-byte offsets), 8-byte postings back to back.
+    // packed is chosen when its table is at
+    // most a quarter of the device's free memory; EPIK_AMD_LAYOUT=compact|packed overrides.
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
     const char *lay = std::getenv("EPIK_AMD_LAYOUT");
-    const bool want_compact = lay && std::strcmp(lay, "compact") == 0;
-    const bool want_slotted = lay && std::strcmp(lay, "slotted") == 0;
-    const uint64_t slot_bytes = want_slotted ? 128 : 8;
-    const bool narrow = d->num_branches <= 65536u;
-    const uint32_t posting_bytes = narrow ? 6u : 8u;
-    const uint32_t slot_cap = (uint32_t)((slot_bytes - 8u) / posting_bytes);
-    const bool slotted = !want_compact && d->num_keys * slot_bytes <= free_mem / 4;
+    if (lay && std::strcmp(lay, "compact") != 0 && std::strcmp(lay, "packed") != 0) {
+        epik_amd_placer_destroy(p);
+        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact or packed");
+    }
+    const bool packed = lay ? std::strcmp(lay, "packed") == 0 : d->num_keys * 8u <= free_mem / 4;
     auto offset_at = [&](uint64_t key) -> uint64_t {
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
                             : static_cast<const uint32_t *>(d->offsets)[key];
     };
+    uint64_t lines = 0;  // packed: 128-byte lines of the posting region
     for (uint64_t key = 0; key < d->num_keys; ++key) {
         if (offset_at(key + 1) < offset_at(key)) {
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
         }
-        if (offset_at(key + 1) - offset_at(key) >= (1ull << 24)) {
+        const uint64_t len = offset_at(key + 1) - offset_at(key);
+        if (len >= (1ull << 24)) {
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
         }
+        lines += (len * 6u + 127u) / 128u;
     }
-    epik_amd::PlaceParams &pp = p->params;
-    if (slotted) {
-        p->layout = narrow ? epik_amd::DbLayout::kSlotted16 : epik_amd::DbLayout::kSlotted32;
-        // tail size: lists longer than a slot's payload, each padded to 128 bytes
-        const uint64_t table_bytes = d->num_keys * slot_bytes;
-        uint64_t tail_units = 0;
-        for (uint64_t key = 0; key < d->num_keys; ++key) {
-            const uint64_t len = offset_at(key + 1) - offset_at(key);
-            if (len > slot_cap) tail_units += (len * posting_bytes + 127u) / 128u;
-        }
-        if (tail_units >= (1ull << 32)) {
-            epik_amd_placer_destroy(p);
-            return fail(EPIK_AMD_ERR_UNSUPPORTED, "tail region of 512 GiB or more");
-        }
-        const uint64_t table_padded = (table_bytes + 127u) & ~127ull;  // the tail starts on a line
-        p->db_bytes = table_padded + tail_units * 128u + 256u;  // +256: the kernel's loads stay inside
+    if (packed && lines >= (1ull << 32)) {
+        epik_amd_placer_destroy(p);
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
+    }
+    {
+        // +512: room behind the last list (descriptors are exact, nothing reads it)
+        p->db_bytes = (packed ? lines * 128u : d->num_entries * 8u) + 512u;
         std::vector<uint8_t> host;
+        std::vector<uint32_t> table;  // packed: {len, line} per code
         try {
             host.assign(p->db_bytes, 0);
+            if (packed) table.assign(d->num_keys * 2, 0);
         } catch (const std::bad_alloc &) {
             epik_amd_placer_destroy(p);
-            return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the slotted database");
+            return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the device database");
         }
-        // one list = chunks of <= 64 postings, each chunk: f32 score[cnt] then branch[cnt]
+        const uint32_t top = pp.n_pad - 1u;
+        // packed: one list = chunks of <= 64 postings, each chunk f32 score[cnt] then u16 cell[cnt]
         auto write_list = [&](uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len) {
             for (uint64_t c0 = 0; c0 < len; c0 += 64) {
                 const uint32_t cnt = (uint32_t)((len - c0 < 64) ? len - c0 : 64);
-                float *scores = reinterpret_cast<float *>(dst);
-                for (uint32_t j = 0; j < cnt; ++j) scores[j] = src[c0 + j].score;
-                if (narrow) {
-                    uint16_t *br = reinterpret_cast<uint16_t *>(dst + 4u * cnt);
-                    for (uint32_t j = 0; j < cnt; ++j) br[j] = (uint16_t)src[c0 + j].branch;
-                } else {
-                    uint32_t *br = reinterpret_cast<uint32_t *>(dst + 4u * cnt);
-                    for (uint32_t j = 0; j < cnt; ++j) br[j] = src[c0 + j].branch;
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint16_t cell = (uint16_t)(top - src[c0 + j].branch);
+                    std::memcpy(dst + 4u * j, &src[c0 + j].score, 4);
+                    std::memcpy(dst + 4u * cnt + 2u * j, &cell, 2);
                 }
-                dst += (size_t)cnt * posting_bytes;
+                dst += (size_t)cnt * 6u;
             }
         };
-        uint64_t unit = 0;
-        for (uint64_t key = 0; key < d->num_keys; ++key) {
-            const uint64_t b = offset_at(key), len = offset_at(key + 1) - b;
-            uint8_t *slot = host.data() + key * slot_bytes;
-            uint32_t hdr[2] = {(uint32_t)len, 0u};
-            if (len > slot_cap) {
-                hdr[1] = (uint32_t)unit;
-                write_list(host.data() + table_padded + unit * 128u, d->values + b, len);
-                unit += (len * posting_bytes + 127u) / 128u;
-            } else if (len) {
-                write_list(slot + 8, d->values + b, len);
+        if (packed) {
+            p->layout = epik_amd::DbLayout::kPacked;
+            uint64_t line = 0;
+            for (uint64_t key = 0; key < d->num_keys; ++key) {
+                const uint64_t b = offset_at(key), len = offset_at(key + 1) - b;
+                table[2 * key] = (uint32_t)len;
+                table[2 * key + 1] = (uint32_t)line;
+                write_list(host.data() + line * 128u, d->values + b, len);
+                line += (len * 6u + 127u) / 128u;
             }
-            std::memcpy(slot, hdr, 8);
+            CREATE_TRY(hipMalloc(&p->d_table, table.size() * 4u + 8u));
+            CREATE_TRY(hipMemcpy(p->d_table, table.data(), table.size() * 4u, hipMemcpyHostToDevice));
+        } else {
+            p->layout = p->offsets64 ? epik_amd::DbLayout::kCompact64 : epik_amd::DbLayout::kCompact32;
+            for (uint64_t i = 0; i < d->num_entries; ++i) {  // {f32 score, u32 cell}
+                const uint32_t cell = top - d->values[i].branch;
+                std::memcpy(host.data() + 8u * i, &d->values[i].score, 4);
+                std::memcpy(host.data() + 8u * i + 4u, &cell, 4);
+            }
+            const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
+            CREATE_TRY(hipMalloc(&p->d_table, off_bytes));
+            CREATE_TRY(hipMemcpy(p->d_table, d->offsets, off_bytes, hipMemcpyHostToDevice));
         }
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_db), p->db_bytes));
-        CREATE_TRY(hipMemcpy(p->d_db, host.data(), p->db_bytes, hipMemcpyHostToDevice));
-        pp.db = p->d_db;
-        pp.tail_offset = table_padded;
-        pp.slot_bytes = (uint32_t)slot_bytes;
-        pp.slot_cap = slot_cap;
-    } else {
-        p->layout = p->offsets64 ? epik_amd::DbLayout::kCompact64 : epik_amd::DbLayout::kCompact32;
-        const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
-        const size_t val_bytes = (size_t)d->num_entries * sizeof(epik_amd_pkdb_value);
-        CREATE_TRY(hipMalloc(&p->d_offsets, off_bytes));
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_values), val_bytes ? val_bytes : 8));
-        CREATE_TRY(hipMemcpy(p->d_offsets, d->offsets, off_bytes, hipMemcpyHostToDevice));
-        if (val_bytes) CREATE_TRY(hipMemcpy(p->d_values, d->values, val_bytes, hipMemcpyHostToDevice));
-        pp.offsets = p->d_offsets;
-        pp.values = p->d_values;
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_postings), p->db_bytes));
+        CREATE_TRY(hipMemcpy(p->d_postings, host.data(), p->db_bytes, hipMemcpyHostToDevice));
+        pp.table = p->d_table;
+        pp.postings = p->d_postings;
     }
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_char_class), 256 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_total), sizeof(unsigned long long)));
@@ -332,23 +324,13 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     pp.keep_factor = d->keep_factor;
     pp.threshold = d->threshold;
     pp.log_threshold = d->log_threshold;
-    pp.log10_keep_factor_margin =
-        d->keep_factor > 0.0 ? (float)(std::log10(d->keep_factor) - 1e-3) : -INFINITY;
-    // + the dummy cell the null posting adds +0.0 to; a multiple of 4 rows of 64 (the epilogue's sweeps)
-    pp.n_pad = (d->num_branches + 1u + 255u) & ~255u;
-    {
-        const uint32_t dummy_cell = pp.n_pad - 1u;
-        const float zero = 0.0f;
-        uint8_t null_host[16] = {0};
-        std::memcpy(null_host + 0, &dummy_cell, 4);   // compact: {branch, score}
-        std::memcpy(null_host + 4, &zero, 4);
-        std::memcpy(null_host + 8, &zero, 4);         // slotted / packed: score[1] then branch[1]
-        std::memcpy(null_host + 12, &dummy_cell, 4);
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_null), 256));
-        CREATE_TRY(hipMemset(p->d_null, 0, 256));
-        CREATE_TRY(hipMemcpy(p->d_null, null_host, sizeof null_host, hipMemcpyHostToDevice));
-        pp.null_posting = p->d_null;
+#ifdef EPIK_AMD_ABLATION
+    if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
+    if (const char *st = std::getenv("EPIK_AMD_STAMPS"); st && st[0] == '1') {
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), 8 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(pp.dbg, 0, 8 * sizeof(unsigned long long)));
     }
+#endif
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, d->device));
     for (int wide = 0; wide < 2; ++wide) {

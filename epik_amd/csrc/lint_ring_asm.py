@@ -5,12 +5,13 @@ The ring's posting loads are issued from inline asm (uncounted by hipcc's s_wait
 bookkeeping), so a compiler-generated copy of a ring register made while its load is
 still in flight would capture stale data.  Every ring stage is, in program order,
 
-    asm: s_waitcnt vmcnt(N) ; slot vA vB   wait for slot i (its registers named in the text)
-    compiler code                          consumes slot i in place
-    asm: global_load_* -> slot i-1         refill of the slot the previous stage consumed
+    asm: s_waitcnt vmcnt(N) ; v_mad / v_mov    wait for slot i and move its values out
+    compiler code                              LDS read-add-write on the moved-out values
+    asm: buffer_load_* -> slot i               refill of the slot
 
-so a compiler-generated instruction may name a ring register only between the wait that
-names it and the next asm load into it.  Anything else fails the lint.
+so a ring register is in flight from the asm load that writes it until an asm VALU
+instruction reads it behind a wait; a compiler-generated instruction that names a register
+in flight fails the lint.
 Usage: lint_ring_asm.py place_kernel.s
 """
 import re
@@ -74,8 +75,10 @@ def lint_loop(name, body, events, problems):
         if in_asm:
             if s.startswith(("buffer_load_", "global_load_")):
                 inflight |= regs_of(operands[0])
-            elif s.startswith("v_mov_b32") and len(operands) == 2:
-                inflight -= regs_of(operands[1])  # moved out behind the wait of this statement
+            elif s.startswith("v_") and len(operands) >= 2:
+                # consumed (v_mov / v_mad) behind the wait of this same asm statement
+                for o in operands[1:]:
+                    inflight -= regs_of(o)
             continue
         touched = set()
         for o in operands:

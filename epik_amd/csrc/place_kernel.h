@@ -17,24 +17,17 @@ namespace epik_amd {
 
 // How the phylo-k-mer database is laid out in HBM (place_kernel.hip documents both).
 enum class DbLayout : int {
-    kCompact32 = 0,  // CSR, 32-bit offsets, 8-byte postings
-    kCompact64 = 1,  // CSR, 64-bit offsets
-    kSlotted16 = 2,  // 128-byte slot per k-mer code + tail region, 16-bit branch ids
-    kSlotted32 = 3,  // same with 32-bit branch ids (num_branches > 65536)
+    kCompact32 = 0,  // CSR: 32-bit offsets[num_keys + 1], 8-byte {f32 score, u32 cell} postings back to back
+    kCompact64 = 1,  // same with 64-bit offsets
+    kPacked = 2,     // 8-byte {len, first 128-byte line} entry per k-mer code, lists on whole lines,
+                     // 6 bytes per posting: f32 score[cnt] then u16 cell[cnt] per chunk of <= 64
 };
 
 // Kernel arguments: the database in HBM, the placer constants of place.cpp:83-96, and
 // one batch of reads.
 struct PlaceParams {
-    // compact layout
-    const void *offsets;         // OffT[num_keys + 1]
-    const uint2 *values;         // {branch, float bits of log10 score}[num_entries]
-    // slotted layout
-    const uint8_t *db;           // slot table, then the tail region
-    uint64_t tail_offset;        // byte offset of the tail region = num_keys * slot_bytes
-    uint32_t slot_bytes;         // 128
-    uint32_t slot_cap;           // postings that fit a slot's payload
-    const uint8_t *null_posting; // 16 bytes: {u32 dummy cell, f32 +0.0} then {f32 +0.0, u16/u32 dummy cell}
+    const void *table;           // compact: OffT offsets[num_keys + 1]; packed: uint2 {len, line}[num_keys]
+    const uint8_t *postings;     // scores + cells, cell = n_pad - 1 - branch
     const uint32_t *char_class;  // [256]
     const uint8_t *seqs;
     const uint64_t *seq_offsets; // [n_reads + 1]
@@ -49,8 +42,7 @@ struct PlaceParams {
     double keep_factor;
     float threshold;
     float log_threshold;
-    float log10_keep_factor_margin;  // log10(keep_factor) - 1e-3: early exit of the top-k rounds
-    uint32_t n_pad;                  // num_branches rounded up to 64
+    uint32_t n_pad;                  // LDS rows per wave: num_branches + the dummy row, rounded up to 256
     uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + chunk descriptors)
     uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
     unsigned long long *dbg;         // phase cycle sums (-DEPIK_AMD_ABLATION builds, EPIK_AMD_STAMPS=1)

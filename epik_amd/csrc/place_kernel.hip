@@ -10,10 +10,10 @@
 // Mapping: ONE WAVEFRONT (64 lanes) PLACES ONE READ.  The per-branch score and
 // count vectors (`_scores[thread]`, `_counts[thread]`, place.h:126-131) live in a
 // wave-private slice of LDS.  K-mers are consumed strictly in read order; the 64
-// lanes stride one posting list at a time (8-byte {branch, score} postings,
-// coalesced), and because branches are distinct inside a list no two lanes of an
-// instruction touch the same LDS cell, while LDS executes a wave's instructions in
-// order -- so every branch receives its float32 adds in exactly the k-mer order of
+// lanes stride one posting list at a time (6-byte {score, row} postings, coalesced),
+// and because branches are distinct inside a list no two lanes of an instruction
+// touch the same LDS cell, while LDS executes a wave's instructions in order -- so
+// every branch receives its float32 adds in exactly the k-mer order of
 // place.cpp:349-371 and the sums are bit-identical to the CPU loop.
 //
 // This is gather / scatter-add: HBM-bandwidth bound, no MFMA.
@@ -146,138 +146,129 @@ __device__ __forceinline__ double pow10_f64(double x) { return exp10(x); }
 
 // ---------------------------------------------------------------------------------
 // Database layouts in HBM.  Both answer phylo_kmer_db::search (place.cpp:300,311): a
-// k-mer code -> (opaque 40-bit address, list length); the wave then streams the list
-// in chunks of <= 64 postings.  `issue` puts one chunk's loads in flight from inline
-// asm (hipcc must not count them, see the ring below); `load_posting` is the plain,
-// compiler-counted access of the cold ambiguous path.
+// k-mer code -> (byte offset of its posting list in p.postings, list length).
+//
+// A posting is i2l::pkdb_value with the branch id replaced by the LDS row that accumulates
+// it, stored as cell = n_pad - 1 - branch.  The wave streams a list in chunks of <= 64
+// postings through RANGE-CHECKED buffer loads: the chunk's buffer descriptor holds its
+// byte length, lane l reads posting l, and a lane past the end reads 0 -- cell 0 = row
+// n_pad - 1, a dummy row no branch owns.  So a stage needs no address clamp, no exec mask
+// and no branch, and a padding chunk is a descriptor of zero bytes that touches no memory.
+// (tools/probe_buffer.hip: the range check includes soffset; 6-byte {score, cell} structs
+// read as 2-byte-aligned dwords work too but halve the load throughput.)
+//
+// A chunk descriptor {address (48 bits) | count << 48} is unpacked by every lane at once,
+// once per trip of the ring (vector work), into the kFields variable words of the chunk's
+// loads; a stage then pulls its chunk's words out with v_readlane: the CU's single scalar
+// unit does no unpacking.  `issue` puts one chunk's loads in flight from inline asm (hipcc
+// must not count them, see the ring below); `load_posting` is the plain, compiler-counted
+// access of the cold ambiguous path and returns {LDS row, score bits}.
 // ---------------------------------------------------------------------------------
+constexpr int kRawBufferFormat = 0x00020000;  // 4th descriptor word: untyped 32-bit raw buffer
 
-// Compact CSR: offsets[code .. code+1] into an array of 8-byte {branch, score} postings,
-// exactly i2l::pkdb_value.  Address unit = one posting.  Used when the slot table of the
-// layout below would not fit.
+// Compact CSR: offsets[code .. code+1] delimit the list in units of one posting; the lists
+// lie back to back as 8-byte {f32 score, u32 cell} (4 or 8 bytes per code + 8 per posting;
+// chosen when the table of the layout below would not fit).
 template <typename OffT>
 struct CompactLayout {
     static constexpr int kLoads = 1;  // vector-memory instructions per chunk
+    static constexpr uint32_t kChunkBytes = 64u * 8u;
+    static constexpr uint32_t kLaneStep = 8;
+    static constexpr int kFields = 3;  // base lo, base hi, bytes
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
                                                   uint32_t &len)
     {
-        const OffT *__restrict__ offsets = static_cast<const OffT *>(p.offsets);
+        const OffT *__restrict__ offsets = static_cast<const OffT *>(p.table);
         const OffT b = offsets[key];
         const OffT e = offsets[(uint64_t)key + 1];
-        addr = (uint64_t)b;
+        addr = (uint64_t)b * 8u;
         len = (uint32_t)(e - b);
     }
-    // absolute byte address of chunk c (64 postings each) of the list at `addr`
-    __device__ static __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t addr, uint32_t c)
-    {
-        return (uint64_t)(p.values + addr + (uint64_t)c * 64u);
-    }
-    // A chunk descriptor {address (48 bits) | count << 48} is unpacked by every lane at once,
-    // once per trip of the ring (vector work), into kFields words; a stage then pulls its
-    // chunk's words out with v_readlane: the CU's single scalar unit does no unpacking.
-    // Every chunk holds at least one posting (padding chunks point at a null posting).
-    static constexpr int kFields = 3;      // address lo, address hi, byte offset of the last posting
-    static constexpr uint32_t kLaneStep = 8;  // bytes per lane in `last`
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
         const uint32_t hi = (uint32_t)(d >> 32);
         f[0] = (uint32_t)d;
         f[1] = hi & 0xffffu;
-        f[2] = ((hi >> 16) - 1u) * 8u;
+        f[2] = (hi >> 16) * 8u;
     }
-    // Puts one chunk's load in flight: lane l reads posting min(l, cnt-1); lanes past the end
-    // re-read the last posting (same cache lines, no exec masking).  f[] is wave-uniform.
-    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane_off, uint32_t &branch,
+    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
                                                  uint32_t &score)
     {
-        const uint64_t base = ((uint64_t)f[1] << 32) | f[0];
-        const uint32_t off = min(lane_off, f[2]);
+        const v4i srd = {(int)f[0], (int)f[1], (int)f[2], kRawBufferFormat};
         v2u out;
-        // s_nop 4: base comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2"
+        // s_nop 4: the descriptor comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen"
                      : "=&v"(out)
-                     : "v"(off), "s"(base)
+                     : "v"(lane * 8u), "s"(srd)
                      : "memory");
-        branch = out.x;
-        score = out.y;
+        score = out.x;
+        cell = out.y;
     }
-    // the null posting padding chunks point at: {branch = dummy cell, score = +0.0}
-    __device__ static __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return (uint64_t)p.null_posting | (1ull << 48); }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
                                                          uint32_t j)
     {
         (void)len;
-        return p.values[addr + j];
+        const uint2 e = *reinterpret_cast<const uint2 *>(p.postings + addr + (uint64_t)j * 8u);
+        return make_uint2(p.n_pad - 1u - e.y, e.x);
     }
 };
 
-// Slotted: a direct-index table of 128-byte slots, one per k-mer code, = one L2 line.
-//   slot   : u32 len | u32 tail (128-byte units into the tail region) | payload
-//   len <= cap : the whole list sits in the payload        -> ONE line per k-mer, lookup included
-//   len >  cap : the list sits in the tail region, 128-byte aligned
-// A list is stored chunk by chunk (<= 64 postings): f32 score[cnt] then BranchT branch[cnt]
-// (6 bytes per posting with 16-bit branch ids instead of 8), so a full chunk is exactly
-// three lines and no line is shared between lists.  Address unit = one byte from p.db.
-template <typename BranchT>
-struct SlottedLayout {
+// Packed (default): a direct-index table of 8-byte entries {u32 len, u32 line} per k-mer
+// code (16 codes per 128-byte L2 line) and every list on whole 128-byte lines of its own.
+// A list is stored chunk by chunk (<= 64 postings): f32 score[cnt] then u16 cell[cnt] --
+// 6 bytes per posting, a full chunk is exactly three lines, no line is shared between lists.
+struct PackedLayout {
     static constexpr int kLoads = 2;
-    static constexpr uint32_t kPosting = 4u + (uint32_t)sizeof(BranchT);
+    static constexpr uint32_t kChunkBytes = 64u * 6u;
+    static constexpr int kFields = 4;  // base lo, base hi, bytes of the chunk, byte offset of its cells
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
                                                   uint32_t &len)
     {
-        const uint64_t slot = (uint64_t)key * p.slot_bytes;
-        const uint2 h = *reinterpret_cast<const uint2 *>(p.db + slot);
+        const uint2 h = static_cast<const uint2 *>(p.table)[key];
         len = h.x;
-        addr = (h.x <= p.slot_cap) ? slot + 8u : p.tail_offset + (uint64_t)h.y * 128u;
+        addr = (uint64_t)h.y * 128u;
     }
-    __device__ static __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t addr, uint32_t c)
-    {
-        return (uint64_t)(p.db + addr + (uint64_t)c * 64u * kPosting);
-    }
-    // see CompactLayout: address lo, address hi, byte offset of the last score
-    static constexpr int kFields = 3;
-    static constexpr uint32_t kLaneStep = 4;
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
         const uint32_t hi = (uint32_t)(d >> 32);
+        const uint32_t cnt = hi >> 16;
         f[0] = (uint32_t)d;
         f[1] = hi & 0xffffu;
-        f[2] = ((hi >> 16) - 1u) * 4u;
+        f[2] = cnt * 6u;
+        f[3] = cnt * 4u;
     }
-    // One chunk = f32 score[cnt] then BranchT branch[cnt]: two loads, lane l reads posting
-    // min(l, cnt-1) of each.  The branch array starts at 4*cnt = last + 4.  f[] is wave-uniform.
-    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane_off, uint32_t &branch,
+    // One descriptor over the whole chunk; the cell load adds the scalar offset 4*cnt, which
+    // takes part in the range check: lane l < cnt reads score l and cell l, every other lane
+    // reads cell 0 (and, up to lane 1.5*cnt, a score made of cell bytes that lands on the dummy row).
+    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
                                                  uint32_t &score)
     {
-        const uint64_t base = ((uint64_t)f[1] << 32) | f[0];
-        const uint32_t off_s = min(lane_off, f[2]);
-        const uint32_t off_b = (sizeof(BranchT) == 2 ? (off_s >> 1) : off_s) + f[2] + 4u;
-        if (sizeof(BranchT) == 2) {
-            asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_ushort %1, %3, %4"
-                         : "=&v"(score), "=&v"(branch)
-                         : "v"(off_s), "v"(off_b), "s"(base)
-                         : "memory");
-        } else {
-            asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4"
-                         : "=&v"(score), "=&v"(branch)
-                         : "v"(off_s), "v"(off_b), "s"(base)
-                         : "memory");
-        }
+        const v4i srd = {(int)f[0], (int)f[1], (int)f[2], kRawBufferFormat};
+        asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
+                     : "=&v"(score), "=&v"(cell)
+                     : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[3])
+                     : "memory");
     }
-    __device__ static __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return ((uint64_t)p.null_posting + 8u) | (1ull << 48); }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
                                                          uint32_t j)
     {
         const uint32_t chunk = j >> 6, r = j & 63u;
         const uint32_t rest = len - (chunk << 6);
         const uint32_t cnt = rest < 64u ? rest : 64u;
-        const uint8_t *base = p.db + addr + (uint64_t)chunk * 64u * kPosting;
-        uint2 e;
-        e.y = *reinterpret_cast<const uint32_t *>(base + 4u * r);
-        e.x = (uint32_t) * reinterpret_cast<const BranchT *>(base + 4u * cnt + (uint32_t)sizeof(BranchT) * r);
-        return e;
+        const uint8_t *base = p.postings + addr + (uint64_t)chunk * kChunkBytes;
+        const uint32_t cell = *reinterpret_cast<const uint16_t *>(base + 4u * cnt + 2u * r);
+        return make_uint2(p.n_pad - 1u - cell, *reinterpret_cast<const uint32_t *>(base + 4u * r));
     }
 };
+
+// absolute address of chunk c (64 postings each) of the list at byte offset `addr`
+template <typename Layout>
+__device__ __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t addr, uint32_t c)
+{
+    return (uint64_t)(p.postings + addr + (uint64_t)c * Layout::kChunkBytes);
+}
+// the padding chunk: zero bytes at a valid address
+__device__ __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return (uint64_t)p.postings; }
 
 // Everything a wave knows about the 64-character tile it is encoding.
 struct Tile {
@@ -385,7 +376,7 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
                     Layout::lookup(p, key, b0, n);
                     for (uint32_t off = 0; off < n; off += kWave) {
                         if (off + (uint32_t)lane < n) {
-                            const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);
+                            const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);  // {row, score bits}
                             uint2 cv = lds.load(e.x);
                             const uint32_t c = cv.y;
                             // Only the first ambiguous key that reaches a branch scores it:
@@ -435,7 +426,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     uint32_t touched = 0;
     float lane_best_f = -INFINITY;  // this lane's best score
     // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 4 * 64: cells
-    // behind N hold no count (the dummy cell of the null posting was cleared by the caller),
+    // behind N hold no count (the dummy row of the out-of-range lanes was cleared by the caller),
     // so there is no bounds test.  Four rows per lane and trip: the four LDS reads go out
     // together, and the arithmetic is branch-free.
     constexpr int kUnroll = 4;
@@ -672,6 +663,13 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         lds.count = reinterpret_cast<CountT *>(base + (size_t)p.n_pad * 4);
         lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * (4 + sizeof(CountT)));  // n_pad % 256 == 0
     }
+    // LDS byte addresses of the dummy row (cell 0) in the two vectors: row = n_pad - 1 - cell
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) CountT lds_count;
+    const uint32_t score_top = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(lds_f32 *)lds.score + (p.n_pad - 1u) * 4u);
+    const uint32_t count_top = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(lds_count *)lds.count + (p.n_pad - 1u) * (uint32_t)sizeof(CountT));
     // the argument block itself, for the out-of-line parts (no private copy of `p`)
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
     for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.store(i, 0u, 0u);
@@ -731,7 +729,13 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                         exact = tl.in_range && inv_w == 0 && amb_w == 0;
                         any_amb = any_amb || (__ballot(is_amb) != 0);
                     }
+#ifdef EPIK_AMD_ABLATION
+                    // bit 16: every lookup falls into the first 4096 table entries (L2-resident):
+                    // what the kernel would cost without the table's HBM traffic (wrong lists)
+                    if (exact) Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : tl.key, start[t], llen[t]);
+#else
                     if (exact) Layout::lookup(p, tl.key, start[t], llen[t]);
+#endif
                 }
             }
             EPIK_STAMP(0)  // front end: encode + lookups issued
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     const uint32_t idx = first[t] - w0;  // wraps when in front of the window
                     if (nch[t] != 0 && idx < kChunkCap) {
                         const uint64_t cnt = llen[t] < (uint32_t)kWave ? llen[t] : (uint32_t)kWave;
-                        chunks[idx] = Layout::chunk_address(p, start[t], 0) | (cnt << 48);
+                        chunks[idx] = chunk_address<Layout>(p, start[t], 0) | (cnt << 48);
                     }
                     uint64_t long_lists = __ballot(nch[t] > 1u);
                     while (long_lists) {
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                         if (c >= 1u && (c << 6) < l_len && idx2 < kChunkCap) {
                             const uint32_t rest = l_len - (c << 6);
                             const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                            chunks[idx2] = Layout::chunk_address(p, l_start, c) | (cnt << 48);
+                            chunks[idx2] = chunk_address<Layout>(p, l_start, c) | (cnt << 48);
                         }
                         // lists of more than 64 chunks (> 4096 postings): the lanes take further turns
                         for (uint32_t c2 = c + (uint32_t)kWave; (c2 << 6) < l_len; c2 += kWave) {
@@ -789,54 +793,48 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                             if (idx3 < kChunkCap) {
                                 const uint32_t rest = l_len - (c2 << 6);
                                 const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                                chunks[idx3] = Layout::chunk_address(p, l_start, c2) | (cnt << 48);
+                                chunks[idx3] = chunk_address<Layout>(p, l_start, c2) | (cnt << 48);
                             }
                         }
                     }
                 }
-                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = Layout::null_chunk(p);
+                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = null_chunk(p);
 
                 // (3) stream the chunks through a ring of kRing in-flight loads.  The loads are
                 // issued from inline asm (Layout::issue): hipcc must not count them, or it would
                 // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
-                // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that point
-                // and loads retire in issue order --, moves the posting out of the slot registers
-                // inside that same asm statement, and refills the slot with the next chunk.
+                // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that
+                // point and loads retire in issue order --, turns the cell into its two LDS
+                // addresses and moves the score out of the slot register inside that same asm
+                // statement, and refills the slot with the next chunk.
                 // (Letting hipcc read the slot registers itself, even behind a "+v" wait, is not
                 // safe: it is free to copy them into other registers AHEAD of the wait.)
-                uint32_t ring_b[kRing], ring_s[kRing];
-                int32_t ring_last[kRing];  // byte offset of the slot's last posting, -1 step = empty slot
+                uint32_t ring_c[kRing], ring_s[kRing];
 #pragma unroll
-                for (int i = 0; i < kRing; ++i) {
-                    ring_b[i] = ring_s[i] = 0;
-                    ring_last[i] = -(int32_t)Layout::kLaneStep;
-                }
-                const uint32_t lane_off = (uint32_t)lane * Layout::kLaneStep;
-                auto consume = [&](uint32_t br, uint32_t sc_bits, int32_t last, auto &&between) {
-                    // Every lane reads its cell (lanes past the chunk's end hold a copy of the
-                    // last posting: a valid address, a broadcast read); `between` (the refill)
-                    // overlaps the LDS latency; the add and the write-back come last and only
-                    // the chunk's own lanes write.
-                    const float sc = __uint_as_float(sc_bits);
+                for (int i = 0; i < kRing; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
+                auto accumulate = [&](uint32_t score_addr, uint32_t count_addr, uint32_t sc_bits, auto &&between) {
+                    // Every lane updates the row of its posting: branches are distinct inside a
+                    // list, lanes past the chunk's end all hold the dummy row (whose content
+                    // nobody reads).  `between` (the refill) overlaps the LDS read latency.
+                    lds_f32 *score_cell = (lds_f32 *)(uintptr_t)score_addr;
+                    lds_count *count_cell = (lds_count *)(uintptr_t)count_addr;
 #ifdef EPIK_AMD_ABLATION
                     const bool skip_acc = (p.ablate & 1u) != 0;
-                    if (skip_acc) asm volatile("" ::"v"(br), "v"(sc));
+                    if (skip_acc) asm volatile("" ::"v"(score_addr), "v"(count_addr), "v"(sc_bits));
 #else
                     constexpr bool skip_acc = false;
 #endif
-                    float *score_cell = &lds.score[br];
-                    CountT *count_cell = &lds.count[br];
                     float old_score = 0.0f;
                     uint32_t old_count = 0;
-                    if (!skip_acc) {  // both LDS reads go out for all lanes
+                    if (!skip_acc) {
                         old_score = *score_cell;
                         old_count = (uint32_t)*count_cell;
                     }
                     between();
                     __builtin_amdgcn_sched_barrier(0);  // keep the adds (and their LDS wait) below the refill
-                    if (!skip_acc && (int32_t)lane_off <= last) {
-                        *score_cell = __fadd_rn(old_score, sc);       // :366
-                        *count_cell = (CountT)(old_count + 1u);       // :365
+                    if (!skip_acc) {
+                        *score_cell = __fadd_rn(old_score, __uint_as_float(sc_bits));  // :366
+                        *count_cell = (CountT)(old_count + 1u);                        // :365
                     }
                 };
                 uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
@@ -846,38 +844,48 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
 #pragma unroll
                     for (int i = 0; i < kRing; ++i) {
-                        uint32_t br, sc_bits;
-                        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                                     : "=&v"(br), "=&v"(sc_bits)
-                                     : "v"(ring_b[i]), "v"(ring_s[i]), "i"(Layout::kLoads * (kRing - 1))
+                        uint32_t score_addr, count_addr, sc_bits;
+                        asm volatile("s_waitcnt vmcnt(%7)\n\t"
+                                     "v_mad_i32_i24 %0, %3, -4, %5\n\t"
+                                     "v_mad_i32_i24 %1, %3, %8, %6\n\t"
+                                     "v_mov_b32 %2, %4"
+                                     : "=&v"(score_addr), "=&v"(count_addr), "=&v"(sc_bits)
+                                     : "v"(ring_c[i]), "v"(ring_s[i]), "s"(score_top), "s"(count_top),
+                                       "n"(Layout::kLoads * (kRing - 1)), "n"(-(int)sizeof(CountT))
                                      : "memory");
-                        consume(br, sc_bits, ring_last[i], [&]() {
+                        accumulate(score_addr, count_addr, sc_bits, [&]() {
                             uint32_t f[Layout::kFields];
 #pragma unroll
                             for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
-                            ring_last[i] = (int32_t)f[2];
-                            Layout::issue(f, lane_off, ring_b[i], ring_s[i]);
+                            Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]);
                         });
                     }
                 }
                 // tail: nothing more to issue; retire the ring and consume what it holds
                 {
-                    uint32_t br[kRing], sc_bits[kRing];
+                    uint32_t score_addr[kRing], count_addr[kRing], sc_bits[kRing];
 #pragma unroll
                     for (int i = 0; i < kRing; ++i) {
                         if (i == 0)
-                            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                                         : "=&v"(br[i]), "=&v"(sc_bits[i])
-                                         : "v"(ring_b[i]), "v"(ring_s[i])
+                            asm volatile("s_waitcnt vmcnt(0)\n\t"
+                                         "v_mad_i32_i24 %0, %3, -4, %5\n\t"
+                                         "v_mad_i32_i24 %1, %3, %7, %6\n\t"
+                                         "v_mov_b32 %2, %4"
+                                         : "=&v"(score_addr[i]), "=&v"(count_addr[i]), "=&v"(sc_bits[i])
+                                         : "v"(ring_c[i]), "v"(ring_s[i]), "s"(score_top), "s"(count_top),
+                                           "n"(-(int)sizeof(CountT))
                                          : "memory");
                         else
-                            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                                         : "=&v"(br[i]), "=&v"(sc_bits[i])
-                                         : "v"(ring_b[i]), "v"(ring_s[i])
+                            asm volatile("v_mad_i32_i24 %0, %3, -4, %5\n\t"
+                                         "v_mad_i32_i24 %1, %3, %7, %6\n\t"
+                                         "v_mov_b32 %2, %4"
+                                         : "=&v"(score_addr[i]), "=&v"(count_addr[i]), "=&v"(sc_bits[i])
+                                         : "v"(ring_c[i]), "v"(ring_s[i]), "s"(score_top), "s"(count_top),
+                                           "n"(-(int)sizeof(CountT))
                                          : "memory");
                     }
 #pragma unroll
-                    for (int i = 0; i < kRing; ++i) consume(br[i], sc_bits[i], ring_last[i], []() {});
+                    for (int i = 0; i < kRing; ++i) accumulate(score_addr[i], count_addr[i], sc_bits[i], []() {});
                 }
             }
         }
@@ -895,7 +903,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         }
 #endif
         // ---- correction, sum_scores, top-k, LWR, rows out, reset of the wave's vectors ----------
-        if (lane == 0) lds.store(p.n_pad - 1u, 0u, 0u);  // the null posting's dummy cell
+        if (lane == 0) lds.store(p.n_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
         place_epilogue<Layout, CountT>(kp, lds, read, n_kmers);
         EPIK_STAMP(4)  // top-k, LWR, rows out, reset
     }
@@ -981,12 +989,9 @@ hipError_t dispatch(DbLayout layout, bool wide_counts, F &&f)
         case DbLayout::kCompact64:
             return wide_counts ? f.template operator()<CompactLayout<uint64_t>, uint32_t>()
                                : f.template operator()<CompactLayout<uint64_t>, uint16_t>();
-        case DbLayout::kSlotted16:
-            return wide_counts ? f.template operator()<SlottedLayout<uint16_t>, uint32_t>()
-                               : f.template operator()<SlottedLayout<uint16_t>, uint16_t>();
-        case DbLayout::kSlotted32:
-            return wide_counts ? f.template operator()<SlottedLayout<uint32_t>, uint32_t>()
-                               : f.template operator()<SlottedLayout<uint32_t>, uint16_t>();
+        case DbLayout::kPacked:
+            return wide_counts ? f.template operator()<PackedLayout, uint32_t>()
+                               : f.template operator()<PackedLayout, uint16_t>();
     }
     return hipErrorInvalidValue;
 }

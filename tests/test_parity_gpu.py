@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["packed", "slotted", "compact"])
+@pytest.fixture(autouse=True, params=["packed", "compact"])
 def db_layout(request, monkeypatch):
-    """Every parity test runs on both HBM layouts of the database (the slot table with
-    inline short lists, and the plain CSR used when that table would not fit)."""
+    """Every parity test runs on both HBM layouts of the database (line-aligned lists behind
+    a direct-index table, and the CSR used when that table would not fit)."""
     monkeypatch.setenv("EPIK_AMD_LAYOUT", request.param)
     return request.param
 
