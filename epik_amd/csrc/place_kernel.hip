@@ -220,7 +220,7 @@ struct CompactLayout {
 struct PackedLayout {
     static constexpr int kLoads = 2;
     static constexpr uint32_t kChunkBytes = 64u * 6u;
-    static constexpr int kFields = 4;  // base lo, base hi, bytes of the chunk, byte offset of its cells
+    static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
                                                   uint32_t &len)
     {
@@ -231,11 +231,9 @@ struct PackedLayout {
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
         const uint32_t hi = (uint32_t)(d >> 32);
-        const uint32_t cnt = hi >> 16;
         f[0] = (uint32_t)d;
         f[1] = hi & 0xffffu;
-        f[2] = cnt * 6u;
-        f[3] = cnt * 4u;
+        f[2] = hi >> 16;
     }
     // One descriptor over the whole chunk; the cell load adds the scalar offset 4*cnt, which
     // takes part in the range check: lane l < cnt reads score l and cell l, every other lane
@@ -243,10 +241,11 @@ struct PackedLayout {
     __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
                                                  uint32_t &score)
     {
-        const v4i srd = {(int)f[0], (int)f[1], (int)f[2], kRawBufferFormat};
+        // f[2] sits in a scalar register (v_readlane): the two products are scalar instructions
+        const v4i srd = {(int)f[0], (int)f[1], (int)(f[2] * 6u), kRawBufferFormat};
         asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
                      : "=&v"(score), "=&v"(cell)
-                     : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[3])
+                     : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[2] * 4u)
                      : "memory");
     }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
@@ -812,15 +811,28 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                 uint32_t ring_c[kRing], ring_s[kRing];
 #pragma unroll
                 for (int i = 0; i < kRing; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
-                auto accumulate = [&](uint32_t score_addr, uint32_t count_addr, uint32_t sc_bits, auto &&between) {
-                    // Every lane updates the row of its posting: branches are distinct inside a
-                    // list, lanes past the chunk's end all hold the dummy row (whose content
-                    // nobody reads).  `between` (the refill) overlaps the LDS read latency.
+                // One stage: (1) asm: wait for the slot, turn its cell into the two LDS addresses;
+                // (2) hipcc: both LDS reads, and meanwhile the next chunk's descriptor words out of
+                // the lanes; (3) asm: the float add, reading the score straight from the slot
+                // register (place.cpp:366); (4) hipcc: count + 1 (:365), both LDS writes;
+                // (5) asm: refill the slot.  Every lane updates the row of its posting: branches
+                // are distinct inside a list, and the lanes past the chunk's end all hold the
+                // dummy row, whose content nobody reads.
+                auto stage = [&](uint32_t &slot_cell, uint32_t &slot_score, auto wait_count, auto &&refill_words,
+                                 auto &&refill) {
+                    uint32_t score_addr, count_addr;
+                    asm volatile("s_waitcnt vmcnt(%5)\n\t"
+                                 "v_mad_i32_i24 %0, %2, -4, %3\n\t"
+                                 "v_mad_i32_i24 %1, %2, %6, %4"
+                                 : "=&v"(score_addr), "=&v"(count_addr)
+                                 : "v"(slot_cell), "s"(score_top), "s"(count_top), "n"(decltype(wait_count)::value),
+                                   "n"(-(int)sizeof(CountT))
+                                 : "memory");
                     lds_f32 *score_cell = (lds_f32 *)(uintptr_t)score_addr;
                     lds_count *count_cell = (lds_count *)(uintptr_t)count_addr;
 #ifdef EPIK_AMD_ABLATION
                     const bool skip_acc = (p.ablate & 1u) != 0;
-                    if (skip_acc) asm volatile("" ::"v"(score_addr), "v"(count_addr), "v"(sc_bits));
+                    if (skip_acc) asm volatile("" ::"v"(score_addr), "v"(count_addr));
 #else
                     constexpr bool skip_acc = false;
 #endif
@@ -830,12 +842,15 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                         old_score = *score_cell;
                         old_count = (uint32_t)*count_cell;
                     }
-                    between();
-                    __builtin_amdgcn_sched_barrier(0);  // keep the adds (and their LDS wait) below the refill
+                    refill_words();
+                    __builtin_amdgcn_sched_barrier(0);  // the v_readlanes above overlap the LDS reads' latency
+                    float new_score;
+                    asm volatile("v_add_f32 %0, %1, %2" : "=v"(new_score) : "v"(old_score), "v"(slot_score) : "memory");
                     if (!skip_acc) {
-                        *score_cell = __fadd_rn(old_score, __uint_as_float(sc_bits));  // :366
-                        *count_cell = (CountT)(old_count + 1u);                        // :365
+                        *score_cell = new_score;
+                        *count_cell = (CountT)(old_count + 1u);
                     }
+                    refill();
                 };
                 uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
                 for (uint32_t c0 = 0; c0 < n_padded; c0 += kRing) {
@@ -844,49 +859,20 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
 #pragma unroll
                     for (int i = 0; i < kRing; ++i) {
-                        uint32_t score_addr, count_addr, sc_bits;
-                        asm volatile("s_waitcnt vmcnt(%7)\n\t"
-                                     "v_mad_i32_i24 %0, %3, -4, %5\n\t"
-                                     "v_mad_i32_i24 %1, %3, %8, %6\n\t"
-                                     "v_mov_b32 %2, %4"
-                                     : "=&v"(score_addr), "=&v"(count_addr), "=&v"(sc_bits)
-                                     : "v"(ring_c[i]), "v"(ring_s[i]), "s"(score_top), "s"(count_top),
-                                       "n"(Layout::kLoads * (kRing - 1)), "n"(-(int)sizeof(CountT))
-                                     : "memory");
-                        accumulate(score_addr, count_addr, sc_bits, [&]() {
-                            uint32_t f[Layout::kFields];
+                        uint32_t f[Layout::kFields];
+                        stage(
+                            ring_c[i], ring_s[i], std::integral_constant<int, Layout::kLoads *(kRing - 1)>{},
+                            [&]() {
 #pragma unroll
-                            for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
-                            Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]);
-                        });
+                                for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
+                            },
+                            [&]() { Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]); });
                     }
                 }
-                // tail: nothing more to issue; retire the ring and consume what it holds
-                {
-                    uint32_t score_addr[kRing], count_addr[kRing], sc_bits[kRing];
+                // tail: nothing more to issue; retire the ring (the first stage waits for all of it)
 #pragma unroll
-                    for (int i = 0; i < kRing; ++i) {
-                        if (i == 0)
-                            asm volatile("s_waitcnt vmcnt(0)\n\t"
-                                         "v_mad_i32_i24 %0, %3, -4, %5\n\t"
-                                         "v_mad_i32_i24 %1, %3, %7, %6\n\t"
-                                         "v_mov_b32 %2, %4"
-                                         : "=&v"(score_addr[i]), "=&v"(count_addr[i]), "=&v"(sc_bits[i])
-                                         : "v"(ring_c[i]), "v"(ring_s[i]), "s"(score_top), "s"(count_top),
-                                           "n"(-(int)sizeof(CountT))
-                                         : "memory");
-                        else
-                            asm volatile("v_mad_i32_i24 %0, %3, -4, %5\n\t"
-                                         "v_mad_i32_i24 %1, %3, %7, %6\n\t"
-                                         "v_mov_b32 %2, %4"
-                                         : "=&v"(score_addr[i]), "=&v"(count_addr[i]), "=&v"(sc_bits[i])
-                                         : "v"(ring_c[i]), "v"(ring_s[i]), "s"(score_top), "s"(count_top),
-                                           "n"(-(int)sizeof(CountT))
-                                         : "memory");
-                    }
-#pragma unroll
-                    for (int i = 0; i < kRing; ++i) accumulate(score_addr[i], count_addr[i], sc_bits[i], []() {});
-                }
+                for (int i = 0; i < kRing; ++i)
+                    stage(ring_c[i], ring_s[i], std::integral_constant<int, 0>{}, []() {}, []() {});
             }
         }
 

@@ -5,7 +5,7 @@ Runs the bench workload through several variants IN ONE PROCESS, interleaved ove
 rounds (devices differ by several percent: never compare across runs).  A variant is a
 comma-separated list of key=value:
     lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
-    layout=compact|packed, ablate=<bitmask>, stamps=1   (env read at placer creation)
+    layout=compact|packed, wide=0|1, ablate=<bitmask>, stamps=1   (env read at placer creation)
 Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
 """
 import ctypes
@@ -41,6 +41,7 @@ def main():
     placers = []
     for kv in variants:
         os.environ["EPIK_AMD_ABLATE"] = kv.get("ablate", "0")
+        os.environ["EPIK_AMD_WIDE_COUNTS"] = kv.get("wide", "0")
         os.environ["EPIK_AMD_STAMPS"] = kv.get("stamps", "0")
         os.environ["EPIK_AMD_LAYOUT"] = kv.get("layout", "packed")
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
