@@ -731,7 +731,10 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
 #ifdef EPIK_AMD_ABLATION
                     // bit 16: every lookup falls into the first 4096 table entries (L2-resident):
                     // what the kernel would cost without the table's HBM traffic (wrong lists)
-                    if (exact) Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : tl.key, start[t], llen[t]);
+                    // bits 32 / 64: the table shrunk to a half / a quarter (key >> 1, key >> 2)
+                    if (exact)
+                        Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : (tl.key >> ((p.ablate >> 5) & 3u)), start[t],
+                                       llen[t]);
 #else
                     if (exact) Layout::lookup(p, tl.key, start[t], llen[t]);
 #endif
