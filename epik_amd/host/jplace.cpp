@@ -1,9 +1,12 @@
 #include "jplace.hpp"
 
+#include <algorithm>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
+#include <thread>
+#include <vector>
 
 namespace epik_amd::io {
 
@@ -60,22 +63,48 @@ void jplace_writer::start()
     _out.flush();
 }
 
-jplace_writer& jplace_writer::operator<<(const impl::placed_collection& placed)
+namespace {
+
+void append_double(std::string& out, double v)
 {
-    std::string buffer;
-    for (const auto& placed_seq : placed.placed_seqs) {
-        buffer += _first ? "\n        {\n" : ",\n        {\n";
-        _first = false;
+    if (!std::isfinite(v)) {  // JSON has no inf/nan (RapidJSON refuses them too)
+        out += "null";
+        return;
+    }
+    char buf[40];
+    const auto res = std::to_chars(buf, buf + sizeof buf, v);  // shortest round-trip form
+    const std::string_view text(buf, (size_t)(res.ptr - buf));
+    out += text;
+    if (text.find_first_of(".eE") == std::string_view::npos) out += ".0";  // Writer::Double keeps a fraction
+}
+
+void append_uint(std::string& out, uint64_t v)
+{
+    char buf[24];
+    const auto res = std::to_chars(buf, buf + sizeof buf, v);
+    out.append(buf, (size_t)(res.ptr - buf));
+}
+
+/// The objects of placed_seqs[begin, end), joined with "," (no leading or trailing comma).
+void format_objects(const impl::placed_collection& placed, size_t begin, size_t end, std::string& buffer)
+{
+    for (size_t i = begin; i < end; ++i) {
+        const auto& placed_seq = placed.placed_seqs[i];
+        buffer += i == begin ? "\n        {\n" : ",\n        {\n";
         buffer += "            \"p\": [";
         bool first_row = true;
         for (const auto& p : placed_seq.placements) {  // jplace.cpp:121-139; `count` is not written
             buffer += first_row ? "\n                [" : ",\n                [";
             first_row = false;
-            buffer += std::to_string(p.branch_id);
-            buffer += ", " + json_double((double)p.score);
-            buffer += ", " + json_double(p.weight_ratio);
-            buffer += ", " + json_double(p.distal_length);
-            buffer += ", " + json_double(p.pendant_length);
+            append_uint(buffer, p.branch_id);
+            buffer += ", ";
+            append_double(buffer, (double)p.score);
+            buffer += ", ";
+            append_double(buffer, p.weight_ratio);
+            buffer += ", ";
+            append_double(buffer, p.distal_length);
+            buffer += ", ";
+            append_double(buffer, p.pendant_length);
             buffer += "]";
         }
         buffer += first_row ? "],\n" : "\n            ],\n";
@@ -90,7 +119,41 @@ jplace_writer& jplace_writer::operator<<(const impl::placed_collection& placed)
         buffer += first_name ? "]\n" : "\n            ]\n";
         buffer += "        }";
     }
-    _out << buffer;
+}
+
+}  // namespace
+
+jplace_writer& jplace_writer::operator<<(const impl::placed_collection& placed)
+{
+    return write(placed, 1);
+}
+
+jplace_writer& jplace_writer::write(const impl::placed_collection& placed, size_t num_threads)
+{
+    const size_t n = placed.placed_seqs.size();
+    if (n == 0) return *this;
+    // one slice of the batch per thread, formatted side by side, written in order
+    const size_t parts = std::max<size_t>(1, std::min(num_threads, n / 2048 + 1));
+    std::vector<std::string> buffers(parts);
+    auto format_part = [&](size_t part) {
+        const size_t begin = n * part / parts, end = n * (part + 1) / parts;
+        buffers[part].reserve((end - begin) * 900);
+        format_objects(placed, begin, end, buffers[part]);
+    };
+    if (parts == 1) {
+        format_part(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t part = 1; part < parts; ++part) threads.emplace_back(format_part, part);
+        format_part(0);
+        for (auto& t : threads) t.join();
+    }
+    for (const auto& buffer : buffers) {
+        if (buffer.empty()) continue;
+        if (!_first) _out.put(',');
+        _first = false;
+        _out.write(buffer.data(), (std::streamsize)buffer.size());
+    }
     _out.flush();
     return *this;
 }

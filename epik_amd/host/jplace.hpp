@@ -19,6 +19,8 @@ public:
     jplace_writer(const std::string& filename, const std::string& invocation, std::string_view newick_tree);
     void start();
     jplace_writer& operator<<(const impl::placed_collection& placed);
+    /// the same, with the JSON text of the batch formatted by `num_threads` threads
+    jplace_writer& write(const impl::placed_collection& placed, size_t num_threads);
     void end();
 
 private:

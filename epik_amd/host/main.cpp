@@ -11,6 +11,11 @@
 // accepts DNA databases, epik-aa protein ones.
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <iomanip>
@@ -30,6 +35,59 @@
 
 #ifndef EPIK_AMD_NO_MAIN
 namespace {
+
+/// Hand-over between two stages of the driver: at most `capacity` items wait; close() wakes
+/// everybody and makes push() / pop() return false.
+template <typename T>
+class bounded_queue {
+public:
+    explicit bounded_queue(size_t capacity) : _capacity(capacity) {}
+    bool push(T item)
+    {
+        std::unique_lock<std::mutex> lock(_mutex);
+        _not_full.wait(lock, [&] { return _closed || _items.size() < _capacity; });
+        if (_closed) return false;
+        _items.push_back(std::move(item));
+        _not_empty.notify_one();
+        return true;
+    }
+    bool pop(T& item)
+    {
+        std::unique_lock<std::mutex> lock(_mutex);
+        _not_empty.wait(lock, [&] { return _closed || !_items.empty(); });
+        if (_items.empty()) return false;  // closed and drained
+        item = std::move(_items.front());
+        _items.pop_front();
+        _not_full.notify_one();
+        return true;
+    }
+    void close()
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        _closed = true;
+        _not_full.notify_all();
+        _not_empty.notify_all();
+    }
+
+private:
+    std::mutex _mutex;
+    std::condition_variable _not_full, _not_empty;
+    std::deque<T> _items;
+    size_t _capacity;
+    bool _closed = false;
+};
+
+/// Busy time of one stage.
+class stage_clock {
+public:
+    void start() { _begin = std::chrono::steady_clock::now(); }
+    void stop() { _total += std::chrono::steady_clock::now() - _begin; }
+    double ms() const { return std::chrono::duration<double, std::milli>(_total).count(); }
+
+private:
+    std::chrono::steady_clock::time_point _begin;
+    std::chrono::steady_clock::duration _total{};
+};
 
 #ifdef EPIK_AMD_AA
 constexpr const char* kSequenceType = "Proteins";
@@ -298,20 +356,75 @@ int main(int argc, char** argv)
         double average_speed = 0.0;
         size_t num_iterations = 0;
 
-        epik_amd::io::batch_fasta reader(query_file, batch_size);
-        while (true) {
-            const auto batch = reader.next_batch();
-            if (batch.empty()) break;
-            const auto begin_batch = std::chrono::steady_clock::now();
-            const auto placed_batch = placer.place(batch, num_threads);
-            const auto end_batch = std::chrono::steady_clock::now();
-            auto ms_diff = (float)std::chrono::duration_cast<std::chrono::milliseconds>(end_batch - begin_batch).count();
-            if (ms_diff == 0) ms_diff = 1;
-            average_speed += 1000.0 * (double)batch_size / ms_diff;  // main.cpp:351-352 (nominal batch size)
-            jplace << placed_batch;
-            num_seq_placed += batch.size();
-            ++num_iterations;
+        // Three stages on three threads, batches handed on through short queues: the FASTA
+        // reader, the placer (this thread: dedup, GPU, length join) and the jplace writer
+        // (formatting on `--jobs` threads).  The reference runs them one after the other
+        // (main.cpp:336-361); batch boundaries, dedup per batch and output order are the same.
+        struct work_item {
+            std::vector<epik_amd::seq_record> batch;     // owns the bytes the views below point into
+            epik_amd::placer::placed_collection placed;
+        };
+        bounded_queue<std::vector<epik_amd::seq_record>> to_place(4);
+        bounded_queue<work_item> to_write(4);
+        std::exception_ptr reader_error, writer_error;
+        stage_clock read_clock, place_clock, write_clock;
+        std::thread reader_thread([&] {
+            try {
+                epik_amd::io::batch_fasta reader(query_file, batch_size);
+                while (true) {
+                    read_clock.start();
+                    auto batch = reader.next_batch();
+                    read_clock.stop();
+                    const bool last = batch.empty();
+                    if (!to_place.push(std::move(batch)) || last) break;  // an empty batch ends the stream
+                }
+            } catch (...) {
+                reader_error = std::current_exception();
+                to_place.push({});
+            }
+        });
+        std::thread writer_thread([&] {
+            try {
+                work_item item;
+                while (to_write.pop(item)) {
+                    write_clock.start();
+                    jplace.write(item.placed, num_threads);
+                    write_clock.stop();
+                }
+            } catch (...) {
+                writer_error = std::current_exception();
+                to_write.close();
+            }
+        });
+        std::exception_ptr placer_error;
+        try {
+            std::vector<epik_amd::seq_record> batch;
+            while (to_place.pop(batch) && !batch.empty()) {
+                const auto begin_batch = std::chrono::steady_clock::now();
+                place_clock.start();
+                auto placed_batch = placer.place(batch, num_threads);
+                place_clock.stop();
+                const auto end_batch = std::chrono::steady_clock::now();
+                auto ms_diff =
+                    (float)std::chrono::duration_cast<std::chrono::milliseconds>(end_batch - begin_batch).count();
+                if (ms_diff == 0) ms_diff = 1;
+                average_speed += 1000.0 * (double)batch_size / ms_diff;  // main.cpp:351-352 (nominal batch size)
+                num_seq_placed += batch.size();
+                ++num_iterations;
+                if (!to_write.push(work_item{std::move(batch), std::move(placed_batch)})) break;
+            }
+        } catch (...) {
+            placer_error = std::current_exception();
         }
+        to_place.close();
+        to_write.close();
+        reader_thread.join();
+        writer_thread.join();
+        for (const auto& error : {placer_error, reader_error, writer_error})
+            if (error) std::rethrow_exception(error);
+        if (std::getenv("EPIK_AMD_STAGE_TIMES"))
+            std::cout << "stage read " << read_clock.ms() << " ms\nstage place " << place_clock.ms()
+                      << " ms\nstage write " << write_clock.ms() << " ms" << std::endl;
         jplace.end();
         if (num_iterations) average_speed /= (double)num_iterations;
         std::cout << std::endl
