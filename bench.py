@@ -50,6 +50,10 @@ def parse_args():
                     help="target CPU time of the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--scattered", action="store_true",
                     help="non-contiguous branch sets in the synthetic posting lists")
+    ap.add_argument("--states", choices=["nucl", "amino"], default="nucl",
+                    help="amino: the protein path (BASELINE configs[3]: --states amino --kmer-size 7 "
+                         "--read-length 300 --p-present 0.0026); the default line is configs[1]")
+    ap.add_argument("--p-present", type=float, default=0.6, help="fraction of k-mer codes that have a posting list")
     return ap.parse_args()
 
 
@@ -131,13 +135,20 @@ def main():
 
     # ---- synthetic workload, identical DB on every rank ---------------
     tree = synth.make_tree(args.leaves, seed=42)
-    db = synth.make_db(tree.num_nodes, kmer_size=args.kmer_size, seed=43, scattered=args.scattered)
-    data, offs = synth.make_reads(args.reads_per_step, args.read_length, seed=44 + rank)
-    workload = (f"nucl k={args.kmer_size} omega=1.5 mu=1.0 synthetic DB, N={tree.num_nodes} branches, "
+    if rank == 0:
+        print("[bench] building the synthetic database ...", file=sys.stderr, flush=True)
+    db = synth.make_db(tree.num_nodes, states=args.states, kmer_size=args.kmer_size, seed=43,
+                       p_present=args.p_present, scattered=args.scattered)
+    data, offs = synth.make_reads(args.reads_per_step, args.read_length, states=args.states, seed=44 + rank)
+    unit = "bp" if args.states == "nucl" else "aa"
+    workload = (f"{args.states} k={args.kmer_size} omega=1.5 mu=1.0 synthetic DB, N={tree.num_nodes} branches, "
                 f"{db.num_entries} postings ({db.num_entries * 8 / 1e6:.0f} MB), "
-                f"{args.reads_per_step} x {args.read_length} bp reads per step per GPU"
-                + (", scattered branch sets" if args.scattered else ""))
+                f"{args.reads_per_step} x {args.read_length} {unit} reads per step per GPU"
+                + (", scattered branch sets" if args.scattered else "")
+                + (f", {args.p_present:g} of the codes present" if args.p_present != 0.6 else ""))
 
+    if rank == 0:
+        print(f"[bench] {db.num_entries} postings; uploading ...", file=sys.stderr, flush=True)
     placer = Placer.from_synth(db, device=local_rank)
     n = args.reads_per_step
     keep = placer.keep_at_most
