@@ -33,6 +33,9 @@ EXPORTS = (
     "epik_amd_placer_place",
     "epik_amd_placer_place_device",
     "epik_amd_placer_algorithmic_bytes",
+    "epik_amd_placer_create_sharded",
+    "epik_amd_placer_accumulate_device",
+    "epik_amd_placer_finish_device",
     "epik_amd_placer_set_wide_counts",
     "epik_amd_placer_launch_info",
     "epik_amd_placer_set_timing",
@@ -89,6 +92,13 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_last_error.argtypes = []
     lib.epik_amd_placer_create.restype = i32
     lib.epik_amd_placer_create.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.POINTER(vp)]
+    lib.epik_amd_placer_create_sharded.restype = i32
+    lib.epik_amd_placer_create_sharded.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32,
+                                                   ctypes.POINTER(vp)]
+    lib.epik_amd_placer_accumulate_device.restype = i32
+    lib.epik_amd_placer_accumulate_device.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    lib.epik_amd_placer_finish_device.restype = i32
+    lib.epik_amd_placer_finish_device.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp]
     lib.epik_amd_placer_destroy.restype = None
     lib.epik_amd_placer_destroy.argtypes = [vp]
     lib.epik_amd_placer_place.restype = i32

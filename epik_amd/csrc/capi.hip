@@ -135,8 +135,16 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
 
 int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
 {
+    return epik_amd_placer_create_sharded(d, 0, 1, out);
+}
+
+int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count,
+                                   epik_amd_placer **out)
+{
     if (!d || !out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
     *out = nullptr;
+    if (shard_count == 0 || shard_index >= shard_count)
+        return fail(EPIK_AMD_ERR_INVALID, "shard_index must be below shard_count");
     if (d->abi_version != EPIK_AMD_ABI_VERSION)
         return fail(EPIK_AMD_ERR_INVALID, "abi_version mismatch");
     if (d->kmer_size < 1 || d->kmer_size > 32)
@@ -237,13 +245,19 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
                             : static_cast<const uint32_t *>(d->offsets)[key];
     };
+    // k-mer-space shard: this placer keeps the lists of the codes with code % count == index
+    auto kept_len = [&](uint64_t key) -> uint64_t {
+        return (shard_count == 1 || key % shard_count == shard_index) ? offset_at(key + 1) - offset_at(key) : 0;
+    };
     uint64_t lines = 0;  // packed: 128-byte lines of the posting region
+    uint64_t kept_entries = 0;
     for (uint64_t key = 0; key < d->num_keys; ++key) {
         if (offset_at(key + 1) < offset_at(key)) {
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
         }
-        const uint64_t len = offset_at(key + 1) - offset_at(key);
+        const uint64_t len = kept_len(key);
+        kept_entries += len;
         if (len >= (1ull << 24)) {
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
@@ -256,7 +270,7 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     }
     {
         // +512: room behind the last list (descriptors are exact, nothing reads it)
-        p->db_bytes = (packed ? lines * 128u : d->num_entries * 8u) + 512u;
+        p->db_bytes = (packed ? lines * 128u : kept_entries * 8u) + 512u;
         std::vector<uint8_t> host;
         std::vector<uint32_t> table;  // packed: {len, line} per code
         try {
@@ -283,7 +297,7 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
             p->layout = epik_amd::DbLayout::kPacked;
             uint64_t line = 0;
             for (uint64_t key = 0; key < d->num_keys; ++key) {
-                const uint64_t b = offset_at(key), len = offset_at(key + 1) - b;
+                const uint64_t b = offset_at(key), len = kept_len(key);
                 table[2 * key] = (uint32_t)len;
                 table[2 * key + 1] = (uint32_t)line;
                 write_list(host.data() + line * 128u, d->values + b, len);
@@ -293,14 +307,29 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
             CREATE_TRY(hipMemcpy(p->d_table, table.data(), table.size() * 4u, hipMemcpyHostToDevice));
         } else {
             p->layout = p->offsets64 ? epik_amd::DbLayout::kCompact64 : epik_amd::DbLayout::kCompact32;
-            for (uint64_t i = 0; i < d->num_entries; ++i) {  // {f32 score, u32 cell}
-                const uint32_t cell = top - d->values[i].branch;
-                std::memcpy(host.data() + 8u * i, &d->values[i].score, 4);
-                std::memcpy(host.data() + 8u * i + 4u, &cell, 4);
-            }
+            // the kept lists back to back as {f32 score, u32 cell}; with one shard the offsets
+            // are the caller's, otherwise they are rebuilt over the kept lists
+            std::vector<uint8_t> own_offsets;
             const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
+            if (shard_count > 1) own_offsets.assign(off_bytes, 0);
+            uint64_t at = 0;
+            for (uint64_t key = 0; key < d->num_keys; ++key) {
+                const uint64_t b = offset_at(key), len = kept_len(key);
+                for (uint64_t j = 0; j < len; ++j, ++at) {
+                    const uint32_t cell = top - d->values[b + j].branch;
+                    std::memcpy(host.data() + 8u * at, &d->values[b + j].score, 4);
+                    std::memcpy(host.data() + 8u * at + 4u, &cell, 4);
+                }
+                if (shard_count > 1) {
+                    if (p->offsets64)
+                        reinterpret_cast<uint64_t *>(own_offsets.data())[key + 1] = at;
+                    else
+                        reinterpret_cast<uint32_t *>(own_offsets.data())[key + 1] = (uint32_t)at;
+                }
+            }
             CREATE_TRY(hipMalloc(&p->d_table, off_bytes));
-            CREATE_TRY(hipMemcpy(p->d_table, d->offsets, off_bytes, hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(p->d_table, shard_count > 1 ? static_cast<const void *>(own_offsets.data()) : d->offsets,
+                                 off_bytes, hipMemcpyHostToDevice));
         }
         CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_postings), p->db_bytes));
         CREATE_TRY(hipMemcpy(p->d_postings, host.data(), p->db_bytes, hipMemcpyHostToDevice));
@@ -347,6 +376,7 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
         while (g.waves_per_block > 1 && g.waves_per_block * g.lds_wave_bytes > kMaxLdsPerBlock / 2) g.waves_per_block >>= 1;
         g.lds_block_bytes = g.waves_per_block * g.lds_wave_bytes;
         CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, wide != 0, g.lds_block_bytes));
+        CREATE_TRY(epik_amd::set_finish_reads_lds_limit(wide != 0, g.lds_block_bytes));
         // persistent-style grid: exactly the workgroups that are resident at once
         // (registers, LDS and the 32-waves/CU cap decide), each striding over the reads
         int per_cu = 0;
@@ -363,10 +393,13 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
 }
 
 static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets, uint64_t n,
-                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream)
+                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream,
+                  float *partial_scores = nullptr, uint32_t *partial_counts = nullptr)
 {
     if (n == 0) return EPIK_AMD_OK;
     epik_amd::PlaceParams pp = p->params;
+    pp.partial_scores = partial_scores;  // non-null: accumulate only
+    pp.partial_counts = partial_counts;
     pp.seqs = static_cast<const uint8_t *>(d_seqs);
     pp.seq_offsets = static_cast<const uint64_t *>(d_seq_offsets);
     pp.n_reads = n;
@@ -386,6 +419,43 @@ static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offs
         HIP_TRY(hipEventRecord(p->ev_stop, stream));
         p->ev_recorded = true;
     }
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_accumulate_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
+                                      uint64_t n, void *d_scores, void *d_counts, void *stream)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (n && (!d_seqs || !d_seq_offsets || !d_scores || !d_counts))
+        return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    return launch(p, d_seqs, d_seq_offsets, n, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream),
+                  static_cast<float *>(d_scores), static_cast<uint32_t *>(d_counts));
+}
+
+int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets, uint64_t n,
+                                  const void *d_scores, const void *d_counts, void *d_rows, void *d_n_rows,
+                                  void *d_kmer_counts, void *stream)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (n == 0) return EPIK_AMD_OK;
+    if (!d_seq_offsets || !d_scores || !d_counts || !d_rows || !d_n_rows)
+        return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    epik_amd::PlaceParams pp = p->params;
+    pp.seq_offsets = static_cast<const uint64_t *>(d_seq_offsets);
+    pp.n_reads = n;
+    pp.rows = static_cast<epik_amd_placement *>(d_rows);
+    pp.n_rows = static_cast<uint32_t *>(d_n_rows);
+    pp.kmer_counts = static_cast<uint32_t *>(d_kmer_counts);
+    pp.partial_scores = const_cast<float *>(static_cast<const float *>(d_scores));
+    pp.partial_counts = const_cast<uint32_t *>(static_cast<const uint32_t *>(d_counts));
+    const auto &g = p->geo[p->wide_counts ? 1 : 0];
+    pp.lds_wave_bytes = g.lds_wave_bytes;
+    uint64_t blocks = (n + g.waves_per_block - 1) / g.waves_per_block;
+    if (blocks > g.max_blocks) blocks = g.max_blocks;
+    HIP_TRY(epik_amd::launch_finish_reads(pp, p->wide_counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
+                                          g.lds_block_bytes, static_cast<hipStream_t>(stream)));
     return EPIK_AMD_OK;
 }
 

@@ -35,6 +35,10 @@ struct PlaceParams {
     epik_amd_placement *rows;    // [n_reads * keep_at_most]
     uint32_t *n_rows;            // [n_reads]
     uint32_t *kmer_counts;       // [n_reads * keep_at_most] or null
+    // k-mer-space shard: raw per-branch sums, [n_reads][num_branches].  Non-null in
+    // place_reads_kernel = accumulate only (no epilogue); the input of finish_reads_kernel.
+    float *partial_scores;
+    uint32_t *partial_counts;
     uint32_t kmer_size;
     uint32_t alphabet_size;
     uint32_t num_branches;
@@ -53,6 +57,9 @@ hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool wide_c
 hipError_t set_place_reads_lds_limit(DbLayout layout, bool wide_counts, size_t lds_bytes);
 hipError_t place_reads_occupancy(DbLayout layout, bool wide_counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu);
+hipError_t launch_finish_reads(const PlaceParams &p, bool wide_counts, dim3 grid, dim3 block, size_t lds_bytes,
+                               hipStream_t stream);
+hipError_t set_finish_reads_lds_limit(bool wide_counts, size_t lds_bytes);
 hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
                                     hipStream_t stream);
 

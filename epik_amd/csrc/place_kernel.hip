@@ -698,7 +698,14 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         // place.cpp:322 underflows for len < k; we report "no placement" -- also for a read whose
         // k-mers could overflow this kernel's count type (the host then uses the wide kernel)
         if (len < k || len - k + 1 >= (uint64_t)WaveLds<CountT>::kSeen) {
-            if (lane == 0) p.n_rows[read] = 0;
+            if (p.partial_scores) {  // accumulate-only launch: an all-zero partial vector
+                for (uint32_t i = lane; i < p.num_branches; i += kWave) {
+                    p.partial_scores[read * p.num_branches + i] = 0.0f;
+                    p.partial_counts[read * p.num_branches + i] = 0u;
+                }
+            } else if (lane == 0) {
+                p.n_rows[read] = 0;
+            }
             continue;
         }
         const uint64_t n_kmers = len - k + 1;  // :322
@@ -891,6 +898,20 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
             continue;
         }
 #endif
+        if (p.partial_scores) {
+            // Accumulate-only launch (k-mer-space shard of the database): this GPU
+            // holds part of the lists, so the raw per-branch sums and counts leave for HBM, to be
+            // added across GPUs before finish_reads_kernel runs the epilogue on the totals.
+            for (uint32_t i = lane; i < p.n_pad; i += kWave) {
+                const uint2 cv = lds.load(i);
+                if (i < p.num_branches) {
+                    p.partial_scores[read * p.num_branches + i] = __uint_as_float(cv.x);
+                    p.partial_counts[read * p.num_branches + i] = cv.y & ~(uint32_t)WaveLds<CountT>::kSeen;
+                }
+                lds.store(i, 0u, 0u);
+            }
+            continue;
+        }
         // ---- correction, sum_scores, top-k, LWR, rows out, reset of the wave's vectors ----------
         if (lane == 0) lds.store(p.n_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
         place_epilogue<Layout, CountT>(kp, lds, read, n_kmers);
@@ -900,6 +921,41 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
     if (p.dbg && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg[i], dbg_t[i]);
 #endif
+}
+
+// Second half of a k-mer-space-sharded placement: the per-branch sums and counts of every
+// read, already added over the shards, come back from HBM into the wave's LDS vectors and
+// go through the same epilogue (place.cpp:418-422, 134-199, 241-267) as a one-GPU placement.
+template <typename CountT>
+__global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    WaveLds<CountT> lds;
+    {
+        unsigned char *base = lds_raw + (size_t)wave_in_block * p.lds_wave_bytes;
+        lds.score = reinterpret_cast<float *>(base);
+        lds.count = reinterpret_cast<CountT *>(base + (size_t)p.n_pad * 4);
+        lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * (4 + sizeof(CountT)));
+    }
+    const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.store(i, 0u, 0u);
+    const uint32_t k = p.kmer_size;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave_in_block;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    for (uint64_t read = wave_global; read < p.n_reads; read += total_waves) {
+        const uint64_t len = p.seq_offsets[read + 1] - p.seq_offsets[read];
+        if (len < k || len - k + 1 >= (uint64_t)WaveLds<CountT>::kSeen) {
+            if (lane == 0) p.n_rows[read] = 0;
+            continue;
+        }
+        for (uint32_t i = lane; i < p.num_branches; i += kWave)
+            lds.store(i, __float_as_uint(p.partial_scores[read * p.num_branches + i]),
+                      p.partial_counts[read * p.num_branches + i]);
+        place_epilogue<PackedLayout, CountT>(kp, lds, read, len - k + 1);  // also clears the vectors
+    }
 }
 
 // Algorithmic bytes of SURVEY.md 8(d): one thread per read, plain loops.
@@ -1011,6 +1067,24 @@ hipError_t place_reads_occupancy(DbLayout layout, bool wide_counts, int block_th
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, place_reads_kernel<L, C>,
                                                             block_threads, lds_bytes);
     });
+}
+
+hipError_t launch_finish_reads(const PlaceParams &p, bool wide_counts, dim3 grid, dim3 block, size_t lds_bytes,
+                               hipStream_t stream)
+{
+    if (wide_counts)
+        hipLaunchKernelGGL((finish_reads_kernel<uint32_t>), grid, block, lds_bytes, stream, p);
+    else
+        hipLaunchKernelGGL((finish_reads_kernel<uint16_t>), grid, block, lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t set_finish_reads_lds_limit(bool wide_counts, size_t lds_bytes)
+{
+    return wide_counts ? hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_reads_kernel<uint32_t>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                       : hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_reads_kernel<uint16_t>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,

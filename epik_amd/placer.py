@@ -74,7 +74,8 @@ class Placer:
     def __init__(self, offsets: np.ndarray, values: np.ndarray, *, states: str, kmer_size: int,
                  num_branches: int, threshold, log_threshold=None, keep_at_most: int = 7,
                  keep_factor: float = 0.01, device: int = 0, branch_length=None,
-                 subtree_num_nodes=None, subtree_total_length=None, char_class=None):
+                 subtree_num_nodes=None, subtree_total_length=None, char_class=None,
+                 shard_index: int = 0, shard_count: int = 1):
         lib = capi.load()
         sigma = alphabet.alphabet_size(states)
         self.states = states
@@ -106,7 +107,11 @@ class Placer:
             num_entries=num_entries, offsets=off.ctypes.data, values=vals.ctypes.data,
             char_class=cls.ctypes.data, device=self.device, reserved=0)
         handle = ctypes.c_void_p()
-        capi.check(lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(handle)))
+        # shard_count > 1: this placer keeps the posting lists of the codes with
+        # code % shard_count == shard_index (k-mer-space shard, `epik_amd_placer_create_sharded`)
+        self.shard_index, self.shard_count = int(shard_index), int(shard_count)
+        capi.check(lib.epik_amd_placer_create_sharded(ctypes.byref(desc), self.shard_index, self.shard_count,
+                                                      ctypes.byref(handle)))
         self._lib = lib
         self._handle = handle
         if branch_length is not None:
@@ -168,6 +173,21 @@ class Placer:
         capi.check(self._lib.epik_amd_placer_place_device(
             self._handle, d_seqs, d_seq_offsets, int(n), d_rows, d_n_rows, d_kmer_counts or None,
             stream or None))
+
+    def accumulate_device(self, d_seqs: int, d_seq_offsets: int, n: int, d_scores: int, d_counts: int,
+                          stream: int = 0) -> None:
+        """First half of a k-mer-space-sharded placement: raw float32 score sums and k-mer counts of
+        this shard's lists, [n][num_branches] each (`epik_amd_placer_accumulate_device`)."""
+        capi.check(self._lib.epik_amd_placer_accumulate_device(
+            self._handle, d_seqs, d_seq_offsets, int(n), d_scores, d_counts, stream or None))
+
+    def finish_device(self, d_seq_offsets: int, n: int, d_scores: int, d_counts: int, d_rows: int,
+                      d_n_rows: int, d_kmer_counts: int = 0, stream: int = 0) -> None:
+        """Second half: correction, top-k and like-weight-ratio on the sums added over the shards
+        (`epik_amd_placer_finish_device`)."""
+        capi.check(self._lib.epik_amd_placer_finish_device(
+            self._handle, d_seq_offsets, int(n), d_scores, d_counts, d_rows, d_n_rows,
+            d_kmer_counts or None, stream or None))
 
     def algorithmic_bytes(self, d_seqs: int, d_seq_offsets: int, n: int, d_n_rows: int = 0,
                           stream: int = 0) -> int:

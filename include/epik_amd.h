@@ -145,6 +145,35 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
  */
 int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled);
 
+/*
+ * Database larger than one GPU's memory: k-mer-space shard (BASELINE configs[4]).
+ * No reference counterpart -- the reference keeps one database in host RAM (main.cpp:277).
+ *
+ * epik_amd_placer_create_sharded() is create() keeping only the posting lists of the k-mer codes
+ * with code % shard_count == shard_index (the descriptor still describes the whole database;
+ * create() == create_sharded(desc, 0, 1, out)).  Every shard then sees ALL reads of a batch:
+ *
+ *   accumulate_device : per read, the raw float32 score sums and the k-mer counts of this
+ *                       shard's lists, d_scores / d_counts = [n][num_branches] (place.cpp:349-371
+ *                       without 418-422);
+ *   (caller)          : adds d_scores and d_counts over the shards -- a reduce-scatter over the
+ *                       read dimension with RCCL, each GPU keeping the totals of its own reads;
+ *   finish_device     : correction, top-k, like-weight-ratio and filter on the totals
+ *                       (place.cpp:418-422, 134-199, 241-267); rows as epik_amd_placer_place_device.
+ *
+ * With one shard the two calls give exactly the rows of place_device.  With several, a branch's
+ * float32 adds happen in a different order (per shard, then over shards): scores agree to float32
+ * rounding, like-weight-ratios within the 1e-5 bar, and a read's ambiguous k-mers follow the
+ * first-key-scores rule (place.cpp:385-388) inside each shard only.
+ */
+int epik_amd_placer_create_sharded(const epik_amd_placer_desc *desc, uint32_t shard_index,
+                                   uint32_t shard_count, epik_amd_placer **out);
+int epik_amd_placer_accumulate_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
+                                      uint64_t n, void *d_scores, void *d_counts, void *stream);
+int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets, uint64_t n,
+                                  const void *d_scores, const void *d_counts, void *d_rows, void *d_n_rows,
+                                  void *d_kmer_counts, void *stream);
+
 /* Launch geometry actually used (for reports): waves per workgroup, workgroups
  * of the last launch, dynamic LDS bytes per workgroup. */
 int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,

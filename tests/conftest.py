@@ -41,6 +41,10 @@ def mixed_reads(rng, n, k, alphabet_plain="ACGT", alphabet_amb="ACGTNRY-", max_l
 
 @pytest.fixture(scope="session")
 def gpu_available():
+    # torch first: it brings its own HIP runtime, which must initialise before libepik_amd's
+    # (the system one) does, or torch finds "No HIP GPUs" later in this process (bench.py's order)
+    import torch
+    torch.cuda.is_available()
     from epik_amd import capi
     return capi.device_count() > 0
 

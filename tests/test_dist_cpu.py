@@ -45,3 +45,25 @@ def test_gloo_sharded_placement_matches_single_process(world, oracle_lib):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert f"dist ok: world={world}" in out.stdout
+
+
+def test_owner_bounds_are_equal_slices():
+    for n in (0, 1, 7, 203, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [edist.owner_bounds(n, r, world) for r in range(world)]
+            per = -(-n // world) if n else 0
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(b - a <= per for a, b in spans) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_kmer_sharded_placement_matches_oracle(world, oracle_lib):
+    """The exchange step of the k-mer-space shard: all-to-all of the per-read branch vectors +
+    sum in rank order, numpy engine in place of the two kernel halves."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker_kmer.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert f"kmer-shard ok: world={world}" in out.stdout
