@@ -187,6 +187,42 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
             return fail(EPIK_AMD_ERR_INVALID, "offsets[0] != 0 or offsets[num_keys] != num_entries");
     }
 
+    // The lists themselves (host-only checks, before any device is touched): monotone offsets,
+    // lists shorter than 2^24, every branch below num_branches, and -- what the kernel's
+    // lane-parallel read-add-write of a list relies on -- no branch twice in one list
+    // (the reference's lists are built per branch, one score each: main.cpp:257).
+    {
+        const bool o64 = d->offset_bits == 64;
+        auto off = [&](uint64_t key) -> uint64_t {
+            return o64 ? static_cast<const uint64_t *>(d->offsets)[key] : static_cast<const uint32_t *>(d->offsets)[key];
+        };
+        std::vector<uint32_t> seen_in;  // seen_in[b] = 1 + the last list that held branch b
+        try {
+            seen_in.assign(d->num_branches, 0);
+        } catch (const std::bad_alloc &) {
+            return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
+        }
+        uint32_t list_id = 0;
+        for (uint64_t key = 0; key < d->num_keys; ++key) {
+            const uint64_t b = off(key), e = off(key + 1);
+            if (e < b || e > d->num_entries) return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
+            if (e - b >= (1ull << 24)) return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
+            if (e == b) continue;
+            if (++list_id == 0) {  // the list counter wrapped (> 4 G non-empty lists): start a new epoch
+                std::fill(seen_in.begin(), seen_in.end(), 0u);
+                list_id = 1;
+            }
+            for (uint64_t i = b; i < e; ++i) {
+                const uint32_t branch = d->values[i].branch;
+                if (branch >= d->num_branches)
+                    return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
+                if (seen_in[branch] == list_id)
+                    return fail(EPIK_AMD_ERR_INVALID, "a posting list names the same branch twice");
+                seen_in[branch] = list_id;
+            }
+        }
+    }
+
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return fail(EPIK_AMD_ERR_NO_DEVICE, "no HIP device available (libepik_amd has no CPU fallback)");
@@ -207,14 +243,6 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     p->offsets64 = d->offset_bits == 64;
     p->num_keys = d->num_keys;
     p->num_entries = d->num_entries;
-
-    // every posting's branch must index the LDS score vector
-    for (uint64_t i = 0; i < d->num_entries; ++i) {
-        if (d->values[i].branch >= d->num_branches) {
-            delete p;
-            return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
-        }
-    }
 
 
     // LDS rows per wave: the branches + the dummy row that out-of-range lanes of the posting
@@ -252,16 +280,8 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     uint64_t lines = 0;  // packed: 128-byte lines of the posting region
     uint64_t kept_entries = 0;
     for (uint64_t key = 0; key < d->num_keys; ++key) {
-        if (offset_at(key + 1) < offset_at(key)) {
-            epik_amd_placer_destroy(p);
-            return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
-        }
         const uint64_t len = kept_len(key);
         kept_entries += len;
-        if (len >= (1ull << 24)) {
-            epik_amd_placer_destroy(p);
-            return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
-        }
         lines += (len * 6u + 127u) / 128u;
     }
     if (packed && lines >= (1ull << 32)) {

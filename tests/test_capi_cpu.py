@@ -70,6 +70,33 @@ def test_create_rejects_bad_descriptors(small_case, over, code):
     assert lib.epik_amd_last_error()
 
 
+@pytest.mark.parametrize("damage,message", [
+    ("duplicate_branch", b"same branch twice"),
+    ("branch_out_of_range", b"branch >= num_branches"),
+    ("offsets_not_monotone", b"not monotone"),
+])
+def test_create_rejects_bad_lists(small_case, damage, message):
+    """Host-only checks of the posting lists, made before any device is touched (so they run here)."""
+    import numpy as np
+    _, db = small_case
+    lib = capi.load()
+    offsets = np.ascontiguousarray(db.offsets, dtype=np.uint32).copy()
+    values = db.values.copy()
+    key = int(np.nonzero(np.diff(offsets.astype(np.int64)) >= 2)[0][1])   # a list of two postings or more, not the first
+    b = int(offsets[key])
+    if damage == "duplicate_branch":
+        values["branch"][b + 1] = values["branch"][b]
+    elif damage == "branch_out_of_range":
+        values["branch"][b] = db.num_branches
+    else:
+        offsets[key + 1] = offsets[key] - 1   # this list would end before it begins
+    desc, keep = _desc(db, offsets=offsets.ctypes.data, values=values.ctypes.data)
+    handle = ctypes.c_void_p()
+    rc = lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(handle))
+    assert rc == capi.ERR_INVALID and not handle.value
+    assert message in lib.epik_amd_last_error(), lib.epik_amd_last_error()
+
+
 def test_no_gpu_means_loud_failure_not_cpu_fallback(small_case):
     if capi.device_count() > 0:
         pytest.skip("a GPU is present")
