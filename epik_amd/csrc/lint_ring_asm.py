@@ -53,10 +53,9 @@ def lint_loop(name, body, events, problems):
         return
     # From the loop's first asm statement to a margin behind its last asm load (the
     # fall-through into the tail, which still runs before the drain).  Walk it in program
-    # order with a per-register state: a slot register is IN FLIGHT from its asm load until
-    # the asm wait that names it (`s_waitcnt vmcnt(N) ; slot vA vB`); from that wait to the
-    # refill the compiler may read it (the consume) or reuse it.  The loop is cyclic, so at
-    # its top every slot counts as in flight.
+    # order with a per-register state: a slot register is IN FLIGHT from its asm load until an
+    # asm vector instruction reads it (behind the stage's asm wait); from there to the refill
+    # the compiler may reuse it.  The loop is cyclic, so at its top every slot counts as in flight.
     lo, hi = max(0, min(waits[0], loads[0]) - 1), loads[-1] + 15  # -1: the ;;#ASMSTART line
     inflight = set(ring)
     in_asm = False

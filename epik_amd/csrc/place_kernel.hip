@@ -173,7 +173,6 @@ template <typename OffT>
 struct CompactLayout {
     static constexpr int kLoads = 1;  // vector-memory instructions per chunk
     static constexpr uint32_t kChunkBytes = 64u * 8u;
-    static constexpr uint32_t kLaneStep = 8;
     static constexpr int kFields = 3;  // base lo, base hi, bytes
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
                                                   uint32_t &len)
@@ -813,11 +812,10 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                 // issued from inline asm (Layout::issue): hipcc must not count them, or it would
                 // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
                 // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that
-                // point and loads retire in issue order --, turns the cell into its two LDS
-                // addresses and moves the score out of the slot register inside that same asm
-                // statement, and refills the slot with the next chunk.
-                // (Letting hipcc read the slot registers itself, even behind a "+v" wait, is not
-                // safe: it is free to copy them into other registers AHEAD of the wait.)
+                // point and loads retire in issue order --, consumes the slot's two registers
+                // inside asm statements only, and refills the slot with the next chunk.
+                // (Letting hipcc read a slot register itself, even behind a "+v" wait, is not
+                // safe: it is free to copy it into another register AHEAD of the wait.)
                 uint32_t ring_c[kRing], ring_s[kRing];
 #pragma unroll
                 for (int i = 0; i < kRing; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
