@@ -188,7 +188,7 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     }
 
     // The lists themselves (host-only checks, before any device is touched): monotone offsets,
-    // lists shorter than 2^24, every branch below num_branches, and -- what the kernel's
+    // lists shorter than 2^24, every branch below num_branches, finite scores, and -- what the kernel's
     // lane-parallel read-add-write of a list relies on -- no branch twice in one list
     // (the reference's lists are built per branch, one score each: main.cpp:257).
     {
@@ -216,6 +216,8 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
                 const uint32_t branch = d->values[i].branch;
                 if (branch >= d->num_branches)
                     return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
+                if (!std::isfinite(d->values[i].score))  // the kernel marks "no edge" with -inf
+                    return fail(EPIK_AMD_ERR_INVALID, "posting with a non-finite score");
                 if (seen_in[branch] == list_id)
                     return fail(EPIK_AMD_ERR_INVALID, "a posting list names the same branch twice");
                 seen_in[branch] = list_id;

@@ -407,7 +407,8 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const float k_f = (float)p.kmer_size;
     const float log_thr = p.log_threshold;
     // ---- score correction (:418-422), dense over N --------------------------------------
-    // cell[i].x becomes the corrected score (-inf = "not an edge"), cell[i].y the count.
+    // score[i] becomes the corrected score (-inf = "not an edge"); count[i] keeps the count
+    // (and the ambiguous path's flag bit).
     const float nk_f = (float)n_kmers;
     const uint32_t nk_u = (uint32_t)n_kmers;  // the host rejects reads of 2^32 characters or more
     const float inv_k = __fdiv_rn(1.0f, k_f);
@@ -452,7 +453,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             const float sc = c ? s[u] : -INFINITY;  // -inf = "not an edge"
             touched += c ? 1u : 0u;
             lane_best_f = fmaxf(lane_best_f, sc);
-            lds.store(base + (uint32_t)u * kWave + (uint32_t)lane, __float_as_uint(sc), c);
+            lds.score[base + (uint32_t)u * kWave + (uint32_t)lane] = sc;  // the count cell stays as it is
         }
     }
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
@@ -504,14 +505,14 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         n_cand = 0;
         const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
         for (uint32_t base = 0; base < n_rows_pad; base += kUnroll * kWave) {
-            uint2 cv[kUnroll];
+            float row[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
+            for (int u = 0; u < kUnroll; ++u) row[u] = lds.score[base + (uint32_t)u * kWave + (uint32_t)lane];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
-                const float sc = __uint_as_float(cv[u].x);  // -inf where there is no edge
-                const bool edge = cv[u].y != 0;
+                const float sc = row[u];             // -inf where there is no edge (a sum of finite
+                const bool edge = sc != -INFINITY;   // log10 scores never is)
                 // exp2(-inf) = 0: rows without an edge add nothing
                 rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
                 const bool is_cand = edge && sc >= tau_f;
@@ -546,44 +547,15 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             ranked_in_place = true;
         }
     }
-    double score_sum, ref_power = 0.0;
-    {
-        const float not_placed = (float)N - (float)touched;  // :174
-        if (relative_sum) {
-            double rel = wave_sum_f64((double)rel_sum);
-            if (not_placed != 0.0f)
-                rel += (double)(not_placed *
-                                __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
-            ref_power = pow10_f64((double)ref_score);
-            score_sum = ref_power * rel;
-        } else {
-            // everything in double, term by term, as place.cpp:174-183
-            double sum_placed = 0.0;
-            for (uint32_t i = lane; i < N; i += kWave) {
-                const uint2 cv = lds.load(i);
-                if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
-            }
-            sum_placed = wave_sum_f64(sum_placed);
-            score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
-        }
-    }
-    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
-
-    // ---- rank, LWR (:241-264), filter_by_ratio (:188-199); <= 3 candidates per lane ------
-    const double best_power = (relative_sum && ref_score == best_score) ? ref_power : pow10_f64((double)best_score);
-    const double best_ratio =
-        (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
-    const double ratio_threshold = best_ratio * keep_factor;                      // :192
+    // ---- rank: <= 3 candidates per lane, rank = number of candidates with a larger key --------
     const uint32_t n_q = (n_cand + kWave - 1) / kWave;
     uint64_t my_key[kTilesPerPass];
     uint32_t my_rank[kTilesPerPass];
-    double my_lwr[kTilesPerPass];
 #pragma unroll
     for (int q = 0; q < kTilesPerPass; ++q) {
         const uint32_t idx = (uint32_t)q * kWave + (uint32_t)lane;
         my_key[q] = 0;
         my_rank[q] = ranked_in_place ? idx : 0u;
-        my_lwr[q] = 0.0;
         if ((uint32_t)q < n_q && idx < n_cand) {
             const uint2 c = cand[idx];
             my_key[q] = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
@@ -608,16 +580,59 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             }
         }
     }
+    // ---- 10^score of every row that will be reported (:254), the lanes side by side.  The row of
+    // rank 0 carries best_score: its power is rows[0]'s (:191) and, whenever best_score is the
+    // reference point of the relative sum, 10^ref_score as well -- one exp10 instead of three.
+    double my_power[kTilesPerPass];
+    double best_power = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTilesPerPass; ++q) {
+        my_power[q] = 0.0;
+        if ((uint32_t)q < n_q) {
+            const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
+            if (has_row) my_power[q] = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));
+            const uint64_t first = __ballot(has_row && my_rank[q] == 0);
+            if (first)
+                best_power = __longlong_as_double(
+                    (long long)readlane_u64((uint64_t)__double_as_longlong(my_power[q]), __builtin_ctzll(first)));
+        }
+    }
+    double score_sum;
+    {
+        const float not_placed = (float)N - (float)touched;  // :174
+        if (relative_sum) {
+            double rel = wave_sum_f64((double)rel_sum);
+            if (not_placed != 0.0f)
+                rel += (double)(not_placed *
+                                __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
+            const double ref_power = (ref_score == best_score) ? best_power : pow10_f64((double)ref_score);
+            score_sum = ref_power * rel;
+        } else {
+            // everything in double, term by term, as place.cpp:174-183
+            double sum_placed = 0.0;
+            for (uint32_t i = lane; i < N; i += kWave) {
+                const uint2 cv = lds.load(i);
+                if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
+            }
+            sum_placed = wave_sum_f64(sum_placed);
+            score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
+        }
+    }
+    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
+
+    // ---- LWR (:241-264), filter_by_ratio (:188-199) ---------------------------------------------
+    const double best_ratio =
+        (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
+    const double ratio_threshold = best_ratio * keep_factor;                      // :192
+    double my_lwr[kTilesPerPass];
     uint64_t kept_ranks = 0;  // bit r set <=> the row of rank r passes the filter
 #pragma unroll
     for (int q = 0; q < kTilesPerPass; ++q) {
+        my_lwr[q] = 0.0;
         if ((uint32_t)q < n_q) {
             const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-            if (has_row && score_sum != 0.0) {
-                const double power = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));  // :254
-                my_lwr[q] = (power == 0.0) ? 0.0 : power / score_sum;                             // :255-262
-            }
-            if (has_row && my_lwr[q] >= ratio_threshold) kept_ranks |= 1ull << my_rank[q];      // :197
+            if (has_row && score_sum != 0.0 && my_power[q] != 0.0) my_lwr[q] = my_power[q] / score_sum;  // :255-262
+            if (has_row && my_lwr[q] >= ratio_threshold) kept_ranks |= 1ull << my_rank[q];            // :197
         }
     }
     kept_ranks = wave_or_u64(kept_ranks);
@@ -634,7 +649,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
                 out.lwr = my_lwr[q];
                 p.rows[read * keep + slot] = out;
                 if (p.kmer_counts)
-                    p.kmer_counts[read * keep + slot] = (touched && branch < N) ? (uint32_t)lds.count[branch] : 0u;
+                    p.kmer_counts[read * keep + slot] = (touched && branch < N) ? ((uint32_t)lds.count[branch] & ~(uint32_t)lds.kSeen) : 0u;
             }
         }
     }

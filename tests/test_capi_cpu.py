@@ -73,6 +73,7 @@ def test_create_rejects_bad_descriptors(small_case, over, code):
 @pytest.mark.parametrize("damage,message", [
     ("duplicate_branch", b"same branch twice"),
     ("branch_out_of_range", b"branch >= num_branches"),
+    ("infinite_score", b"non-finite score"),
     ("offsets_not_monotone", b"not monotone"),
 ])
 def test_create_rejects_bad_lists(small_case, damage, message):
@@ -88,6 +89,8 @@ def test_create_rejects_bad_lists(small_case, damage, message):
         values["branch"][b + 1] = values["branch"][b]
     elif damage == "branch_out_of_range":
         values["branch"][b] = db.num_branches
+    elif damage == "infinite_score":
+        values["score"][b] = -np.inf
     else:
         offsets[key + 1] = offsets[key] - 1   # this list would end before it begins
     desc, keep = _desc(db, offsets=offsets.ctypes.data, values=values.ctypes.data)
