@@ -9,8 +9,10 @@ the tolerance of the `keep_factor` cut may be present in one file only.
 
 `--legacy` reproduces what the reference's scripts/jplace_diff.py measures (that script's
 CLI is broken: its option is --only-best but its parameter is only_first): per name, the
-two placements match if their sets of 10**likelihood agree within 1e-4, else if their
-sets of edges are equal; like_weight_ratio is not looked at (jplace_diff.py:21, 197-225).
+two placements match if their sets of likelihood values agree within 1e-4, else if every edge
+of either file is in both with |10**l1 - 10**l2| <= 1e-4; like_weight_ratio is not looked at
+(jplace_diff.py:21, 197-225).  tests/test_host_cpu.py checks this mode against the reference's
+own function wherever /root/reference is present.
 """
 from __future__ import annotations
 
@@ -58,19 +60,28 @@ def diff_strict(a: dict, b: dict, lwr_tol: float = LWR_TOL, keep_factor: float =
 
 
 def diff_legacy(a: dict, b: dict, only_best: bool = False):
-    """Semantics of the reference's scripts/jplace_diff.py; returns names that do not match."""
+    """Semantics of the reference's scripts/jplace_diff.py (:160-172, :187-231); returns the names of
+    the first file that do not match.  Per name: with `only_best`, the first rows' edges must agree
+    (two empty lists match); otherwise the two SETS of likelihood values agreeing pairwise within
+    1e-4 is a match whatever edges carry them (:201-208), else every edge of the union must be in both
+    files with |10^l1 - 10^l2| <= 1e-4 (:212-226).  like_weight_ratio is never looked at."""
     mismatches = []
-    for name in sorted(set(a) & set(b)):
-        ra, rb = a[name], b[name]
+    for name in a:
+        ra, rb = a[name], b[name]   # a name missing from the second file is a KeyError there too (:190)
         if only_best:
-            ra, rb = ra[:1], rb[:1]
-        la = sorted(10 ** r["likelihood"] for r in ra)
-        lb = sorted(10 ** r["likelihood"] for r in rb)
-        if len(la) == len(lb) and all(abs(x - y) < LEGACY_EPS for x, y in zip(la, lb)):
+            if len(ra) == len(rb) == 0:
+                continue
+            if not ra or not rb or ra[0]["edge_num"] != rb[0]["edge_num"]:
+                mismatches.append(name)
             continue
-        if {r["edge_num"] for r in ra} == {r["edge_num"] for r in rb}:
+        la = sorted({r["likelihood"] for r in ra})
+        lb = sorted({r["likelihood"] for r in rb})
+        if len(la) == len(lb) and all(abs(x - y) <= LEGACY_EPS for x, y in zip(la, lb)):
             continue
-        mismatches.append(name)
+        ea = {r["edge_num"]: r["likelihood"] for r in ra}
+        eb = {r["edge_num"]: r["likelihood"] for r in rb}
+        if any(e not in ea or e not in eb or abs(10 ** ea[e] - 10 ** eb[e]) > LEGACY_EPS for e in set(ea) | set(eb)):
+            mismatches.append(name)
     return mismatches
 
 

@@ -117,7 +117,63 @@ def test_jplace_write_read_and_diff(tmp_path):
                    dict(edge_num=2, likelihood=-2.0, like_weight_ratio=0.5)]}
     tie_b = {"x": tie_a["x"][::-1]}
     assert jplace_diff.diff_strict(tie_a, tie_b) == []
-    # legacy semantics: same edge set counts as a match even with different likelihoods
+    # legacy semantics (the reference's script): LWR is ignored, likelihoods are compared
     leg = json.loads(json.dumps(parsed))
-    leg["q1"][0]["likelihood"] = -1.0
+    leg["q1"][0]["like_weight_ratio"] = 0.123
     assert jplace_diff.diff_legacy(parsed, leg) == []
+    leg["q1"][0]["likelihood"] = -1.0
+    assert "q1" in jplace_diff.diff_legacy(parsed, leg)
+
+
+REFERENCE_DIFFER = "/root/reference/scripts/jplace_diff.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_DIFFER), reason="the reference is not present on this machine")
+def test_legacy_differ_agrees_with_the_reference_script(tmp_path, capsys):
+    """`--legacy` against the reference's own comparison function (its CLI wrapper is broken, the
+    function behind it is callable), on jplace pairs with every kind of disagreement."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_jplace_diff", REFERENCE_DIFFER)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(7)
+    names = [f"s{i}" for i in range(60)]
+
+    def rows(n):
+        edges = rng.choice(40, size=n, replace=False)
+        return [dict(edge_num=int(e), likelihood=float(-rng.uniform(0.5, 6.0)), like_weight_ratio=float(rng.random()),
+                     distal_length=0.1, pendant_length=0.2) for e in edges]
+
+    first = {name: rows(int(rng.integers(0, 6))) for name in names}
+    second = json.loads(json.dumps(first))
+    for i, name in enumerate(names):
+        r = second[name]
+        kind = i % 6
+        if kind == 1 and r:
+            r[0]["likelihood"] += 5e-5           # inside the 1e-4 window
+        elif kind == 2 and r:
+            r[0]["likelihood"] -= 0.5            # outside: compared edge by edge on 10**likelihood
+        elif kind == 3 and r:
+            r[0]["edge_num"] = 99                # another edge with the same likelihood: still a "match" there
+        elif kind == 4 and r:
+            r.pop()                              # a row missing
+        elif kind == 5:
+            r.append(dict(edge_num=77, likelihood=-9.0, like_weight_ratio=0.0, distal_length=0.0, pendant_length=0.0))
+
+    def write(path, placed):
+        doc = {"fields": jplace.FIELDS, "version": 3, "tree": "(A:1{0},B:2{1}):0{2};", "metadata": {},
+               "placements": [{"p": [[r[f] for f in jplace.FIELDS] for r in rws], "nm": [[name, 1]]}
+                              for name, rws in placed.items()]}
+        with open(path, "w") as fh:
+            json.dump(doc, fh)
+
+    a, b = str(tmp_path / "a.jplace"), str(tmp_path / "b.jplace")
+    write(a, first)
+    write(b, second)
+    for only_best in (False, True):
+        capsys.readouterr()
+        ref.jplace_diff.callback(a, b, only_best)
+        out = capsys.readouterr().out
+        matched = int(out.strip().splitlines()[-1].split("/")[0])
+        ours = jplace_diff.diff_legacy(jplace.read_jplace(a), jplace.read_jplace(b), only_best)
+        assert matched == len(names) - len(ours), (only_best, matched, ours)
