@@ -63,6 +63,27 @@ def test_launcher_builds_reference_argv():
         assert flag in out.stdout
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/epik.py"), reason="the reference is not present on this machine")
+@pytest.mark.parametrize("states,max_ram", [("nucl", None), ("amino", "4G")])
+def test_launcher_argv_equals_the_reference_launcher(monkeypatch, capsys, states, max_ram):
+    """The reference's own `place_queries` (epik.py:73-98) with subprocess.call intercepted,
+    beside ours: same flags, same order, same values; ours only picks its own binary."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_epik", "/root/reference/epik.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    seen = []
+    monkeypatch.setattr(ref.subprocess, "call", lambda command: seen.append(list(command)) or 0)
+    ref.place_queries("db.ipk", states, 1.5, 0.8, "out", 3, max_ram, "q.fasta")
+    capsys.readouterr()
+    sys.path.insert(0, ROOT)
+    import epik
+    ours = epik.driver_command(database="db.ipk", states=states, omega=1.5, mu=0.8, outputdir="out", threads=3,
+                               max_ram=max_ram, gpus=1, input_file="q.fasta")   # one GPU: no extra flag
+    assert os.path.basename(ours[0]) == os.path.basename(seen[0][0])      # epik-dna / epik-aa
+    assert ours[1:] == seen[0][1:]
+
+
 def test_dbfile_roundtrip_and_filters(tmp_path):
     tree = synth.make_tree(8, seed=1)
     db = synth.make_db(tree.num_nodes, kmer_size=4, p_present=0.7, seed=5, lognormal=(1.0, 1.0))
