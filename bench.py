@@ -135,8 +135,14 @@ def main():
 
     if not torch.cuda.is_available() or capi.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: epik_amd has no CPU fallback")
+    # Rehearsal of the N>1 path on a one-GPU box (EPIK_AMD_BENCH_REHEARSAL=1): every rank uses
+    # device 0 and the ranks meet over gloo, since RCCL wants one device per rank.  Its numbers
+    # mean nothing; it exists so that the multi-rank code path can be run before the driver does.
+    rehearsal = os.environ.get("EPIK_AMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = edist.init_process_group("nccl")  # RCCL; None when WORLD_SIZE == 1
+    dist = edist.init_process_group("gloo" if rehearsal else "nccl")  # nccl = RCCL; None when WORLD_SIZE == 1
 
     # ---- synthetic workload, identical DB on every rank ---------------
     tree = synth.make_tree(args.leaves, seed=42)
@@ -216,7 +222,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = edist.max_over_ranks(elapsed, dist, device=dev)
+    elapsed = edist.max_over_ranks(elapsed, dist, device=None if rehearsal else dev)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
 
     if rank == 0:
