@@ -1,0 +1,62 @@
+"""BASELINE configs[1] at its full size (N=999, k=10, 1 M x 150 bp reads, the bench.py workload):
+too many reads for the oracle, so the whole batch goes through size-independent properties and a
+random sample of it through the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import assert_rows_match
+from epik_amd import synth
+
+pytestmark = pytest.mark.gpu
+N_READS = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def full_case(gpu_available):
+    assert gpu_available, "pytest -m gpu needs a HIP device (no CPU fallback exists)"
+    from epik_amd.placer import Placer
+    tree = synth.make_tree(500, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
+    data, offs = synth.make_reads(N_READS, 150, seed=44)
+    with Placer.from_synth(db) as pl:
+        first = pl.place_packed(data, offs)
+        again = pl.place_packed(data, offs)
+        # the same reads in another order: every read is placed on its own, nothing of a wave's
+        # previous read may leak into the next one (the LDS vectors are reset per read)
+        perm = np.random.default_rng(5).permutation(N_READS)
+        shuffled = pl.place_packed(data.reshape(N_READS, 150)[perm].reshape(-1), offs)
+    return db, data, offs, first, again, perm, shuffled
+
+
+def test_rows_are_well_formed(full_case):
+    db, _, _, (rows, n_rows, counts), *_ = full_case
+    keep = rows.shape[1]
+    assert n_rows.min() >= 1 and n_rows.max() <= keep
+    valid = np.arange(keep)[None, :] < n_rows[:, None]
+    assert rows["branch"][valid].max() < db.num_branches
+    score = np.where(valid, rows["score"], -np.inf)
+    assert (np.diff(score, axis=1) <= 0).all(), "scores must be sorted in descending order"
+    lwr = np.where(valid, rows["lwr"], 0.0)
+    assert (lwr >= 0).all() and (lwr.sum(axis=1) <= 1.0 + 1e-9).all()
+    assert (lwr[:, :1] >= lwr).all(), "the best row carries the largest like_weight_ratio"
+    assert (lwr[valid] >= 0.01 * np.repeat(lwr[:, 0], n_rows) - 1e-15).all(), "filter_by_ratio (place.cpp:188-199)"
+    assert (counts[valid] <= 141).all() and (counts[valid] >= 0).all()
+    # equal like_weight_ratio <=> equal score inside a read (both are monotone in the score)
+    same_score = (np.diff(score, axis=1) == 0) & valid[:, 1:]
+    assert (np.diff(lwr, axis=1)[same_score] == 0).all()
+
+
+def test_idempotent_and_order_independent(full_case):
+    _, _, _, first, again, perm, shuffled = full_case
+    for a, b in zip(first, again):
+        assert a.tobytes() == b.tobytes(), "two runs over the same batch differ"
+    for a, b in zip(first, shuffled):
+        assert a[perm].tobytes() == b.tobytes(), "a read's rows depend on its position in the batch"
+
+
+def test_random_sample_matches_the_oracle(full_case, oracle_lib):
+    db, data, offs, (rows, n_rows, counts), *_ = full_case
+    pick = np.sort(np.random.default_rng(9).choice(N_READS, size=4000, replace=False))
+    sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
+    ref = oracle_lib.Oracle.from_synth(db).place(sample, sample_offs, num_threads=0)
+    assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
