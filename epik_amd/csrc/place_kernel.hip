@@ -294,10 +294,21 @@ __device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uin
     t.cls = cls;
     t.inv_mask = __ballot(cls == 0 && pos < len);  // characters past the end belong to no window
     t.amb_mask = __ballot(multi);
-    uint32_t key = state;
-    for (uint32_t j = 1; j < k; ++j) {
-        const uint32_t nxt = (uint32_t)__shfl((int)state, lane + (int)j);
-        key = key * sigma + nxt;
+    // Window code of the k characters from this lane on: the states of the next lanes come down
+    // one lane per step with a whole-wave DPP shift (wave_shl:1, lane i <- lane i+1, 0 behind lane
+    // 63) -- a few cycles per step, where an LDS shuffle per step costs a round trip each.
+    uint32_t key = state, next = state;
+    const uint32_t steps = __builtin_amdgcn_readfirstlane(k) - 1u;
+    if (sigma == 4u) {  // wave-uniform
+        for (uint32_t j = 0; j < steps; ++j) {
+            next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
+            key = (key << 2) | next;
+        }
+    } else {
+        for (uint32_t j = 0; j < steps; ++j) {
+            next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
+            key = key * sigma + next;
+        }
     }
     t.key = key;
     t.in_range = ((uint32_t)lane < stride) && (pos < n_kmers);
