@@ -277,18 +277,27 @@ struct Tile {
     bool in_range;      // this lane starts a window of the read (p < n_kmers, lane < tile stride)
 };
 
-// i2l::to_kmers<one_ambiguity_policy> for one tile (place.cpp:294): each lane
-// classifies one character; the window code is gathered from the next k-1 lanes.
-__device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uint64_t len,
-                                            uint64_t tile_pos, uint64_t n_kmers, uint32_t k,
-                                            uint32_t sigma, uint32_t stride,
-                                            const uint32_t *__restrict__ char_class)
+// i2l::to_kmers<one_ambiguity_policy> for one tile (place.cpp:294) in three steps, so that a
+// pass can issue the loads of all its tiles together: the character of this lane (branch-free:
+// positions past the end re-read the last character and are masked later), its class through
+// the 256-entry table, and the window code gathered from the next k-1 lanes.
+__device__ __forceinline__ uint32_t tile_char(const uint8_t *__restrict__ seq, uint64_t len, uint64_t tile_pos)
+{
+    const uint64_t pos = tile_pos + (uint64_t)lane_id();
+    return seq[pos < len ? pos : len - 1];  // len >= k >= 1
+}
+__device__ __forceinline__ uint32_t tile_class(uint32_t ch, uint64_t len, uint64_t tile_pos,
+                                               const uint32_t *__restrict__ char_class)
+{
+    const uint32_t cls = char_class[ch];
+    return tile_pos + (uint64_t)lane_id() < len ? cls : 0u;  // past the end: no character
+}
+__device__ __forceinline__ Tile tile_from_class(uint32_t cls, uint64_t len, uint64_t tile_pos, uint64_t n_kmers,
+                                                uint32_t k, uint32_t sigma, uint32_t stride)
 {
     Tile t;
     const int lane = lane_id();
     const uint64_t pos = tile_pos + (uint64_t)lane;
-    uint32_t cls = 0;
-    if (pos < len) cls = char_class[seq[pos]];
     const bool multi = (cls & (cls - 1)) != 0;
     const uint32_t state = (cls && !multi) ? (uint32_t)(__ffs((int)cls) - 1) : 0u;
     t.cls = cls;
@@ -313,6 +322,14 @@ __device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uin
     t.key = key;
     t.in_range = ((uint32_t)lane < stride) && (pos < n_kmers);
     return t;
+}
+__device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uint64_t len,
+                                            uint64_t tile_pos, uint64_t n_kmers, uint32_t k,
+                                            uint32_t sigma, uint32_t stride,
+                                            const uint32_t *__restrict__ char_class)
+{
+    const uint32_t cls = tile_class(tile_char(seq, len, tile_pos), len, tile_pos, char_class);
+    return tile_from_class(cls, len, tile_pos, n_kmers, k, sigma, stride);
 }
 
 // Wave-private LDS: score[b] = _scores[thread][b] (float32), count[b] = _counts[thread][b]
@@ -744,13 +761,20 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         for (uint64_t pass_pos = 0; pass_pos < n_kmers; pass_pos += (uint64_t)kTilesPerPass * stride) {
             uint64_t start[kTilesPerPass];
             uint32_t llen[kTilesPerPass];
+            // the characters of all tiles, then their classes: two round trips per pass, not two per tile
+            uint32_t tile_cls[kTilesPerPass];
+#pragma unroll
+            for (int t = 0; t < kTilesPerPass; ++t) tile_cls[t] = tile_char(seq, len, pass_pos + (uint64_t)t * stride);
+#pragma unroll
+            for (int t = 0; t < kTilesPerPass; ++t)
+                tile_cls[t] = tile_class(tile_cls[t], len, pass_pos + (uint64_t)t * stride, p.char_class);
 #pragma unroll
             for (int t = 0; t < kTilesPerPass; ++t) {
                 start[t] = 0;
                 llen[t] = 0;
                 const uint64_t tile_pos = pass_pos + (uint64_t)t * stride;
                 if (tile_pos < n_kmers) {  // wave-uniform
-                    const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
+                    const Tile tl = tile_from_class(tile_cls[t], len, tile_pos, n_kmers, k, sigma, stride);
                     bool exact = tl.in_range;
                     if ((tl.inv_mask | tl.amb_mask) != 0) {  // wave-uniform, cold
                         const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
