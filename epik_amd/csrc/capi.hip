@@ -258,19 +258,23 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     }
 
     // ---- choose the HBM layout ---------------------------------------------------------
-    //  packed  (default): an 8-byte {len, line} entry per k-mer code + every list on 128-byte
-    //          lines of its own: measured the fastest;
+    //  packed : an 8-byte {len, line} entry per k-mer code + every list on 128-byte lines of its own;
+    //  paired : the same lists behind a table keyed by the (k-1)-mer that two consecutive k-mers of
+    //           a read share: one table line per two lookups, 16 bytes per code; 4-letter alphabets
+    //           only (place_kernel.hip: PackedLayout<true>) -- the default for them;
     //  compact: the CSR (4- or 8-byte offsets), 8-byte postings back to back.
-    // packed is chosen when its table is at
-    // most a quarter of the device's free memory; EPIK_AMD_LAYOUT=compact|packed overrides.
+    // paired / packed are chosen when the table is at most a quarter of the device's free memory;
+    // EPIK_AMD_LAYOUT=compact|packed|paired overrides (paired falls back to packed for other alphabets).
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
     const char *lay = std::getenv("EPIK_AMD_LAYOUT");
-    if (lay && std::strcmp(lay, "compact") != 0 && std::strcmp(lay, "packed") != 0) {
+    if (lay && std::strcmp(lay, "compact") != 0 && std::strcmp(lay, "packed") != 0 && std::strcmp(lay, "paired") != 0) {
         epik_amd_placer_destroy(p);
-        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact or packed");
+        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed or paired");
     }
-    const bool packed = lay ? std::strcmp(lay, "packed") == 0 : d->num_keys * 8u <= free_mem / 4;
+    const bool can_pair = d->alphabet_size == 4;
+    const bool paired = can_pair && (lay ? std::strcmp(lay, "paired") == 0 : d->num_keys * 16u <= free_mem / 4);
+    const bool packed = paired || (lay ? std::strcmp(lay, "compact") != 0 : d->num_keys * 8u <= free_mem / 4);
     auto offset_at = [&](uint64_t key) -> uint64_t {
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
                             : static_cast<const uint32_t *>(d->offsets)[key];
@@ -297,7 +301,7 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
         std::vector<uint32_t> table;  // packed: {len, line} per code
         try {
             host.assign(p->db_bytes, 0);
-            if (packed) table.assign(d->num_keys * 2, 0);
+            if (packed) table.assign(d->num_keys * (paired ? 4 : 2), 0);
         } catch (const std::bad_alloc &) {
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the device database");
@@ -316,12 +320,22 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
             }
         };
         if (packed) {
-            p->layout = epik_amd::DbLayout::kPacked;
+            p->layout = paired ? epik_amd::DbLayout::kPaired : epik_amd::DbLayout::kPacked;
+            // paired: the entry of code c = a.X = Y.b (X its last k-1 letters, Y its first k-1) is stored
+            // in block X at slot a and in block Y at slot 4 + b; a block is 8 entries
+            const uint32_t shift = 2u * d->kmer_size - 2u;
             uint64_t line = 0;
             for (uint64_t key = 0; key < d->num_keys; ++key) {
                 const uint64_t b = offset_at(key), len = kept_len(key);
-                table[2 * key] = (uint32_t)len;
-                table[2 * key + 1] = (uint32_t)line;
+                if (paired) {
+                    const uint64_t as_suffix = ((key & ((1ull << shift) - 1ull)) * 8u + (key >> shift)) * 2u;
+                    const uint64_t as_prefix = ((key >> 2) * 8u + 4u + (key & 3u)) * 2u;
+                    table[as_suffix] = table[as_prefix] = (uint32_t)len;
+                    table[as_suffix + 1] = table[as_prefix + 1] = (uint32_t)line;
+                } else {
+                    table[2 * key] = (uint32_t)len;
+                    table[2 * key + 1] = (uint32_t)line;
+                }
                 write_list(host.data() + line * 128u, d->values + b, len);
                 line += (len * 6u + 127u) / 128u;
             }

@@ -21,12 +21,15 @@ enum class DbLayout : int {
     kCompact64 = 1,  // same with 64-bit offsets
     kPacked = 2,     // 8-byte {len, first 128-byte line} entry per k-mer code, lists on whole lines,
                      // 6 bytes per posting: f32 score[cnt] then u16 cell[cnt] per chunk of <= 64
+    kPaired = 3,     // the same lists; the table keyed by the (k-1)-mer two consecutive k-mers share
+                     // (4-letter alphabets): one table line per two lookups, 16 bytes per code
 };
 
 // Kernel arguments: the database in HBM, the placer constants of place.cpp:83-96, and
 // one batch of reads.
 struct PlaceParams {
-    const void *table;           // compact: OffT offsets[num_keys + 1]; packed: uint2 {len, line}[num_keys]
+    const void *table;           // compact: OffT offsets[num_keys + 1]; packed: uint2 {len, line}[num_keys];
+                                 // paired: uint2 {len, line}[num_keys / 4][8]
     const uint8_t *postings;     // scores + cells, cell = n_pad - 1 - branch
     const uint32_t *char_class;  // [256]
     const uint8_t *seqs;

@@ -174,8 +174,8 @@ struct CompactLayout {
     static constexpr int kLoads = 1;  // vector-memory instructions per chunk
     static constexpr uint32_t kChunkBytes = 64u * 8u;
     static constexpr int kFields = 3;  // base lo, base hi, bytes
-    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
-                                                  uint32_t &len)
+    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t /*position*/,
+                                                  uint64_t &addr, uint32_t &len)
     {
         const OffT *__restrict__ offsets = static_cast<const OffT *>(p.table);
         const OffT b = offsets[key];
@@ -213,17 +213,35 @@ struct CompactLayout {
 };
 
 // Packed (default): a direct-index table of 8-byte entries {u32 len, u32 line} per k-mer
-// code (16 codes per 128-byte L2 line) and every list on whole 128-byte lines of its own.
-// A list is stored chunk by chunk (<= 64 postings): f32 score[cnt] then u16 cell[cnt] --
-// 6 bytes per posting, a full chunk is exactly three lines, no line is shared between lists.
+// code and every list on whole 128-byte lines of its own.  A list is stored chunk by chunk
+// (<= 64 postings): f32 score[cnt] then u16 cell[cnt] -- 6 bytes per posting, a full chunk is
+// exactly three lines, no line is shared between lists.
+//
+// A random 8-byte lookup costs a whole 128-byte line of fabric traffic (tools/probe_sector.hip),
+// a third of what a read fetches.  kPaired (4-letter alphabets) halves the number of lines:
+// the table is keyed by the (k-1)-mer X that two CONSECUTIVE k-mers of a read share -- a.X and
+// X.b -- and block X holds the entries of all eight k-mers that have X as their suffix (slots
+// 0..3, by first letter a) or as their prefix (slots 4..7, by last letter b).  Every k-mer is
+// therefore stored twice; the k-mer at an even position of the read is looked up as a.X in
+// the block of its suffix, the next one as X.b in the block of its prefix -- the same block,
+// the same line, one fetch for the two lanes.  16 bytes of table per code instead of 8.
+template <bool kPaired>
 struct PackedLayout {
     static constexpr int kLoads = 2;
     static constexpr uint32_t kChunkBytes = 64u * 6u;
     static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk
-    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr,
-                                                  uint32_t &len)
+    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t position,
+                                                  uint64_t &addr, uint32_t &len)
     {
-        const uint2 h = static_cast<const uint2 *>(p.table)[key];
+        uint64_t entry = key;
+        if (kPaired) {
+            const uint32_t shift = 2u * p.kmer_size - 2u;  // X = k-1 letters of 2 bits
+            const bool as_prefix = (position & 1u) != 0;
+            const uint32_t block = as_prefix ? key >> 2 : key & ((1u << shift) - 1u);
+            const uint32_t slot = as_prefix ? 4u + (key & 3u) : key >> shift;
+            entry = (uint64_t)block * 8u + slot;
+        }
+        const uint2 h = static_cast<const uint2 *>(p.table)[entry];
         len = h.x;
         addr = (uint64_t)h.y * 128u;
     }
@@ -399,7 +417,7 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
                     const uint32_t key = key0 + st * weight;
                     uint64_t b0;
                     uint32_t n;
-                    Layout::lookup(p, key, b0, n);
+                    Layout::lookup(p, key, 0u, b0, n);
                     for (uint32_t off = 0; off < n; off += kWave) {
                         if (off + (uint32_t)lane < n) {
                             const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);  // {row, score bits}
@@ -789,10 +807,10 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     // what the kernel would cost without the table's HBM traffic (wrong lists)
                     // bits 32 / 64: the table shrunk to a half / a quarter (key >> 1, key >> 2)
                     if (exact)
-                        Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : (tl.key >> ((p.ablate >> 5) & 3u)), start[t],
-                                       llen[t]);
+                        Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : (tl.key >> ((p.ablate >> 5) & 3u)),
+                                       (uint32_t)tile_pos + (uint32_t)lane, start[t], llen[t]);
 #else
-                    if (exact) Layout::lookup(p, tl.key, start[t], llen[t]);
+                    if (exact) Layout::lookup(p, tl.key, (uint32_t)tile_pos + (uint32_t)lane, start[t], llen[t]);
 #endif
                 }
             }
@@ -1002,7 +1020,7 @@ __global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
         for (uint32_t i = lane; i < p.num_branches; i += kWave)
             lds.store(i, __float_as_uint(p.partial_scores[read * p.num_branches + i]),
                       p.partial_counts[read * p.num_branches + i]);
-        place_epilogue<PackedLayout, CountT>(kp, lds, read, len - k + 1);  // also clears the vectors
+        place_epilogue<PackedLayout<false>, CountT>(kp, lds, read, len - k + 1);  // also clears the vectors
     }
 }
 
@@ -1038,7 +1056,7 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
                 uint64_t addr;
                 uint32_t llen;
                 if (n_amb == 0) {
-                    Layout::lookup(p, (uint32_t)key, addr, llen);
+                    Layout::lookup(p, (uint32_t)key, 0u, addr, llen);
                     entries += llen;
                 } else {
                     weight = 1;
@@ -1046,7 +1064,7 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
                     for (uint32_t st = 0; st < p.alphabet_size; ++st)
                         if ((amb_cls >> st) & 1u) {
                             const uint64_t kk = key + (uint64_t)st * weight;
-                            Layout::lookup(p, (uint32_t)kk, addr, llen);
+                            Layout::lookup(p, (uint32_t)kk, 0u, addr, llen);
                             entries += llen;
                         }
                 }
@@ -1083,8 +1101,11 @@ hipError_t dispatch(DbLayout layout, bool wide_counts, F &&f)
             return wide_counts ? f.template operator()<CompactLayout<uint64_t>, uint32_t>()
                                : f.template operator()<CompactLayout<uint64_t>, uint16_t>();
         case DbLayout::kPacked:
-            return wide_counts ? f.template operator()<PackedLayout, uint32_t>()
-                               : f.template operator()<PackedLayout, uint16_t>();
+            return wide_counts ? f.template operator()<PackedLayout<false>, uint32_t>()
+                               : f.template operator()<PackedLayout<false>, uint16_t>();
+        case DbLayout::kPaired:
+            return wide_counts ? f.template operator()<PackedLayout<true>, uint32_t>()
+                               : f.template operator()<PackedLayout<true>, uint16_t>();
     }
     return hipErrorInvalidValue;
 }

@@ -13,7 +13,7 @@ from epik_amd import dist as edist, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["packed", "compact"])
+@pytest.fixture(autouse=True, params=["paired", "compact"])
 def db_layout(request, monkeypatch):
     monkeypatch.setenv("EPIK_AMD_LAYOUT", request.param)
     return request.param

@@ -5,7 +5,7 @@ Runs the bench workload through several variants IN ONE PROCESS, interleaved ove
 rounds (devices differ by several percent: never compare across runs).  A variant is a
 comma-separated list of key=value:
     lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
-    layout=compact|packed, wide=0|1, ablate=<bitmask>, stamps=1   (env read at placer creation)
+    layout=compact|packed|paired, wide=0|1, ablate=<bitmask>, stamps=1   (env read at placer creation)
 Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
 """
 import ctypes
@@ -43,7 +43,7 @@ def main():
         os.environ["EPIK_AMD_ABLATE"] = kv.get("ablate", "0")
         os.environ["EPIK_AMD_WIDE_COUNTS"] = kv.get("wide", "0")
         os.environ["EPIK_AMD_STAMPS"] = kv.get("stamps", "0")
-        os.environ["EPIK_AMD_LAYOUT"] = kv.get("layout", "packed")
+        os.environ["EPIK_AMD_LAYOUT"] = kv.get("layout", "paired")
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
         desc = capi.PlacerDesc(
             abi_version=1, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
