@@ -839,37 +839,35 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
             for (uint32_t w0 = 0; w0 < total; w0 += kChunkCap) {  // one round unless > kChunkCap chunks
                 const uint32_t n_round = min(total - w0, kChunkCap);
                 const uint32_t n_padded = (n_round + (uint32_t)kRing - 1u) & ~((uint32_t)kRing - 1u);
-                // Every lane writes the first chunk of its own lists; the further chunks of a
-                // long list (> 64 postings, about a fifth of the lists) are written by the whole
-                // wave at once, lane j writing chunk j, one list at a time.
+                // Every lane writes the first kOwnChunks chunks of its own lists (lists of up to 192
+                // postings: all but a few percent); the rest of a longer list is written by the
+                // whole wave at once, lane j writing chunk kOwnChunks + j, one list at a time.
+                constexpr uint32_t kOwnChunks = 3;
 #pragma unroll
                 for (int t = 0; t < kTilesPerPass; ++t) {
-                    const uint32_t idx = first[t] - w0;  // wraps when in front of the window
-                    if (nch[t] != 0 && idx < kChunkCap) {
-                        const uint64_t cnt = llen[t] < (uint32_t)kWave ? llen[t] : (uint32_t)kWave;
-                        chunks[idx] = chunk_address<Layout>(p, start[t], 0) | (cnt << 48);
+#pragma unroll
+                    for (uint32_t c = 0; c < kOwnChunks; ++c) {
+                        const uint32_t idx = first[t] + c - w0;  // wraps when in front of the window
+                        if (nch[t] > c && idx < kChunkCap) {
+                            const uint32_t rest = llen[t] - (c << 6);
+                            const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                            chunks[idx] = chunk_address<Layout>(p, start[t], c) | (cnt << 48);
+                        }
                     }
-                    uint64_t long_lists = __ballot(nch[t] > 1u);
+                    uint64_t long_lists = __ballot(nch[t] > kOwnChunks);
                     while (long_lists) {
                         const int m = __builtin_ctzll(long_lists);
                         long_lists &= long_lists - 1;
                         const uint32_t l_first = __builtin_amdgcn_readlane(first[t], m);
                         const uint32_t l_len = __builtin_amdgcn_readlane(llen[t], m);
                         const uint64_t l_start = readlane_u64(start[t], m);
-                        const uint32_t c = (uint32_t)lane;  // chunk index inside the list
-                        const uint32_t idx2 = l_first + c - w0;
-                        if (c >= 1u && (c << 6) < l_len && idx2 < kChunkCap) {
-                            const uint32_t rest = l_len - (c << 6);
-                            const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                            chunks[idx2] = chunk_address<Layout>(p, l_start, c) | (cnt << 48);
-                        }
-                        // lists of more than 64 chunks (> 4096 postings): the lanes take further turns
-                        for (uint32_t c2 = c + (uint32_t)kWave; (c2 << 6) < l_len; c2 += kWave) {
-                            const uint32_t idx3 = l_first + c2 - w0;
-                            if (idx3 < kChunkCap) {
-                                const uint32_t rest = l_len - (c2 << 6);
+                        // lists of more than 64 + kOwnChunks chunks: the lanes take further turns
+                        for (uint32_t c = (uint32_t)lane + kOwnChunks; (c << 6) < l_len; c += kWave) {
+                            const uint32_t idx = l_first + c - w0;
+                            if (idx < kChunkCap) {
+                                const uint32_t rest = l_len - (c << 6);
                                 const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                                chunks[idx3] = chunk_address<Layout>(p, l_start, c2) | (cnt << 48);
+                                chunks[idx] = chunk_address<Layout>(p, l_start, c) | (cnt << 48);
                             }
                         }
                     }
