@@ -752,8 +752,10 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
 #define EPIK_STAMP(k)
 #endif
     for (uint64_t read = wave_global; read < p.n_reads; read += total_waves) {
-        const uint64_t seq_begin = p.seq_offsets[read];
-        const uint64_t len = p.seq_offsets[read + 1] - seq_begin;
+        // the read's bounds are the same in every lane: keep them (and every length, position and
+        // loop bound derived from them) in scalar registers
+        const uint64_t seq_begin = readlane_u64(p.seq_offsets[read], 0);
+        const uint64_t len = readlane_u64(p.seq_offsets[read + 1], 0) - seq_begin;
         const uint8_t *__restrict__ seq = p.seqs + seq_begin;
         // place.cpp:322 underflows for len < k; we report "no placement" -- also for a read whose
         // k-mers could overflow this kernel's count type (the host then uses the wide kernel)
