@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/pmc_insts
 mkdir -p $OUT
 for ab in 0 2 10 26; do
   EPIK_AMD_LIB=$R/epik_amd/libepik_amd_ablate.so EPIK_AMD_ABLATE=$ab timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/ab$ab -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline-seconds 0 > $OUT/ab$ab.log 2>&1
-  echo "== ablate=$ab (layout ${EPIK_AMD_LAYOUT:-compact})"
+  echo "== ablate=$ab (layout ${EPIK_AMD_LAYOUT:-default})"
   python3 - <<PY
 import csv,glob
 acc={}
