@@ -53,6 +53,7 @@ struct epik_amd_placer {
     bool wide_counts = false;  // 32-bit per-branch counts (reads of 32768 k-mers or more)
     bool timing = false;
     void *d_table = nullptr;       // offsets (compact) or {len, line} entries (packed)
+    uint64_t *d_filter = nullptr;  // presence words of the filtered layout
     uint8_t *d_postings = nullptr; // 6-byte postings
     uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
@@ -115,6 +116,7 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     }
 #endif
     (void)hipFree(p->d_table);
+    (void)hipFree(p->d_filter);
     (void)hipFree(p->d_postings);
     (void)hipFree(p->d_char_class);
     (void)hipFree(p->d_seqs);
@@ -264,17 +266,29 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     //           only (place_kernel.hip: PackedLayout<true>) -- the default for them;
     //  compact: the CSR (4- or 8-byte offsets), 8-byte postings back to back.
     // paired / packed are chosen when the table is at most a quarter of the device's free memory;
-    // EPIK_AMD_LAYOUT=compact|packed|paired overrides (paired falls back to packed for other alphabets).
+    //  filtered: packed behind a presence filter keyed like the paired table (other alphabets, sparse
+    //           databases: chosen when at most a quarter of the codes have a list);
+    // EPIK_AMD_LAYOUT=compact|packed|paired|filtered overrides (paired means filtered for other alphabets).
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
     const char *lay = std::getenv("EPIK_AMD_LAYOUT");
-    if (lay && std::strcmp(lay, "compact") != 0 && std::strcmp(lay, "packed") != 0 && std::strcmp(lay, "paired") != 0) {
+    if (lay && std::strcmp(lay, "compact") != 0 && std::strcmp(lay, "packed") != 0 && std::strcmp(lay, "paired") != 0 &&
+        std::strcmp(lay, "filtered") != 0) {
         epik_amd_placer_destroy(p);
-        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed or paired");
+        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed, paired or filtered");
     }
     const bool can_pair = d->alphabet_size == 4;
     const bool paired = can_pair && (lay ? std::strcmp(lay, "paired") == 0 : d->num_keys * 16u <= free_mem / 4);
     const bool packed = paired || (lay ? std::strcmp(lay, "compact") != 0 : d->num_keys * 8u <= free_mem / 4);
+    // filtered: packed + one presence word per (k-1)-mer, for the other alphabets (2 * sigma bits fit
+    // a word) when few codes have a list: then most lookups end at the filter, two per fetched line
+    uint64_t present_codes = 0;
+    for (uint64_t key = 0; key < d->num_keys; ++key)
+        present_codes += (p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key + 1] != static_cast<const uint64_t *>(d->offsets)[key]
+                                       : static_cast<const uint32_t *>(d->offsets)[key + 1] != static_cast<const uint32_t *>(d->offsets)[key]);
+    const bool can_filter = packed && !paired && !can_pair && d->alphabet_size <= 32;
+    const bool filtered = can_filter && (lay ? std::strcmp(lay, "filtered") == 0 || std::strcmp(lay, "paired") == 0
+                                             : present_codes * 4u <= d->num_keys);
     auto offset_at = [&](uint64_t key) -> uint64_t {
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
                             : static_cast<const uint32_t *>(d->offsets)[key];
@@ -320,7 +334,9 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
             }
         };
         if (packed) {
-            p->layout = paired ? epik_amd::DbLayout::kPaired : epik_amd::DbLayout::kPacked;
+            p->layout = paired     ? epik_amd::DbLayout::kPaired
+                        : filtered ? epik_amd::DbLayout::kFiltered
+                                   : epik_amd::DbLayout::kPacked;
             // paired: the entry of code c = a.X = Y.b (X its last k-1 letters, Y its first k-1) is stored
             // in block X at slot a and in block Y at slot 4 + b; a block is 8 entries
             const uint32_t shift = 2u * d->kmer_size - 2u;
@@ -341,6 +357,25 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
             }
             CREATE_TRY(hipMalloc(&p->d_table, table.size() * 4u + 8u));
             CREATE_TRY(hipMemcpy(p->d_table, table.data(), table.size() * 4u, hipMemcpyHostToDevice));
+            if (filtered) {
+                // filter[X], X a (k-1)-mer: bit a <=> code a.X has a list, bit sigma + b <=> code X.b has one
+                const uint64_t sigma = d->alphabet_size, blocks = d->num_keys / sigma;  // sigma^(k-1)
+                std::vector<uint64_t> filter;
+                try {
+                    filter.assign(blocks, 0);
+                } catch (const std::bad_alloc &) {
+                    epik_amd_placer_destroy(p);
+                    return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the presence filter");
+                }
+                for (uint64_t key = 0; key < d->num_keys; ++key) {
+                    if (kept_len(key) == 0) continue;
+                    filter[key % blocks] |= 1ull << (key / blocks);          // as a.X: X = its last k-1 letters
+                    filter[key / sigma] |= 1ull << (sigma + key % sigma);    // as X.b: X = its first k-1 letters
+                }
+                CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_filter), blocks * 8u));
+                CREATE_TRY(hipMemcpy(p->d_filter, filter.data(), blocks * 8u, hipMemcpyHostToDevice));
+                pp.filter = p->d_filter;
+            }
         } else {
             p->layout = p->offsets64 ? epik_amd::DbLayout::kCompact64 : epik_amd::DbLayout::kCompact32;
             // the kept lists back to back as {f32 score, u32 cell}; with one shard the offsets
@@ -382,6 +417,7 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     CREATE_TRY(hipEventCreate(&p->ev_stop));
 
     pp.char_class = p->d_char_class;
+    pp.sigma_pow_km1 = (uint32_t)(d->num_keys / d->alphabet_size);
     pp.kmer_size = d->kmer_size;
     pp.alphabet_size = d->alphabet_size;
     pp.num_branches = d->num_branches;

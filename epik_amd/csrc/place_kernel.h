@@ -23,6 +23,8 @@ enum class DbLayout : int {
                      // 6 bytes per posting: f32 score[cnt] then u16 cell[cnt] per chunk of <= 64
     kPaired = 3,     // the same lists; the table keyed by the (k-1)-mer two consecutive k-mers share
                      // (4-letter alphabets): one table line per two lookups, 16 bytes per code
+    kFiltered = 4,   // kPacked behind a presence filter keyed the same way (other alphabets, sparse
+                     // databases): one filter word per two lookups, the table only for present codes
 };
 
 // Kernel arguments: the database in HBM, the placer constants of place.cpp:83-96, and
@@ -30,6 +32,8 @@ enum class DbLayout : int {
 struct PlaceParams {
     const void *table;           // compact: OffT offsets[num_keys + 1]; packed: uint2 {len, line}[num_keys];
                                  // paired: uint2 {len, line}[num_keys / 4][8]
+    const uint64_t *filter;      // filtered: [alphabet_size^(kmer_size-1)] presence words
+    uint32_t sigma_pow_km1;      // alphabet_size^(kmer_size-1)
     const uint8_t *postings;     // scores + cells, cell = n_pad - 1 - branch
     const uint32_t *char_class;  // [256]
     const uint8_t *seqs;

@@ -144,6 +144,18 @@ __device__ __forceinline__ float unord_f32(uint32_t o)
 // the device routine differs from it by ulps, which is far inside the 1e-5 LWR bar.
 __device__ __forceinline__ double pow10_f64(double x) { return exp10(x); }
 
+// Everything a wave knows about the 64-character tile it is encoding.
+struct Tile {
+    uint32_t key;       // k-mer code of the window starting at this lane (ambiguous position = state 0)
+    uint32_t prefix;    // code of the window's first k-1 letters ...
+    uint32_t last;      // ... and the state of its last letter: key = prefix * sigma + last
+    uint32_t first;     // state of its first letter (this lane's character)
+    uint32_t cls;       // char_class of this lane's character
+    uint64_t inv_mask;  // wave-uniform: lanes whose character is invalid
+    uint64_t amb_mask;  // wave-uniform: lanes whose character is ambiguous
+    bool in_range;      // this lane starts a window of the read (p < n_kmers, lane < tile stride)
+};
+
 // ---------------------------------------------------------------------------------
 // Database layouts in HBM.  Both answer phylo_kmer_db::search (place.cpp:300,311): a
 // k-mer code -> (byte offset of its posting list in p.postings, list length).
@@ -182,6 +194,11 @@ struct CompactLayout {
         const OffT e = offsets[(uint64_t)key + 1];
         addr = (uint64_t)b * 8u;
         len = (uint32_t)(e - b);
+    }
+    __device__ static __forceinline__ void lookup_window(const PlaceParams &p, const Tile &t, uint32_t position,
+                                                         bool wanted, uint64_t &addr, uint32_t &len)
+    {
+        if (wanted) lookup(p, t.key, position, addr, len);
     }
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
@@ -225,16 +242,24 @@ struct CompactLayout {
 // therefore stored twice; the k-mer at an even position of the read is looked up as a.X in
 // the block of its suffix, the next one as X.b in the block of its prefix -- the same block,
 // the same line, one fetch for the two lanes.  16 bytes of table per code instead of 8.
-template <bool kPaired>
+//
+// kFiltered (other alphabets, sparse databases -- a protein database holds a small fraction of
+// the 20^k codes): the same pairing applied to a presence filter.  filter[X] is one 64-bit
+// word per (k-1)-mer X: bit a says whether a.X has a list, bit sigma + b whether X.b has one.
+// Two consecutive k-mers read the same word; only the k-mers that are present go on to the
+// table (keyed by code, as in the plain layout).  8 bytes of filter per (k-1)-mer.
+enum : int { kPlainTable = 0, kPairedTable = 1, kFilteredTable = 2 };
+template <int kTable>
 struct PackedLayout {
     static constexpr int kLoads = 2;
     static constexpr uint32_t kChunkBytes = 64u * 6u;
     static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk
+    // by code alone (the cold paths; the filter only saves traffic, the table is complete)
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t position,
                                                   uint64_t &addr, uint32_t &len)
     {
         uint64_t entry = key;
-        if (kPaired) {
+        if (kTable == kPairedTable) {
             const uint32_t shift = 2u * p.kmer_size - 2u;  // X = k-1 letters of 2 bits
             const bool as_prefix = (position & 1u) != 0;
             const uint32_t block = as_prefix ? key >> 2 : key & ((1u << shift) - 1u);
@@ -244,6 +269,19 @@ struct PackedLayout {
         const uint2 h = static_cast<const uint2 *>(p.table)[entry];
         len = h.x;
         addr = (uint64_t)h.y * 128u;
+    }
+    // the hot path: the window of lane `position` of the read, `wanted` = it is an exact k-mer
+    __device__ static __forceinline__ void lookup_window(const PlaceParams &p, const Tile &t, uint32_t position,
+                                                         bool wanted, uint64_t &addr, uint32_t &len)
+    {
+        if (kTable == kFilteredTable) {
+            const bool as_prefix = (position & 1u) != 0;
+            const uint32_t shared = as_prefix ? t.prefix : t.key - t.first * p.sigma_pow_km1;  // X
+            const uint32_t bit = as_prefix ? p.alphabet_size + t.last : t.first;
+            const uint64_t word = wanted ? p.filter[shared] : 0ull;
+            wanted = ((word >> bit) & 1ull) != 0;
+        }
+        if (wanted) lookup(p, t.key, position, addr, len);
     }
     __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
     {
@@ -286,15 +324,6 @@ __device__ __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t
 // the padding chunk: zero bytes at a valid address
 __device__ __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return (uint64_t)p.postings; }
 
-// Everything a wave knows about the 64-character tile it is encoding.
-struct Tile {
-    uint32_t key;       // k-mer code of the window starting at this lane (ambiguous position = state 0)
-    uint32_t cls;       // char_class of this lane's character
-    uint64_t inv_mask;  // wave-uniform: lanes whose character is invalid
-    uint64_t amb_mask;  // wave-uniform: lanes whose character is ambiguous
-    bool in_range;      // this lane starts a window of the read (p < n_kmers, lane < tile stride)
-};
-
 // i2l::to_kmers<one_ambiguity_policy> for one tile (place.cpp:294) in three steps, so that a
 // pass can issue the loads of all its tiles together: the character of this lane (branch-free:
 // positions past the end re-read the last character and are masked later), its class through
@@ -324,20 +353,29 @@ __device__ __forceinline__ Tile tile_from_class(uint32_t cls, uint64_t len, uint
     // Window code of the k characters from this lane on: the states of the next lanes come down
     // one lane per step with a whole-wave DPP shift (wave_shl:1, lane i <- lane i+1, 0 behind lane
     // 63) -- a few cycles per step, where an LDS shuffle per step costs a round trip each.
-    uint32_t key = state, next = state;
+    uint32_t prefix = state, next = state;  // the first k-1 letters, then the last one separately
     const uint32_t steps = __builtin_amdgcn_readfirstlane(k) - 1u;
     if (sigma == 4u) {  // wave-uniform
-        for (uint32_t j = 0; j < steps; ++j) {
+        for (uint32_t j = 1; j < steps; ++j) {
             next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
-            key = (key << 2) | next;
+            prefix = (prefix << 2) | next;
         }
     } else {
-        for (uint32_t j = 0; j < steps; ++j) {
+        for (uint32_t j = 1; j < steps; ++j) {
             next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
-            key = key * sigma + next;
+            prefix = prefix * sigma + next;
         }
     }
-    t.key = key;
+    if (steps == 0) {  // k == 1: no prefix
+        t.prefix = 0;
+        t.last = state;
+        t.key = state;
+    } else {
+        t.prefix = prefix;
+        t.last = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
+        t.key = prefix * sigma + t.last;
+    }
+    t.first = state;
     t.in_range = ((uint32_t)lane < stride) && (pos < n_kmers);
     return t;
 }
@@ -808,11 +846,15 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     // bit 16: every lookup falls into the first 4096 table entries (L2-resident):
                     // what the kernel would cost without the table's HBM traffic (wrong lists)
                     // bits 32 / 64: the table shrunk to a half / a quarter (key >> 1, key >> 2)
-                    if (exact)
-                        Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : (tl.key >> ((p.ablate >> 5) & 3u)),
-                                       (uint32_t)tile_pos + (uint32_t)lane, start[t], llen[t]);
+                    if (p.ablate & (16u | 32u | 64u)) {
+                        if (exact)
+                            Layout::lookup(p, (p.ablate & 16u) ? (tl.key & 4095u) : (tl.key >> ((p.ablate >> 5) & 3u)),
+                                           (uint32_t)tile_pos + (uint32_t)lane, start[t], llen[t]);
+                    } else {
+                        Layout::lookup_window(p, tl, (uint32_t)tile_pos + (uint32_t)lane, exact, start[t], llen[t]);
+                    }
 #else
-                    if (exact) Layout::lookup(p, tl.key, (uint32_t)tile_pos + (uint32_t)lane, start[t], llen[t]);
+                    Layout::lookup_window(p, tl, (uint32_t)tile_pos + (uint32_t)lane, exact, start[t], llen[t]);
 #endif
                 }
             }
@@ -1020,7 +1062,7 @@ __global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
         for (uint32_t i = lane; i < p.num_branches; i += kWave)
             lds.store(i, __float_as_uint(p.partial_scores[read * p.num_branches + i]),
                       p.partial_counts[read * p.num_branches + i]);
-        place_epilogue<PackedLayout<false>, CountT>(kp, lds, read, len - k + 1);  // also clears the vectors
+        place_epilogue<PackedLayout<kPlainTable>, CountT>(kp, lds, read, len - k + 1);  // also clears the vectors
     }
 }
 
@@ -1101,11 +1143,14 @@ hipError_t dispatch(DbLayout layout, bool wide_counts, F &&f)
             return wide_counts ? f.template operator()<CompactLayout<uint64_t>, uint32_t>()
                                : f.template operator()<CompactLayout<uint64_t>, uint16_t>();
         case DbLayout::kPacked:
-            return wide_counts ? f.template operator()<PackedLayout<false>, uint32_t>()
-                               : f.template operator()<PackedLayout<false>, uint16_t>();
+            return wide_counts ? f.template operator()<PackedLayout<kPlainTable>, uint32_t>()
+                               : f.template operator()<PackedLayout<kPlainTable>, uint16_t>();
         case DbLayout::kPaired:
-            return wide_counts ? f.template operator()<PackedLayout<true>, uint32_t>()
-                               : f.template operator()<PackedLayout<true>, uint16_t>();
+            return wide_counts ? f.template operator()<PackedLayout<kPairedTable>, uint32_t>()
+                               : f.template operator()<PackedLayout<kPairedTable>, uint16_t>();
+        case DbLayout::kFiltered:
+            return wide_counts ? f.template operator()<PackedLayout<kFilteredTable>, uint32_t>()
+                               : f.template operator()<PackedLayout<kFilteredTable>, uint16_t>();
     }
     return hipErrorInvalidValue;
 }
