@@ -266,8 +266,9 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     //           only (place_kernel.hip: PackedLayout<true>) -- the default for them;
     //  compact: the CSR (4- or 8-byte offsets), 8-byte postings back to back.
     // paired / packed are chosen when the table is at most a quarter of the device's free memory;
-    //  filtered: packed behind a presence filter keyed like the paired table (other alphabets, sparse
-    //           databases: chosen when at most a quarter of the codes have a list);
+    //  filtered: packed behind a presence filter keyed like the paired table: chosen for the other
+    //           alphabets when at most a quarter of the codes have a list (for 4 letters it measures
+    //           the same as paired, sparse or not);
     // EPIK_AMD_LAYOUT=compact|packed|paired|filtered overrides (paired means filtered for other alphabets).
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
@@ -277,18 +278,25 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
         epik_amd_placer_destroy(p);
         return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed, paired or filtered");
     }
-    const bool can_pair = d->alphabet_size == 4;
-    const bool paired = can_pair && (lay ? std::strcmp(lay, "paired") == 0 : d->num_keys * 16u <= free_mem / 4);
-    const bool packed = paired || (lay ? std::strcmp(lay, "compact") != 0 : d->num_keys * 8u <= free_mem / 4);
-    // filtered: packed + one presence word per (k-1)-mer, for the other alphabets (2 * sigma bits fit
-    // a word) when few codes have a list: then most lookups end at the filter, two per fetched line
+    // filtered: one presence word per (k-1)-mer (2 * sigma bits) in front of the packed table, when
+    // few codes have a list: then most lookups end at the filter, two per fetched line
     uint64_t present_codes = 0;
     for (uint64_t key = 0; key < d->num_keys; ++key)
         present_codes += (p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key + 1] != static_cast<const uint64_t *>(d->offsets)[key]
                                        : static_cast<const uint32_t *>(d->offsets)[key + 1] != static_cast<const uint32_t *>(d->offsets)[key]);
-    const bool can_filter = packed && !paired && !can_pair && d->alphabet_size <= 32;
-    const bool filtered = can_filter && (lay ? std::strcmp(lay, "filtered") == 0 || std::strcmp(lay, "paired") == 0
-                                             : present_codes * 4u <= d->num_keys);
+    const bool sparse = present_codes * 4u <= d->num_keys;
+    const bool can_pair = d->alphabet_size == 4, can_filter = d->alphabet_size <= 32;
+    const bool table_fits = d->num_keys * 16u <= free_mem / 4;
+    bool paired = false, filtered = false, packed = false;
+    if (lay) {
+        filtered = can_filter && (std::strcmp(lay, "filtered") == 0 || (!can_pair && std::strcmp(lay, "paired") == 0));
+        paired = can_pair && std::strcmp(lay, "paired") == 0;
+        packed = paired || filtered || std::strcmp(lay, "compact") != 0;
+    } else if (table_fits) {
+        paired = can_pair;  // for 4 letters the paired table already reads one line per two lookups
+        filtered = !paired && can_filter && sparse;
+        packed = true;
+    }
     auto offset_at = [&](uint64_t key) -> uint64_t {
         return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
                             : static_cast<const uint32_t *>(d->offsets)[key];

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["paired", "packed", "compact"])
+@pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact"])
 def db_layout(request, monkeypatch):
     """Every parity test runs on every HBM layout of the database (line-aligned lists behind a
-    direct-index table -- keyed by k-mer, or by the overlap of consecutive k-mers for DNA -- and
-    the CSR used when that table would not fit)."""
+    direct-index table -- keyed by k-mer, or by the overlap of consecutive k-mers for DNA, or behind
+    a presence filter keyed that way -- and the CSR used when that table would not fit)."""
     monkeypatch.setenv("EPIK_AMD_LAYOUT", request.param)
     return request.param
 
