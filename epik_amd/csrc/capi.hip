@@ -250,10 +250,10 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
 
 
     // LDS rows per wave: the branches + the dummy row that out-of-range lanes of the posting
-    // loads fall on; a multiple of 4 rows of 64 (the epilogue's sweeps).  Postings carry a
-    // 16-bit cell = n_pad - 1 - branch.
+    // loads fall on; a multiple of 64 (the epilogue's sweeps).  Postings carry a 16-bit cell =
+    // n_pad - 1 - branch.
     epik_amd::PlaceParams &pp = p->params;
-    pp.n_pad = (d->num_branches + 1u + 255u) & ~255u;
+    pp.n_pad = (d->num_branches + 1u + 63u) & ~63u;
     if (pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u > kMaxLdsPerBlock) {  // the 32-bit-count kernels
         epik_amd_placer_destroy(p);
         return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
@@ -462,6 +462,12 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
         int per_cu = 0;
         CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, wide != 0, (int)(g.waves_per_block * 64u),
                                                    g.lds_block_bytes, &per_cu));
+        // The occupancy query can be one workgroup too optimistic: LDS is handed out in units of
+        // 1280 bytes (160 KiB / 128; measured: 5 x 32512 B did not fit a CU, 5 x 30976 B do), and a
+        // workgroup that is not resident with the others runs behind them -- with this kernel's
+        // fixed stride over the reads that doubles the launch time.
+        const uint32_t lds_units = (g.lds_block_bytes + 1279u) / 1280u;
+        per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
         if (per_cu < 1) per_cu = 1;
         g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }

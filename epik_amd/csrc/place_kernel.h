@@ -53,7 +53,7 @@ struct PlaceParams {
     double keep_factor;
     float threshold;
     float log_threshold;
-    uint32_t n_pad;                  // LDS rows per wave: num_branches + the dummy row, rounded up to 256
+    uint32_t n_pad;                  // LDS rows per wave: num_branches + the dummy row, rounded up to 64
     uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + chunk descriptors)
     uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
     unsigned long long *dbg;         // phase cycle sums (-DEPIK_AMD_ABLATION builds, EPIK_AMD_STAMPS=1)

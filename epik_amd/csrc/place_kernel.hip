@@ -508,20 +508,21 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const bool fast_div = p.kmer_size <= 32u;
     uint32_t touched = 0;
     float lane_best_f = -INFINITY;  // this lane's best score
-    // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 4 * 64: cells
-    // behind N hold no count (the dummy row of the out-of-range lanes was cleared by the caller),
-    // so there is no bounds test.  Four rows per lane and trip: the four LDS reads go out
-    // together, and the arithmetic is branch-free.
+    // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 64: cells behind N hold
+    // no count (the dummy row of the out-of-range lanes was cleared by the caller), so there is no
+    // bounds test.  Four rows per lane and trip while they last (the four LDS reads go out
+    // together), one per trip for the remainder; the arithmetic is branch-free.
     constexpr int kUnroll = 4;
     const uint32_t n_rows_pad = p.n_pad;
-    for (uint32_t base = 0; base < n_rows_pad; base += kUnroll * kWave) {
-        uint2 cv[kUnroll];
-        float pre[kUnroll], s[kUnroll];
+    auto correct_rows = [&](auto unroll, uint32_t base) {
+        constexpr int kRows = decltype(unroll)::value;
+        uint2 cv[kRows];
+        float pre[kRows], s[kRows];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
+        for (int u = 0; u < kRows; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
         float smallest = INFINITY;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kRows; ++u) {
             const uint32_t c = cv[u].y & ~lds.kSeen;
             pre[u] = __fadd_rn(__uint_as_float(cv[u].x), __fmul_rn((float)(nk_u - c), log_thr));  // :420
             s[u] = div_k(pre[u]);                                                                 // :421
@@ -529,16 +530,22 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         }
         if (!fast_div || __ballot(smallest < 0x1p-100f) != 0) {  // wave-uniform, practically never
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) s[u] = __fdiv_rn(pre[u], k_f);
+            for (int u = 0; u < kRows; ++u) s[u] = __fdiv_rn(pre[u], k_f);
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kRows; ++u) {
             const uint32_t c = cv[u].y & ~lds.kSeen;
             const float sc = c ? s[u] : -INFINITY;  // -inf = "not an edge"
             touched += c ? 1u : 0u;
             lane_best_f = fmaxf(lane_best_f, sc);
             lds.score[base + (uint32_t)u * kWave + (uint32_t)lane] = sc;  // the count cell stays as it is
         }
+    };
+    {
+        uint32_t base = 0;
+        for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave)
+            correct_rows(std::integral_constant<int, kUnroll>{}, base);
+        for (; base < n_rows_pad; base += kWave) correct_rows(std::integral_constant<int, 1>{}, base);
     }
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
     touched = wave_sum_u32(touched);
@@ -588,12 +595,13 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     if (touched != 0) {
         n_cand = 0;
         const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
-        for (uint32_t base = 0; base < n_rows_pad; base += kUnroll * kWave) {
-            float row[kUnroll];
+        auto scan_rows = [&](auto unroll, uint32_t base) {
+            constexpr int kRows = decltype(unroll)::value;
+            float row[kRows];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) row[u] = lds.score[base + (uint32_t)u * kWave + (uint32_t)lane];
+            for (int u = 0; u < kRows; ++u) row[u] = lds.score[base + (uint32_t)u * kWave + (uint32_t)lane];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kRows; ++u) {
                 const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
                 const float sc = row[u];             // -inf where there is no edge (a sum of finite
                 const bool edge = sc != -INFINITY;   // log10 scores never is)
@@ -607,6 +615,12 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
                     n_cand += (uint32_t)__popcll(m);
                 }
             }
+        };
+        {
+            uint32_t base = 0;
+            for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave)
+                scan_rows(std::integral_constant<int, kUnroll>{}, base);
+            for (; base < n_rows_pad; base += kWave) scan_rows(std::integral_constant<int, 1>{}, base);
         }
         if (n_cand > kCandCap) {
             // Too many ties at tau for the candidate buffer: repeated selection over all
