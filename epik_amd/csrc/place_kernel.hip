@@ -827,9 +827,9 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
 
         // ---- exact k-mers, read order (place.cpp:294-305, 349-371) -------------------
         // A pass covers kTilesPerPass 64-character tiles: (1) encode every window and
-        // issue all offset-table loads at once, (2) compact the found lists, in read
-        // order, into the wave's LDS descriptor array, (3) stream their postings through
-        // a ring of kRing in-flight 512-byte loads.
+        // issue all table lookups, (2) compact the found lists, in read order, into the
+        // wave's LDS array of chunk descriptors, (3) stream their postings through a ring
+        // of kRing chunks in flight.
         for (uint64_t pass_pos = 0; pass_pos < n_kmers; pass_pos += (uint64_t)kTilesPerPass * stride) {
             uint64_t start[kTilesPerPass];
             uint32_t llen[kTilesPerPass];
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
             }
             EPIK_STAMP(0)  // front end: encode + lookups issued
             // (2) lists -> chunks of <= 64 postings, in read order.  Each lane knows how many
-            // chunks its k-mers need; an exclusive scan over (tile, lane) gives every chunk its
+            // chunks its k-mers need; a prefix sum over (tile, lane) gives every chunk its
             // position in the stream, and the lanes write the chunk descriptors
             //     address (48 bits) | count << 48
             // into LDS themselves.  The streaming loop below then spends only a few scalar
