@@ -451,25 +451,31 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
         }
-        // as many waves per workgroup (<= 4) as fit half of the 160 KiB of LDS
-        g.waves_per_block = 4;
-        while (g.waves_per_block > 1 && g.waves_per_block * g.lds_wave_bytes > kMaxLdsPerBlock / 2) g.waves_per_block >>= 1;
-        g.lds_block_bytes = g.waves_per_block * g.lds_wave_bytes;
+        // Workgroup of 4, 2 or 1 independent waves: whichever keeps the most waves resident on a
+        // CU (ties: the larger workgroup).  LDS is handed out in units of 1280 bytes (160 KiB / 128;
+        // measured: 5 x 32512 B did not fit a CU, 5 x 30976 B do), which the occupancy query does not
+        // know -- and a workgroup that is not resident with the others runs behind them: with this
+        // kernel's fixed stride over the reads that doubles the launch time.  The grid is exactly the
+        // resident workgroups (registers, LDS and the waves-per-CU cap decide), each striding over the reads.
+        uint32_t best_waves = 0;
+        for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
+            const uint32_t block_bytes = wpb * g.lds_wave_bytes;
+            if (block_bytes > kMaxLdsPerBlock) continue;
+            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, wide != 0, block_bytes));
+            int per_cu = 0;
+            CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, wide != 0, (int)(wpb * 64u), block_bytes, &per_cu));
+            const uint32_t lds_units = (block_bytes + 1279u) / 1280u;
+            per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
+            if (per_cu < 1) per_cu = 1;
+            if ((uint32_t)per_cu * wpb > best_waves) {
+                best_waves = (uint32_t)per_cu * wpb;
+                g.waves_per_block = wpb;
+                g.lds_block_bytes = block_bytes;
+                g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+            }
+        }
         CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, wide != 0, g.lds_block_bytes));
         CREATE_TRY(epik_amd::set_finish_reads_lds_limit(wide != 0, g.lds_block_bytes));
-        // persistent-style grid: exactly the workgroups that are resident at once
-        // (registers, LDS and the 32-waves/CU cap decide), each striding over the reads
-        int per_cu = 0;
-        CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, wide != 0, (int)(g.waves_per_block * 64u),
-                                                   g.lds_block_bytes, &per_cu));
-        // The occupancy query can be one workgroup too optimistic: LDS is handed out in units of
-        // 1280 bytes (160 KiB / 128; measured: 5 x 32512 B did not fit a CU, 5 x 30976 B do), and a
-        // workgroup that is not resident with the others runs behind them -- with this kernel's
-        // fixed stride over the reads that doubles the launch time.
-        const uint32_t lds_units = (g.lds_block_bytes + 1279u) / 1280u;
-        per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
-        if (per_cu < 1) per_cu = 1;
-        g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     }
     if (const char *w = std::getenv("EPIK_AMD_WIDE_COUNTS")) p->wide_counts = w[0] == '1';
 #undef CREATE_TRY
