@@ -166,6 +166,7 @@ def main():
         workload += f"; k-mer-space shard over {world} GPU(s), {args.reads_per_step} reads per step in total"
     placer = Placer.from_synth(db, device=local_rank, shard_index=rank if kmer_shard else 0,
                                shard_count=world if kmer_shard else 1)
+    placer.choose_counts(args.read_length)  # what epik_amd_placer_place would pick for this batch
     n = args.reads_per_step
     keep = placer.keep_at_most
     dev = torch.device("cuda", local_rank)

@@ -37,6 +37,7 @@ EXPORTS = (
     "epik_amd_placer_accumulate_device",
     "epik_amd_placer_finish_device",
     "epik_amd_placer_set_wide_counts",
+    "epik_amd_placer_choose_counts",
     "epik_amd_placer_launch_info",
     "epik_amd_placer_set_timing",
     "epik_amd_placer_last_kernel_ms",
@@ -113,6 +114,8 @@ def load() -> ctypes.CDLL:
                                                 ctypes.POINTER(ctypes.c_uint32)]
     lib.epik_amd_placer_set_wide_counts.restype = i32
     lib.epik_amd_placer_set_wide_counts.argtypes = [vp, i32]
+    lib.epik_amd_placer_choose_counts.restype = i32
+    lib.epik_amd_placer_choose_counts.argtypes = [vp, u64]
     lib.epik_amd_placer_set_timing.restype = i32
     lib.epik_amd_placer_set_timing.argtypes = [vp, i32]
     lib.epik_amd_placer_last_kernel_ms.restype = i32

@@ -50,7 +50,8 @@ struct epik_amd_placer {
     int device = 0;
     bool offsets64 = false;
     epik_amd::DbLayout layout = epik_amd::DbLayout::kCompact32;
-    bool wide_counts = false;  // 32-bit per-branch counts (reads of 32768 k-mers or more)
+    int counts = epik_amd::kCounts16;  // width of the per-branch counts the next device launch uses
+    bool counts_forced = false;        // set by the caller / the environment: place() does not choose
     bool timing = false;
     void *d_table = nullptr;       // offsets (compact) or {len, line} entries (packed)
     uint64_t *d_filter = nullptr;  // presence words of the filtered layout
@@ -60,13 +61,14 @@ struct epik_amd_placer {
     epik_amd::PlaceParams params{};  // batch fields are filled per call
     uint64_t num_keys = 0;
     uint64_t num_entries = 0;
-    // launch geometry, [0] = 16-bit counts (default), [1] = 32-bit counts
+    // launch geometry per count width (epik_amd::CountBits)
     struct geometry {
         uint32_t waves_per_block = 4;
         uint32_t lds_wave_bytes = 0;
         uint32_t lds_block_bytes = 0;
         uint32_t max_blocks = 0;
-    } geo[2];
+        uint32_t resident_waves = 0;  // per CU
+    } geo[3];
     uint32_t last_blocks = 0;
     uint32_t last_geo = 0;
     // staging buffers for the host-pointer entry point (grown on demand)
@@ -442,11 +444,16 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
 #endif
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, d->device));
-    for (int wide = 0; wide < 2; ++wide) {
-        auto &g = p->geo[wide];
-        // per wave: float32 scores + 16/32-bit counts + the chunk descriptors of one round
+    for (int counts = 0; counts < 3; ++counts) {
+        auto &g = p->geo[counts];
+        // per wave: float32 scores + 8/16/32-bit counts + the chunk descriptors of one round
         // + one trip of spare entries (the kernel prefetches a trip ahead)
-        g.lds_wave_bytes = pp.n_pad * (wide ? 8u : 6u) + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
+        const uint32_t desc_bytes = (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
+        g.lds_wave_bytes = (pp.n_pad * (4u + (1u << counts)) + desc_bytes + 15u) & ~15u;
+        if (counts == epik_amd::kCounts8 && (pp.n_pad + 7u) / 8u > desc_bytes) {
+            g.max_blocks = 0;  // the 8-bit kernel keeps one flag bit per row in the descriptor area: no room
+            continue;
+        }
         if (g.lds_wave_bytes > kMaxLdsPerBlock) {
             epik_amd_placer_destroy(p);
             return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
@@ -461,9 +468,9 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
         for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
             const uint32_t block_bytes = wpb * g.lds_wave_bytes;
             if (block_bytes > kMaxLdsPerBlock) continue;
-            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, wide != 0, block_bytes));
+            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, block_bytes));
             int per_cu = 0;
-            CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, wide != 0, (int)(wpb * 64u), block_bytes, &per_cu));
+            CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, counts, (int)(wpb * 64u), block_bytes, &per_cu));
             const uint32_t lds_units = (block_bytes + 1279u) / 1280u;
             per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
             if (per_cu < 1) per_cu = 1;
@@ -474,14 +481,31 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
                 g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
             }
         }
-        CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, wide != 0, g.lds_block_bytes));
-        CREATE_TRY(epik_amd::set_finish_reads_lds_limit(wide != 0, g.lds_block_bytes));
+        g.resident_waves = best_waves;
+        CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, g.lds_block_bytes));
+        CREATE_TRY(epik_amd::set_finish_reads_lds_limit(counts, g.lds_block_bytes));
     }
-    if (const char *w = std::getenv("EPIK_AMD_WIDE_COUNTS")) p->wide_counts = w[0] == '1';
+    // EPIK_AMD_WIDE_COUNTS=0|1|2: 16-, 32-, 8-bit counts whatever the reads (tests, experiments)
+    if (const char *w = std::getenv("EPIK_AMD_WIDE_COUNTS")) {
+        p->counts = w[0] == '1' ? epik_amd::kCounts32 : w[0] == '2' ? epik_amd::kCounts8 : epik_amd::kCounts16;
+        if (p->counts == epik_amd::kCounts8 && p->geo[epik_amd::kCounts8].max_blocks == 0) p->counts = epik_amd::kCounts16;
+        p->counts_forced = true;
+    }
 #undef CREATE_TRY
 
     *out = p;
     return EPIK_AMD_OK;
+}
+
+// The narrowest counts that hold the k-mers of a read of `longest` characters, 8 bits only when
+// that keeps more waves on a CU than 16.
+static int counts_for(const epik_amd_placer *p, uint64_t longest)
+{
+    const uint64_t kmers = longest >= p->params.kmer_size ? longest - p->params.kmer_size + 1 : 0;
+    if (kmers >= 32768u) return epik_amd::kCounts32;
+    if (kmers <= 255u && p->geo[epik_amd::kCounts8].resident_waves > p->geo[epik_amd::kCounts16].resident_waves)
+        return epik_amd::kCounts8;
+    return epik_amd::kCounts16;
 }
 
 static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets, uint64_t n,
@@ -498,14 +522,14 @@ static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offs
     pp.rows = static_cast<epik_amd_placement *>(d_rows);
     pp.n_rows = static_cast<uint32_t *>(d_n_rows);
     pp.kmer_counts = static_cast<uint32_t *>(d_counts);
-    const auto &g = p->geo[p->wide_counts ? 1 : 0];
+    const auto &g = p->geo[p->counts];
     pp.lds_wave_bytes = g.lds_wave_bytes;
     uint64_t blocks = (n + g.waves_per_block - 1) / g.waves_per_block;
     if (blocks > g.max_blocks) blocks = g.max_blocks;
     p->last_blocks = (uint32_t)blocks;
-    p->last_geo = p->wide_counts ? 1 : 0;
+    p->last_geo = (uint32_t)p->counts;
     if (p->timing) HIP_TRY(hipEventRecord(p->ev_start, stream));
-    HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->wide_counts, dim3((unsigned)blocks),
+    HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->counts, dim3((unsigned)blocks),
                                          dim3(g.waves_per_block * 64u), g.lds_block_bytes, stream));
     if (p->timing) {
         HIP_TRY(hipEventRecord(p->ev_stop, stream));
@@ -542,11 +566,11 @@ int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets,
     pp.kmer_counts = static_cast<uint32_t *>(d_kmer_counts);
     pp.partial_scores = const_cast<float *>(static_cast<const float *>(d_scores));
     pp.partial_counts = const_cast<uint32_t *>(static_cast<const uint32_t *>(d_counts));
-    const auto &g = p->geo[p->wide_counts ? 1 : 0];
+    const auto &g = p->geo[p->counts];
     pp.lds_wave_bytes = g.lds_wave_bytes;
     uint64_t blocks = (n + g.waves_per_block - 1) / g.waves_per_block;
     if (blocks > g.max_blocks) blocks = g.max_blocks;
-    HIP_TRY(epik_amd::launch_finish_reads(pp, p->wide_counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
+    HIP_TRY(epik_amd::launch_finish_reads(pp, p->counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
                                           g.lds_block_bytes, static_cast<hipStream_t>(stream)));
     return EPIK_AMD_OK;
 }
@@ -588,14 +612,15 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
         longest = std::max<uint64_t>(longest, seq_offsets[i + 1] - seq_offsets[i]);
     }
     HIP_TRY(hipSetDevice(p->device));
-    // 16-bit per-branch counts unless a read has 32768 k-mers or more
-    const bool saved_wide = p->wide_counts;
-    if (longest >= p->params.kmer_size && longest - p->params.kmer_size + 1 >= 32768u) p->wide_counts = true;
-    struct restore_wide {
+    // The narrowest counts that hold the longest read's k-mers: 16 bits normally, 32 for a read of
+    // 32768 k-mers or more, 8 (reads of up to 255 k-mers) when that puts more waves on a CU.
+    const int saved_counts = p->counts;
+    if (!p->counts_forced) p->counts = counts_for(p, longest);
+    struct restore_counts {
         epik_amd_placer *p;
-        bool v;
-        ~restore_wide() { p->wide_counts = v; }
-    } restore{p, saved_wide};
+        int v;
+        ~restore_counts() { p->counts = v; }
+    } restore{p, saved_counts};
     const size_t seq_bytes = (size_t)seq_offsets[n];
     if (seq_bytes + 64 > p->d_seqs_cap) {
         (void)hipFree(p->d_seqs);
@@ -745,7 +770,18 @@ int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_bl
 int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled)
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
-    p->wide_counts = enabled != 0;
+    if (enabled == 2 && p->geo[epik_amd::kCounts8].max_blocks == 0)
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "no 8-bit-count kernel for this tree size");
+    p->counts = enabled == 1 ? epik_amd::kCounts32 : enabled == 2 ? epik_amd::kCounts8 : epik_amd::kCounts16;
+    p->counts_forced = enabled != 0;
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_choose_counts(epik_amd_placer *p, uint64_t longest_read)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    p->counts = counts_for(p, longest_read);
+    p->counts_forced = true;
     return EPIK_AMD_OK;
 }
 

@@ -59,14 +59,18 @@ struct PlaceParams {
     unsigned long long *dbg;         // phase cycle sums (-DEPIK_AMD_ABLATION builds, EPIK_AMD_STAMPS=1)
 };
 
-hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool wide_counts, dim3 grid, dim3 block,
+// Width of the per-branch k-mer counts in LDS: 16 bits by default (reads of up to 32767 k-mers),
+// 32 for longer reads, 8 (reads of up to 255 k-mers) when that lets more waves share a CU.
+enum CountBits : int { kCounts8 = 0, kCounts16 = 1, kCounts32 = 2 };
+
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream);
-hipError_t set_place_reads_lds_limit(DbLayout layout, bool wide_counts, size_t lds_bytes);
-hipError_t place_reads_occupancy(DbLayout layout, bool wide_counts, int block_threads, size_t lds_bytes,
+hipError_t set_place_reads_lds_limit(DbLayout layout, int counts, size_t lds_bytes);
+hipError_t place_reads_occupancy(DbLayout layout, int counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu);
-hipError_t launch_finish_reads(const PlaceParams &p, bool wide_counts, dim3 grid, dim3 block, size_t lds_bytes,
+hipError_t launch_finish_reads(const PlaceParams &p, int counts, dim3 grid, dim3 block, size_t lds_bytes,
                                hipStream_t stream);
-hipError_t set_finish_reads_lds_limit(bool wide_counts, size_t lds_bytes);
+hipError_t set_finish_reads_lds_limit(int counts, size_t lds_bytes);
 hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
                                     hipStream_t stream);
 

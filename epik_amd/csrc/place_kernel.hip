@@ -396,7 +396,10 @@ __device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uin
 // current round and is reused by the epilogue for its top-k candidates.
 template <typename CountT>
 struct WaveLds {
-    static constexpr uint32_t kSeen = 1u << (8 * sizeof(CountT) - 1);
+    // 16- and 32-bit counts keep the ambiguous path's "seen" flag in their top bit; 8-bit counts
+    // use all their bits (reads of up to 255 k-mers) and the flags live in a bitmap (place_ambiguous)
+    static constexpr uint32_t kSeen = sizeof(CountT) == 1 ? 0u : 1u << (8 * sizeof(CountT) - 1);
+    static constexpr uint64_t kMaxKmers = sizeof(CountT) == 1 ? 255u : (1ull << (8 * sizeof(CountT) - 1)) - 1u;
     float *score;    // [n_pad]
     CountT *count;   // [n_pad]
     uint64_t *desc;  // [kTilesPerPass * 64 + kRing]
@@ -429,6 +432,11 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
     const uint32_t sigma = p.alphabet_size;
     const uint32_t stride = kWave - (k - 1);
     const float k_f = (float)k;
+    // 8-bit counts: one "already scored by an ambiguous key" bit per row, in the chunk-descriptor
+    // area (idle between the stream and the epilogue; the host offers this kernel only when it fits)
+    uint32_t *seen_bitmap = reinterpret_cast<uint32_t *>(lds.desc);
+    if (sizeof(CountT) == 1)
+        for (uint32_t i = lane; i < (p.n_pad + 31u) / 32u; i += kWave) seen_bitmap[i] = 0u;
     // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
     {
         const float thr = p.threshold;
@@ -463,7 +471,13 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
                             const uint32_t c = cv.y;
                             // Only the first ambiguous key that reaches a branch scores it:
                             // later ones find counts_amb[b] != 0 and stay out of l_amb (:385-388).
-                            if (!(c & lds.kSeen)) {
+                            bool seen = (c & lds.kSeen) != 0;
+                            if (sizeof(CountT) == 1) {  // no flag bit in the count: a bitmap in the descriptor area
+                                const uint32_t bit = 1u << (e.x & 31u);
+                                seen = (__hip_atomic_fetch_or(&seen_bitmap[e.x >> 5], bit, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WAVEFRONT) & bit) != 0;
+                            }
+                            if (!seen) {
                                 // counts_amb[b] == 1, scores_amb[b] == float(pow(10, score)) (:390-391)
                                 const float prob = (float)pow(10.0, (double)__uint_as_float(e.y));
                                 const float avg = __fdiv_rn(
@@ -811,7 +825,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         const uint8_t *__restrict__ seq = p.seqs + seq_begin;
         // place.cpp:322 underflows for len < k; we report "no placement" -- also for a read whose
         // k-mers could overflow this kernel's count type (the host then uses the wide kernel)
-        if (len < k || len - k + 1 >= (uint64_t)WaveLds<CountT>::kSeen) {
+        if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers) {
             if (p.partial_scores) {  // accumulate-only launch: an all-zero partial vector
                 for (uint32_t i = lane; i < p.num_branches; i += kWave) {
                     p.partial_scores[read * p.num_branches + i] = 0.0f;
@@ -1069,7 +1083,7 @@ __global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
     for (uint64_t read = wave_global; read < p.n_reads; read += total_waves) {
         const uint64_t len = p.seq_offsets[read + 1] - p.seq_offsets[read];
-        if (len < k || len - k + 1 >= (uint64_t)WaveLds<CountT>::kSeen) {
+        if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers) {
             if (lane == 0) p.n_rows[read] = 0;
             continue;
         }
@@ -1145,74 +1159,73 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
 
 namespace {
 
-// Calls f.template operator()<Layout, CountT>() for the runtime variant.
+// Calls f.template operator()<Layout, CountT>() for the runtime variant (counts: CountBits).
+template <typename Layout, typename F>
+hipError_t dispatch_counts(int counts, F &&f)
+{
+    switch (counts) {
+        case kCounts8: return f.template operator()<Layout, uint8_t>();
+        case kCounts16: return f.template operator()<Layout, uint16_t>();
+        case kCounts32: return f.template operator()<Layout, uint32_t>();
+    }
+    return hipErrorInvalidValue;
+}
 template <typename F>
-hipError_t dispatch(DbLayout layout, bool wide_counts, F &&f)
+hipError_t dispatch(DbLayout layout, int counts, F &&f)
 {
     switch (layout) {
-        case DbLayout::kCompact32:
-            return wide_counts ? f.template operator()<CompactLayout<uint32_t>, uint32_t>()
-                               : f.template operator()<CompactLayout<uint32_t>, uint16_t>();
-        case DbLayout::kCompact64:
-            return wide_counts ? f.template operator()<CompactLayout<uint64_t>, uint32_t>()
-                               : f.template operator()<CompactLayout<uint64_t>, uint16_t>();
-        case DbLayout::kPacked:
-            return wide_counts ? f.template operator()<PackedLayout<kPlainTable>, uint32_t>()
-                               : f.template operator()<PackedLayout<kPlainTable>, uint16_t>();
-        case DbLayout::kPaired:
-            return wide_counts ? f.template operator()<PackedLayout<kPairedTable>, uint32_t>()
-                               : f.template operator()<PackedLayout<kPairedTable>, uint16_t>();
-        case DbLayout::kFiltered:
-            return wide_counts ? f.template operator()<PackedLayout<kFilteredTable>, uint32_t>()
-                               : f.template operator()<PackedLayout<kFilteredTable>, uint16_t>();
+        case DbLayout::kCompact32: return dispatch_counts<CompactLayout<uint32_t>>(counts, f);
+        case DbLayout::kCompact64: return dispatch_counts<CompactLayout<uint64_t>>(counts, f);
+        case DbLayout::kPacked: return dispatch_counts<PackedLayout<kPlainTable>>(counts, f);
+        case DbLayout::kPaired: return dispatch_counts<PackedLayout<kPairedTable>>(counts, f);
+        case DbLayout::kFiltered: return dispatch_counts<PackedLayout<kFilteredTable>>(counts, f);
     }
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool wide_counts, dim3 grid, dim3 block,
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream)
 {
-    return dispatch(layout, wide_counts, [&]<typename L, typename C>() {
+    return dispatch(layout, counts, [&]<typename L, typename C>() {
         hipLaunchKernelGGL((place_reads_kernel<L, C>), grid, block, lds_bytes, stream, p);
         return hipGetLastError();
     });
 }
 
-hipError_t set_place_reads_lds_limit(DbLayout layout, bool wide_counts, size_t lds_bytes)
+hipError_t set_place_reads_lds_limit(DbLayout layout, int counts, size_t lds_bytes)
 {
-    return dispatch(layout, wide_counts, [&]<typename L, typename C>() {
+    return dispatch(layout, counts, [&]<typename L, typename C>() {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<L, C>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
 }
 
-hipError_t place_reads_occupancy(DbLayout layout, bool wide_counts, int block_threads, size_t lds_bytes,
+hipError_t place_reads_occupancy(DbLayout layout, int counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu)
 {
-    return dispatch(layout, wide_counts, [&]<typename L, typename C>() {
+    return dispatch(layout, counts, [&]<typename L, typename C>() {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, place_reads_kernel<L, C>,
                                                             block_threads, lds_bytes);
     });
 }
 
-hipError_t launch_finish_reads(const PlaceParams &p, bool wide_counts, dim3 grid, dim3 block, size_t lds_bytes,
+hipError_t launch_finish_reads(const PlaceParams &p, int counts, dim3 grid, dim3 block, size_t lds_bytes,
                                hipStream_t stream)
 {
-    if (wide_counts)
-        hipLaunchKernelGGL((finish_reads_kernel<uint32_t>), grid, block, lds_bytes, stream, p);
-    else
-        hipLaunchKernelGGL((finish_reads_kernel<uint16_t>), grid, block, lds_bytes, stream, p);
-    return hipGetLastError();
+    return dispatch_counts<PackedLayout<kPlainTable>>(counts, [&]<typename L, typename C>() {
+        hipLaunchKernelGGL((finish_reads_kernel<C>), grid, block, lds_bytes, stream, p);
+        return hipGetLastError();
+    });
 }
 
-hipError_t set_finish_reads_lds_limit(bool wide_counts, size_t lds_bytes)
+hipError_t set_finish_reads_lds_limit(int counts, size_t lds_bytes)
 {
-    return wide_counts ? hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_reads_kernel<uint32_t>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                       : hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_reads_kernel<uint16_t>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return dispatch_counts<PackedLayout<kPlainTable>>(counts, [&]<typename L, typename C>() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_reads_kernel<C>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
 }
 
 hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
@@ -1220,7 +1233,7 @@ hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsig
 {
     const dim3 block(256);
     const dim3 grid((unsigned)((p.n_reads + 255) / 256));
-    return dispatch(layout, false, [&]<typename L, typename C>() {
+    return dispatch(layout, kCounts16, [&]<typename L, typename C>() {
         hipLaunchKernelGGL((algorithmic_bytes_kernel<L>), grid, block, 0, stream, p, d_total);
         return hipGetLastError();
     });

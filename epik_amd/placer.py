@@ -189,6 +189,11 @@ class Placer:
             self._handle, d_seq_offsets, int(n), d_scores, d_counts, d_rows, d_n_rows,
             d_kmer_counts or None, stream or None))
 
+    def choose_counts(self, longest_read: int) -> None:
+        """Width of the per-branch counts for the device entry points, chosen as `place_packed`
+        chooses it from the batch (`epik_amd_placer_choose_counts`)."""
+        capi.check(self._lib.epik_amd_placer_choose_counts(self._handle, int(longest_read)))
+
     def algorithmic_bytes(self, d_seqs: int, d_seq_offsets: int, n: int, d_n_rows: int = 0,
                           stream: int = 0) -> int:
         out = ctypes.c_uint64(0)

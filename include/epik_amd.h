@@ -136,14 +136,18 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
                                       void *stream, uint64_t *bytes_out);
 
 /*
- * The kernel keeps one count per branch in LDS: 16 bits by default (a read may have up
- * to 32767 k-mers), which lets 20 wavefronts share a CU.  epik_amd_placer_place() switches
- * to the 32-bit kernel by itself when a batch holds a longer read; for the device-pointer
- * entry point the caller selects it here (enabled != 0).  With 16-bit counts a longer read
- * gets n_rows == 0, like a read shorter than k.  (The reference counts in size_t,
- * place.h:86.)
+ * The kernel keeps one k-mer count per branch in LDS (the reference counts in size_t, place.h:86):
+ * 16 bits by default (reads of up to 32767 k-mers), 32 bits for longer reads, 8 bits (reads of up to
+ * 255 k-mers) when that lets more wavefronts share a CU -- large trees.  epik_amd_placer_place()
+ * looks at the batch and chooses by itself; for the device-pointer entry points the caller chooses
+ * here: enabled = 0 back to the default (16 bits, and place() chooses again), 1 = 32 bits, 2 = 8 bits
+ * (EPIK_AMD_ERR_UNSUPPORTED for trees too large for that kernel).  A read with more k-mers than the
+ * counts hold gets n_rows == 0, like a read shorter than k.
  */
 int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled);
+/* The same choice epik_amd_placer_place() makes, for the device-pointer entry points: the counts
+ * that fit a batch whose longest read has `longest_read` characters. */
+int epik_amd_placer_choose_counts(epik_amd_placer *p, uint64_t longest_read);
 
 /*
  * Database larger than one GPU's memory: k-mer-space shard (BASELINE configs[4]).

@@ -82,11 +82,11 @@ def test_golden_fixture(placer_cls):
             assert int(counts[i, j]) == c
 
 
-@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("wide", ["0", "1", "2"])
 def test_config1_shape_k10(placer_cls, oracle_lib, wide, monkeypatch):
     """BASELINE configs[0]/[1] shape at a size the oracle finishes in seconds:
-    nucl k=10, N=1303 (652 leaves, the D652 substitute), 150 bp reads.  Both the
-    16-bit-count kernels (default) and the 32-bit ("wide") ones must be bit-exact."""
+    nucl k=10, N=1303 (652 leaves, the D652 substitute), 150 bp reads.  The 16-bit-count
+    kernels (default), the 32-bit ("wide") and the 8-bit ones must all be bit-exact."""
     monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", wide)
     tree = synth.make_tree(652, seed=42)
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
@@ -184,3 +184,23 @@ def test_many_ties_overflow_candidate_buffer(placer_cls, oracle_lib):
     for keep_at_most, keep_factor in [(7, 0.01), (64, 0.0)]:
         _compare(placer_cls, oracle_lib, db, data, offs, keep_at_most=keep_at_most,
                  keep_factor=keep_factor)
+
+
+def test_large_tree_short_reads_take_the_8_bit_counts(placer_cls, oracle_lib):
+    """N = 4199: 8-bit counts put more waves on a CU than 16-bit ones, and reads of up to 255 k-mers
+    fit them -- place() switches by itself (ambiguous reads included: their "seen" flags move to a
+    bitmap); a longer read in the batch switches it back."""
+    tree = synth.make_tree(2100, seed=31)
+    db = synth.make_db(tree.num_nodes, kmer_size=8, seed=32, p_present=0.5, lognormal=(4.0, 1.5))
+    rng = np.random.default_rng(33)
+    reads = mixed_reads(rng, 1500, db.kmer_size, max_len=240)
+    data, offs = synth.pack_reads(reads)
+    orc = oracle_lib.Oracle.from_synth(db)
+    with placer_cls.from_synth(db) as pl:
+        got = pl.place_packed(data, offs)
+        narrow = pl.launch_info()
+        assert_rows_match(*got, *orc.place(data, offs, num_threads=0))
+        data2, offs2 = synth.pack_reads(reads[:200] + ["ACGT" * 100])
+        got2 = pl.place_packed(data2, offs2)
+        assert_rows_match(*got2, *orc.place(data2, offs2, num_threads=0))
+        assert narrow["lds_bytes_per_block"] < pl.launch_info()["lds_bytes_per_block"] * narrow["waves_per_block"] / pl.launch_info()["waves_per_block"]
