@@ -124,3 +124,15 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "epik_oracle" not in text, f
+
+
+def test_generated_isa_keeps_its_hands_off_the_load_ring():
+    """The posting loads are issued from inline asm and waited for with counted s_waitcnt: hipcc must
+    not touch a ring register while its load is in flight.  `make asm` regenerates the ISA of every
+    kernel variant and runs epik_amd/csrc/lint_ring_asm.py over it (hipcc cross-compiles here)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    run = subprocess.run(["make", "-C", os.path.join(root, "epik_amd", "csrc"), "asm"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "ring-asm lint: 0 problem(s)" in run.stdout
