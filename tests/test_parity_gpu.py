@@ -149,6 +149,21 @@ def test_amino_k4(placer_cls, oracle_lib):
     _compare(placer_cls, oracle_lib, db, data, offs)
 
 
+def test_amino_k6_sparse(placer_cls, oracle_lib):
+    """A sparse protein database (64 M codes, 1 % of them with a list: what the filtered layout is
+    chosen for), reads of 300 residues with a few ambiguous ones."""
+    tree = synth.make_tree(100, seed=18)
+    db = synth.make_db(tree.num_nodes, states="amino", kmer_size=6, seed=19, p_present=0.01,
+                       lognormal=(2.0, 1.0))
+    rng = np.random.default_rng(20)
+    reads = []
+    for i in range(1500):
+        alpha = alphabet.AMINO_STATES if i % 4 else alphabet.AMINO_STATES + "BZX"
+        reads.append("".join(rng.choice(list(alpha), size=300)))
+    data, offs = synth.pack_reads(reads)
+    _compare(placer_cls, oracle_lib, db, data, offs)
+
+
 def test_placer_place_mirrors_reference_contract(placer_cls, oracle_lib, small_case):
     """Placer.place(): duplicate sequences are placed once and carry all their
     headers (place.cpp:73-81); lengths are joined per branch (place.cpp:110-123)."""
