@@ -229,3 +229,66 @@ def pack_reads(reads) -> tuple:
         offsets[1:] = np.cumsum([len(b) for b in bufs], dtype=np.uint64)
     data = np.frombuffer(b"".join(bufs), dtype=np.uint8).copy() if bufs else np.zeros(0, np.uint8)
     return data, offsets
+
+
+def make_sparse_db(num_branches: int, states: str = "amino", kmer_size: int = 7, omega: float = 1.5,
+                   p_present: float = 0.0026, seed: int = 43, lognormal=(3.0, 1.5)) -> SynthDB:
+    """The database model of `make_db` for a key space too large to draw one uniform number per code
+    (amino k = 7: 1.28 G codes): the present codes are drawn directly (Binomial count, distinct uniform
+    codes), everything else is the same.  Peak host memory = the uint64 offsets array (8 B per code)."""
+    sigma = alphabet.alphabet_size(states)
+    num_keys = sigma ** kmer_size
+    rng = np.random.default_rng(seed)
+    threshold = alphabet.score_threshold(omega, kmer_size, sigma)
+    n_present = int(rng.binomial(num_keys, p_present))
+    keys = np.unique(rng.integers(0, num_keys, size=int(n_present * 1.02) + 16, dtype=np.int64))
+    keys = np.sort(rng.permutation(keys)[:n_present])
+    n_present = int(keys.shape[0])
+    raw = np.floor(rng.lognormal(lognormal[0], lognormal[1], size=n_present))
+    lengths = (1 + np.minimum(num_branches - 1, raw)).astype(np.int64)
+    offsets = np.zeros(num_keys + 1, dtype=np.uint64)
+    offsets[keys + 1] = lengths.astype(np.uint64)
+    np.cumsum(offsets, out=offsets)
+    total = int(offsets[-1])
+    values = np.empty(total, dtype=PKDB_VALUE)
+    list_id = np.repeat(np.arange(n_present, dtype=np.int64), lengths)
+    list_start = np.cumsum(lengths) - lengths
+    within = np.arange(total, dtype=np.int64) - list_start[list_id]
+    start = (rng.random(n_present) * (num_branches - lengths + 1)).astype(np.int64)
+    values["branch"] = (start[list_id] + within).astype(np.uint32)
+    prob = float(threshold) + rng.random(total) * (1.0 - float(threshold))
+    values["score"] = np.log10(prob).astype(np.float32)
+    return SynthDB(states=states, kmer_size=kmer_size, omega=omega, num_branches=num_branches,
+                   offsets=offsets, values=values, threshold=threshold)
+
+
+def reads_hitting(db: SynthDB, n_reads: int, length: int, hit_rate: float, seed: int = 45, dirty: str = ""):
+    """Reads for a sparse database: uniform random reads would find next to nothing in it, so every
+    read is a chain of k-mers that ARE in the database (drawn among the present codes) joined by random
+    letters, about `hit_rate` of its positions starting a planted k-mer; `dirty` letters (ambiguous /
+    invalid characters) replace a few positions of every fourth read."""
+    rng = np.random.default_rng(seed)
+    sigma, k = db.alphabet_size, db.kmer_size
+    chars = np.frombuffer(alphabet.state_chars(db.states).encode(), dtype=np.uint8)
+    lens = np.diff(db.offsets.view(np.int64)) if db.num_keys <= (1 << 26) else None
+    if lens is not None:
+        present = np.nonzero(lens)[0]
+    else:  # large key space: sample codes until enough present ones are found
+        present = np.zeros(0, dtype=np.int64)
+        while present.shape[0] < 200_000:
+            cand = rng.integers(0, db.num_keys, size=4_000_000, dtype=np.int64)
+            present = np.concatenate([present, cand[db.offsets[cand + 1] > db.offsets[cand]]])
+    seqs = chars[rng.integers(0, sigma, size=(n_reads, length))]
+    n_plant = max(1, int(length * hit_rate / k))
+    pos = rng.integers(0, length - k + 1, size=(n_reads, n_plant))
+    code = present[rng.integers(0, present.shape[0], size=(n_reads, n_plant))]
+    for j in range(k):  # letter j of the planted k-mer, first character most significant
+        digit = (code // (sigma ** (k - 1 - j))) % sigma
+        np.put_along_axis(seqs, pos + j, chars[digit], axis=1)
+    if dirty:
+        d = np.frombuffer(dirty.encode(), dtype=np.uint8)
+        rows = np.arange(0, n_reads, 4)
+        for _ in range(3):
+            seqs[rows, rng.integers(0, length, size=rows.shape[0])] = d[rng.integers(0, d.shape[0], size=rows.shape[0])]
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(length)
+    return seqs.reshape(-1).copy(), offsets
