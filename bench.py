@@ -184,7 +184,7 @@ def main():
         N = placer.num_branches
         per = -(-n // world)
         begin, end = edist.owner_bounds(n, rank, world)
-        part = [torch.zeros((per * world, N), dtype=t, device=dev) for t in (torch.float32, torch.int32)]
+        part = [torch.zeros((per * world, N), dtype=t, device=dev) for t in (torch.float32, torch.int16)]
         recv = [torch.empty_like(x) for x in part]
 
         def step():  # noqa: F811

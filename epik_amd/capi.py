@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EPIK_AMD_LIB") or os.path.join(_HERE, "libepik_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 
@@ -29,6 +29,8 @@ EXPORTS = (
     "epik_amd_device_count",
     "epik_amd_last_error",
     "epik_amd_placer_create",
+    "epik_amd_placer_plan",
+    "epik_amd_placer_build_image",
     "epik_amd_placer_destroy",
     "epik_amd_placer_place",
     "epik_amd_placer_place_device",
@@ -67,6 +69,27 @@ class PlacerDesc(ctypes.Structure):
     ]
 
 
+class Plan(ctypes.Structure):
+    """`epik_amd_plan`."""
+
+    _fields_ = [
+        ("kernel", ctypes.c_uint32),
+        ("layout", ctypes.c_uint32),
+        ("team_waves", ctypes.c_uint32),
+        ("team_passes", ctypes.c_uint32),
+        ("slice_rows", ctypes.c_uint32),
+        ("resident_waves", ctypes.c_uint32 * 3),
+        ("table_bytes", ctypes.c_uint64),
+        ("filter_bytes", ctypes.c_uint64),
+        ("posting_bytes", ctypes.c_uint64),
+        ("kept_entries", ctypes.c_uint64),
+    ]
+
+
+#: n_rows of a read with more k-mers than the counts of a device-pointer launch hold
+ROWS_COUNTS_TOO_NARROW = 0xFFFFFFFF
+
+
 class EpikAmdError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"libepik_amd error {code}: {message}")
@@ -97,9 +120,15 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_placer_create_sharded.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.POINTER(vp)]
     lib.epik_amd_placer_accumulate_device.restype = i32
-    lib.epik_amd_placer_accumulate_device.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    lib.epik_amd_placer_accumulate_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, vp]
     lib.epik_amd_placer_finish_device.restype = i32
-    lib.epik_amd_placer_finish_device.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp]
+    lib.epik_amd_placer_finish_device.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.epik_amd_placer_plan.restype = i32
+    lib.epik_amd_placer_plan.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32, u64,
+                                         ctypes.POINTER(Plan)]
+    lib.epik_amd_placer_build_image.restype = i32
+    lib.epik_amd_placer_build_image.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32, u64,
+                                                vp, vp, vp]
     lib.epik_amd_placer_destroy.restype = None
     lib.epik_amd_placer_destroy.argtypes = [vp]
     lib.epik_amd_placer_place.restype = i32

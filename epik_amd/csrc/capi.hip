@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "db_image.hpp"
 #include "epik_amd.h"
 #include "place_kernel.h"
 
@@ -48,7 +49,6 @@ constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // gfx950: 160 KiB per CU
 
 struct epik_amd_placer {
     int device = 0;
-    bool offsets64 = false;
     epik_amd::DbLayout layout = epik_amd::DbLayout::kCompact32;
     int counts = epik_amd::kCounts16;  // width of the per-branch counts the next device launch uses
     bool counts_forced = false;        // set by the caller / the environment: place() does not choose
@@ -59,6 +59,11 @@ struct epik_amd_placer {
     uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
     epik_amd::PlaceParams params{};  // batch fields are filled per call
+    epik_amd::image::Plan plan{};    // kernel, layout and sizes chosen at create()
+    bool team = false;               // the team kernel (one workgroup per read) places; else one wavefront per read
+    int team_waves = 0;
+    const uint8_t *team_table = nullptr;
+    uint32_t team_passes = 0, team_slice_rows = 0, team_rows_pad = 0;
     uint64_t num_keys = 0;
     uint64_t num_entries = 0;
     // launch geometry per count width (epik_amd::CountBits)
@@ -142,92 +147,93 @@ int epik_amd_placer_create(const epik_amd_placer_desc *d, epik_amd_placer **out)
     return epik_amd_placer_create_sharded(d, 0, 1, out);
 }
 
-int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count,
-                                   epik_amd_placer **out)
-{
-    if (!d || !out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
-    *out = nullptr;
-    if (shard_count == 0 || shard_index >= shard_count)
-        return fail(EPIK_AMD_ERR_INVALID, "shard_index must be below shard_count");
-    if (d->abi_version != EPIK_AMD_ABI_VERSION)
-        return fail(EPIK_AMD_ERR_INVALID, "abi_version mismatch");
-    if (d->kmer_size < 1 || d->kmer_size > 32)
-        return fail(EPIK_AMD_ERR_UNSUPPORTED, "kmer_size must be in [1, 32]");
-    if (d->alphabet_size < 2 || d->alphabet_size > 32)
-        return fail(EPIK_AMD_ERR_INVALID, "alphabet_size must be in [2, 32]");
-    if (d->num_branches == 0 || d->num_branches >= (1u << 24))
-        return fail(EPIK_AMD_ERR_INVALID, "num_branches out of range");
-    if (d->num_entries >= (1ull << 40))
-        return fail(EPIK_AMD_ERR_UNSUPPORTED, "more than 2^40 postings");
-    if (d->keep_at_most == 0 || d->keep_at_most > 64)
-        return fail(EPIK_AMD_ERR_UNSUPPORTED, "keep_at_most must be in [1, 64]");
-    if (d->offset_bits != 32 && d->offset_bits != 64)
-        return fail(EPIK_AMD_ERR_INVALID, "offset_bits must be 32 or 64");
-    if (!d->offsets || !d->char_class || (!d->values && d->num_entries))
-        return fail(EPIK_AMD_ERR_INVALID, "null database pointer");
-    // dense key space: num_keys == sigma^k, and codes are 32-bit on the device
+}  // extern "C" (create_impl below is C++)
+
+namespace {
+
+// image::Sink into device memory: bytes go to d_base, front to back, through two pinned staging
+// buffers (the copy of one overlaps the filling of the other).  reserve() cannot fail towards the
+// builder -- after an error it keeps handing out staging memory and finish() reports the error.
+class DeviceSink final : public epik_amd::image::Sink {
+public:
+    static constexpr size_t kStage = 16u << 20;
+    ~DeviceSink() override
     {
-        uint64_t nk = 1;
-        for (uint32_t i = 0; i < d->kmer_size; ++i) {
-            nk *= d->alphabet_size;
-            if (nk > 0xffffffffull) return fail(EPIK_AMD_ERR_UNSUPPORTED, "alphabet_size^kmer_size exceeds 2^32 keys");
+        for (int i = 0; i < 2; ++i) {
+            if (_stage[i]) (void)hipHostFree(_stage[i]);
+            if (_event[i]) (void)hipEventDestroy(_event[i]);
         }
-        if (nk != d->num_keys) return fail(EPIK_AMD_ERR_INVALID, "num_keys != alphabet_size^kmer_size");
     }
-    // offsets must be monotone and end at num_entries (cheap checks of both ends)
+    hipError_t init(uint8_t *d_base, uint64_t total, hipStream_t stream)
     {
-        uint64_t first, last;
-        if (d->offset_bits == 32) {
-            const uint32_t *o = static_cast<const uint32_t *>(d->offsets);
-            first = o[0];
-            last = o[d->num_keys];
-            if (d->num_entries > 0xffffffffull) return fail(EPIK_AMD_ERR_INVALID, "num_entries needs 64-bit offsets");
-        } else {
-            const uint64_t *o = static_cast<const uint64_t *>(d->offsets);
-            first = o[0];
-            last = o[d->num_keys];
+        _base = d_base;
+        _total = total;
+        _stream = stream;
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&_stage[i]), kStage, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            e = hipEventCreateWithFlags(&_event[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
         }
-        if (first != 0 || last != d->num_entries)
-            return fail(EPIK_AMD_ERR_INVALID, "offsets[0] != 0 or offsets[num_keys] != num_entries");
+        return hipSuccess;
+    }
+    uint8_t *reserve(size_t n) override
+    {
+        if (n > kStage) {  // no part of the image is written in pieces this large
+            _overflow = true;
+            n = kStage;
+        }
+        if (_fill + n > kStage) flush();
+        uint8_t *p = _stage[_cur] + _fill;
+        std::memset(p, 0, n);
+        _fill += n;
+        return p;
+    }
+    // everything reserved so far is on its way; returns the first error, checks the size
+    hipError_t finish(bool *size_ok)
+    {
+        flush();
+        const hipError_t e = hipStreamSynchronize(_stream);
+        if (_error == hipSuccess) _error = e;
+        *size_ok = !_overflow && _done == _total;
+        return _error;
     }
 
-    // The lists themselves (host-only checks, before any device is touched): monotone offsets,
-    // lists shorter than 2^24, every branch below num_branches, finite scores, and -- what the kernel's
-    // lane-parallel read-add-write of a list relies on -- no branch twice in one list
-    // (the reference's lists are built per branch, one score each: main.cpp:257).
+private:
+    void flush()
     {
-        const bool o64 = d->offset_bits == 64;
-        auto off = [&](uint64_t key) -> uint64_t {
-            return o64 ? static_cast<const uint64_t *>(d->offsets)[key] : static_cast<const uint32_t *>(d->offsets)[key];
-        };
-        std::vector<uint32_t> seen_in;  // seen_in[b] = 1 + the last list that held branch b
-        try {
-            seen_in.assign(d->num_branches, 0);
-        } catch (const std::bad_alloc &) {
-            return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
+        if (_fill == 0) return;
+        if (_done + _fill > _total) {
+            _overflow = true;  // plan and build disagree: never write past the allocation
+        } else if (_error == hipSuccess) {
+            _error = hipMemcpyAsync(_base + _done, _stage[_cur], _fill, hipMemcpyHostToDevice, _stream);
+            if (_error == hipSuccess) _error = hipEventRecord(_event[_cur], _stream);
+            _used[_cur] = true;
         }
-        uint32_t list_id = 0;
-        for (uint64_t key = 0; key < d->num_keys; ++key) {
-            const uint64_t b = off(key), e = off(key + 1);
-            if (e < b || e > d->num_entries) return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
-            if (e - b >= (1ull << 24)) return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
-            if (e == b) continue;
-            if (++list_id == 0) {  // the list counter wrapped (> 4 G non-empty lists): start a new epoch
-                std::fill(seen_in.begin(), seen_in.end(), 0u);
-                list_id = 1;
-            }
-            for (uint64_t i = b; i < e; ++i) {
-                const uint32_t branch = d->values[i].branch;
-                if (branch >= d->num_branches)
-                    return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
-                if (!std::isfinite(d->values[i].score))  // the kernel marks "no edge" with -inf
-                    return fail(EPIK_AMD_ERR_INVALID, "posting with a non-finite score");
-                if (seen_in[branch] == list_id)
-                    return fail(EPIK_AMD_ERR_INVALID, "a posting list names the same branch twice");
-                seen_in[branch] = list_id;
-            }
-        }
+        _done += _fill;
+        _fill = 0;
+        _cur ^= 1;
+        if (_used[_cur] && _error == hipSuccess) _error = hipEventSynchronize(_event[_cur]);  // its last copy has left
     }
+    uint8_t *_base = nullptr, *_stage[2] = {nullptr, nullptr};
+    hipEvent_t _event[2] = {nullptr, nullptr};
+    bool _used[2] = {false, false};
+    hipStream_t _stream = nullptr;
+    uint64_t _total = 0, _done = 0;
+    size_t _fill = 0;
+    int _cur = 0;
+    bool _overflow = false;
+    hipError_t _error = hipSuccess;
+};
+
+int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count, epik_amd_placer **out)
+{
+    namespace image = epik_amd::image;
+    if (!d || !out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::string err;
+    // everything that needs no device first: argument checks, then the lists themselves
+    if (const int rc = image::validate(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
@@ -237,195 +243,70 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
 
     epik_amd_placer *p = new (std::nothrow) epik_amd_placer();
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
-#define CREATE_TRY(expr)                                  \
-    do {                                                  \
-        const hipError_t e_ = (expr);                     \
-        if (e_ != hipSuccess) {                           \
-            epik_amd_placer_destroy(p);                   \
-            return fail_hip(e_, #expr);                   \
-        }                                                 \
+    struct guard {  // whatever way this function is left before the end, the placer goes with it
+        epik_amd_placer *p;
+        ~guard() { epik_amd_placer_destroy(p); }
+    } owner{p};
+#define CREATE_TRY(expr)                                       \
+    do {                                                       \
+        const hipError_t e_ = (expr);                          \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);      \
     } while (0)
     p->device = d->device;
-    p->offsets64 = d->offset_bits == 64;
     p->num_keys = d->num_keys;
     p->num_entries = d->num_entries;
 
-
-    // LDS rows per wave: the branches + the dummy row that out-of-range lanes of the posting
-    // loads fall on; a multiple of 64 (the epilogue's sweeps).  Postings carry a 16-bit cell =
-    // n_pad - 1 - branch.
-    epik_amd::PlaceParams &pp = p->params;
-    pp.n_pad = (d->num_branches + 1u + 63u) & ~63u;
-    if (pp.n_pad * 8u + (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u > kMaxLdsPerBlock) {  // the 32-bit-count kernels
-        epik_amd_placer_destroy(p);
-        return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
-    }
-
-    // ---- choose the HBM layout ---------------------------------------------------------
-    //  packed : an 8-byte {len, line} entry per k-mer code + every list on 128-byte lines of its own;
-    //  paired : the same lists behind a table keyed by the (k-1)-mer that two consecutive k-mers of
-    //           a read share: one table line per two lookups, 16 bytes per code; 4-letter alphabets
-    //           only (place_kernel.hip: PackedLayout<true>) -- the default for them;
-    //  compact: the CSR (4- or 8-byte offsets), 8-byte postings back to back.
-    // paired / packed are chosen when the table is at most a quarter of the device's free memory;
-    //  filtered: packed behind a presence filter keyed like the paired table: chosen for the other
-    //           alphabets when at most a quarter of the codes have a list (for 4 letters it measures
-    //           the same as paired, sparse or not);
-    // EPIK_AMD_LAYOUT=compact|packed|paired|filtered overrides (paired means filtered for other alphabets).
+    // ---- kernel + layout (db_image.cpp), then the image, streamed into HBM -----------------------------
     size_t free_mem = 0, total_mem = 0;
     CREATE_TRY(hipMemGetInfo(&free_mem, &total_mem));
-    const char *lay = std::getenv("EPIK_AMD_LAYOUT");
-    if (lay && std::strcmp(lay, "compact") != 0 && std::strcmp(lay, "packed") != 0 && std::strcmp(lay, "paired") != 0 &&
-        std::strcmp(lay, "filtered") != 0) {
-        epik_amd_placer_destroy(p);
-        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed, paired or filtered");
+    const image::Source src{d, shard_index, shard_count};
+    image::Plan &plan = p->plan;
+    if (const int rc = image::make_plan(src, free_mem, std::getenv("EPIK_AMD_LAYOUT"), std::getenv("EPIK_AMD_KERNEL"),
+                                        plan, err);
+        rc != EPIK_AMD_OK) {
+        return fail(rc, err);
     }
-    // filtered: one presence word per (k-1)-mer (2 * sigma bits) in front of the packed table, when
-    // few codes have a list: then most lookups end at the filter, two per fetched line
-    uint64_t present_codes = 0;
-    for (uint64_t key = 0; key < d->num_keys; ++key)
-        present_codes += (p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key + 1] != static_cast<const uint64_t *>(d->offsets)[key]
-                                       : static_cast<const uint32_t *>(d->offsets)[key + 1] != static_cast<const uint32_t *>(d->offsets)[key]);
-    const bool sparse = present_codes * 4u <= d->num_keys;
-    const bool can_pair = d->alphabet_size == 4, can_filter = d->alphabet_size <= 32;
-    const bool table_fits = d->num_keys * 16u <= free_mem / 4;
-    bool paired = false, filtered = false, packed = false;
-    if (lay) {
-        filtered = can_filter && (std::strcmp(lay, "filtered") == 0 || (!can_pair && std::strcmp(lay, "paired") == 0));
-        paired = can_pair && std::strcmp(lay, "paired") == 0;
-        packed = paired || filtered || std::strcmp(lay, "compact") != 0;
-    } else if (table_fits) {
-        paired = can_pair;  // for 4 letters the paired table already reads one line per two lookups
-        filtered = !paired && can_filter && sparse;
-        packed = true;
-    }
-    auto offset_at = [&](uint64_t key) -> uint64_t {
-        return p->offsets64 ? static_cast<const uint64_t *>(d->offsets)[key]
-                            : static_cast<const uint32_t *>(d->offsets)[key];
-    };
-    // k-mer-space shard: this placer keeps the lists of the codes with code % count == index
-    auto kept_len = [&](uint64_t key) -> uint64_t {
-        return (shard_count == 1 || key % shard_count == shard_index) ? offset_at(key + 1) - offset_at(key) : 0;
-    };
-    uint64_t lines = 0;  // packed: 128-byte lines of the posting region
-    uint64_t kept_entries = 0;
-    for (uint64_t key = 0; key < d->num_keys; ++key) {
-        const uint64_t len = kept_len(key);
-        kept_entries += len;
-        lines += (len * 6u + 127u) / 128u;
-    }
-    if (packed && lines >= (1ull << 32)) {
-        epik_amd_placer_destroy(p);
-        return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
-    }
+    p->layout = plan.layout;
+    p->team = plan.layout == epik_amd::DbLayout::kTeam;
+    p->db_bytes = plan.posting_bytes;
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream_in, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&p->stream_out, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&p->d_table, plan.table_bytes));
+    if (plan.filter_bytes) CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_filter), plan.filter_bytes));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_postings), plan.posting_bytes));
     {
-        // +512: room behind the last list (descriptors are exact, nothing reads it)
-        p->db_bytes = (packed ? lines * 128u : kept_entries * 8u) + 512u;
-        std::vector<uint8_t> host;
-        std::vector<uint32_t> table;  // packed: {len, line} per code
-        try {
-            host.assign(p->db_bytes, 0);
-            if (packed) table.assign(d->num_keys * (paired ? 4 : 2), 0);
-        } catch (const std::bad_alloc &) {
-            epik_amd_placer_destroy(p);
-            return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the device database");
+        DeviceSink table, filter, postings;
+        CREATE_TRY(table.init(static_cast<uint8_t *>(p->d_table), plan.table_bytes, p->stream_in));
+        if (plan.filter_bytes)
+            CREATE_TRY(filter.init(reinterpret_cast<uint8_t *>(p->d_filter), plan.filter_bytes, p->stream_out));
+        CREATE_TRY(postings.init(p->d_postings, plan.posting_bytes, p->stream));
+        const int rc = image::build(src, plan, table, plan.filter_bytes ? &filter : nullptr, postings, err);
+        bool ok_t = true, ok_f = true, ok_p = true;
+        const hipError_t e_t = table.finish(&ok_t);
+        const hipError_t e_f = plan.filter_bytes ? filter.finish(&ok_f) : hipSuccess;
+        const hipError_t e_p = postings.finish(&ok_p);
+        if (rc != EPIK_AMD_OK) {
+            return fail(rc, err);
         }
-        const uint32_t top = pp.n_pad - 1u;
-        // packed: one list = chunks of <= 64 postings, each chunk f32 score[cnt] then u16 cell[cnt]
-        auto write_list = [&](uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len) {
-            for (uint64_t c0 = 0; c0 < len; c0 += 64) {
-                const uint32_t cnt = (uint32_t)((len - c0 < 64) ? len - c0 : 64);
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    const uint16_t cell = (uint16_t)(top - src[c0 + j].branch);
-                    std::memcpy(dst + 4u * j, &src[c0 + j].score, 4);
-                    std::memcpy(dst + 4u * cnt + 2u * j, &cell, 2);
-                }
-                dst += (size_t)cnt * 6u;
-            }
-        };
-        if (packed) {
-            p->layout = paired     ? epik_amd::DbLayout::kPaired
-                        : filtered ? epik_amd::DbLayout::kFiltered
-                                   : epik_amd::DbLayout::kPacked;
-            // paired: the entry of code c = a.X = Y.b (X its last k-1 letters, Y its first k-1) is stored
-            // in block X at slot a and in block Y at slot 4 + b; a block is 8 entries
-            const uint32_t shift = 2u * d->kmer_size - 2u;
-            uint64_t line = 0;
-            for (uint64_t key = 0; key < d->num_keys; ++key) {
-                const uint64_t b = offset_at(key), len = kept_len(key);
-                if (paired) {
-                    const uint64_t as_suffix = ((key & ((1ull << shift) - 1ull)) * 8u + (key >> shift)) * 2u;
-                    const uint64_t as_prefix = ((key >> 2) * 8u + 4u + (key & 3u)) * 2u;
-                    table[as_suffix] = table[as_prefix] = (uint32_t)len;
-                    table[as_suffix + 1] = table[as_prefix + 1] = (uint32_t)line;
-                } else {
-                    table[2 * key] = (uint32_t)len;
-                    table[2 * key + 1] = (uint32_t)line;
-                }
-                write_list(host.data() + line * 128u, d->values + b, len);
-                line += (len * 6u + 127u) / 128u;
-            }
-            CREATE_TRY(hipMalloc(&p->d_table, table.size() * 4u + 8u));
-            CREATE_TRY(hipMemcpy(p->d_table, table.data(), table.size() * 4u, hipMemcpyHostToDevice));
-            if (filtered) {
-                // filter[X], X a (k-1)-mer: bit a <=> code a.X has a list, bit sigma + b <=> code X.b has one
-                const uint64_t sigma = d->alphabet_size, blocks = d->num_keys / sigma;  // sigma^(k-1)
-                std::vector<uint64_t> filter;
-                try {
-                    filter.assign(blocks, 0);
-                } catch (const std::bad_alloc &) {
-                    epik_amd_placer_destroy(p);
-                    return fail(EPIK_AMD_ERR_INVALID, "out of host memory building the presence filter");
-                }
-                for (uint64_t key = 0; key < d->num_keys; ++key) {
-                    if (kept_len(key) == 0) continue;
-                    filter[key % blocks] |= 1ull << (key / blocks);          // as a.X: X = its last k-1 letters
-                    filter[key / sigma] |= 1ull << (sigma + key % sigma);    // as X.b: X = its first k-1 letters
-                }
-                CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_filter), blocks * 8u));
-                CREATE_TRY(hipMemcpy(p->d_filter, filter.data(), blocks * 8u, hipMemcpyHostToDevice));
-                pp.filter = p->d_filter;
-            }
-        } else {
-            p->layout = p->offsets64 ? epik_amd::DbLayout::kCompact64 : epik_amd::DbLayout::kCompact32;
-            // the kept lists back to back as {f32 score, u32 cell}; with one shard the offsets
-            // are the caller's, otherwise they are rebuilt over the kept lists
-            std::vector<uint8_t> own_offsets;
-            const size_t off_bytes = (size_t)(d->num_keys + 1) * (p->offsets64 ? 8 : 4);
-            if (shard_count > 1) own_offsets.assign(off_bytes, 0);
-            uint64_t at = 0;
-            for (uint64_t key = 0; key < d->num_keys; ++key) {
-                const uint64_t b = offset_at(key), len = kept_len(key);
-                for (uint64_t j = 0; j < len; ++j, ++at) {
-                    const uint32_t cell = top - d->values[b + j].branch;
-                    std::memcpy(host.data() + 8u * at, &d->values[b + j].score, 4);
-                    std::memcpy(host.data() + 8u * at + 4u, &cell, 4);
-                }
-                if (shard_count > 1) {
-                    if (p->offsets64)
-                        reinterpret_cast<uint64_t *>(own_offsets.data())[key + 1] = at;
-                    else
-                        reinterpret_cast<uint32_t *>(own_offsets.data())[key + 1] = (uint32_t)at;
-                }
-            }
-            CREATE_TRY(hipMalloc(&p->d_table, off_bytes));
-            CREATE_TRY(hipMemcpy(p->d_table, shard_count > 1 ? static_cast<const void *>(own_offsets.data()) : d->offsets,
-                                 off_bytes, hipMemcpyHostToDevice));
+        CREATE_TRY(e_t);
+        CREATE_TRY(e_f);
+        CREATE_TRY(e_p);
+        if (!ok_t || !ok_f || !ok_p) {
+            return fail(EPIK_AMD_ERR_INVALID, "internal: the database image does not have the planned size");
         }
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_postings), p->db_bytes));
-        CREATE_TRY(hipMemcpy(p->d_postings, host.data(), p->db_bytes, hipMemcpyHostToDevice));
-        pp.table = p->d_table;
-        pp.postings = p->d_postings;
     }
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_char_class), 256 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_total), sizeof(unsigned long long)));
     CREATE_TRY(hipMemcpy(p->d_char_class, d->char_class, 256 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    CREATE_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipStreamCreateWithFlags(&p->stream_in, hipStreamNonBlocking));
-    CREATE_TRY(hipStreamCreateWithFlags(&p->stream_out, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&p->ev_start));
     CREATE_TRY(hipEventCreate(&p->ev_stop));
 
+    epik_amd::PlaceParams &pp = p->params;
+    pp.n_pad = plan.n_pad;
+    pp.table = p->d_table;
+    pp.filter = p->d_filter;
+    pp.postings = p->d_postings;
     pp.char_class = p->d_char_class;
     pp.sigma_pow_km1 = (uint32_t)(d->num_keys / d->alphabet_size);
     pp.kmer_size = d->kmer_size;
@@ -444,46 +325,73 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
 #endif
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, d->device));
-    for (int counts = 0; counts < 3; ++counts) {
-        auto &g = p->geo[counts];
-        // per wave: float32 scores + 8/16/32-bit counts + the chunk descriptors of one round
-        // + one trip of spare entries (the kernel prefetches a trip ahead)
-        const uint32_t desc_bytes = (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
-        g.lds_wave_bytes = (pp.n_pad * (4u + (1u << counts)) + desc_bytes + 15u) & ~15u;
-        if (counts == epik_amd::kCounts8 && (pp.n_pad + 7u) / 8u > desc_bytes) {
-            g.max_blocks = 0;  // the 8-bit kernel keeps one flag bit per row in the descriptor area: no room
-            continue;
+    if (p->team) {
+        // ---- team kernel: one workgroup of W waves per read (team_kernel.hip) -------------------------
+        p->team_waves = plan.team_waves;
+        p->team_table = static_cast<const uint8_t *>(p->d_table);
+        p->team_passes = plan.team_passes;
+        p->team_slice_rows = plan.team_slice_rows;
+        p->team_rows_pad = plan.team_rows_pad;
+        const uint32_t desc_bytes = epik_amd::team_desc_bytes(d->keep_at_most);
+        for (int counts = 0; counts < 3; ++counts) {
+            auto &g = p->geo[counts];
+            g.waves_per_block = (uint32_t)plan.team_waves;
+            g.lds_wave_bytes = epik_amd::team_slice_bytes(plan.team_rows_pad, counts);
+            g.lds_block_bytes = (uint32_t)epik_amd::team_lds_bytes(plan.team_waves, plan.team_passes, g.lds_wave_bytes,
+                                                                   desc_bytes, d->keep_at_most);
+            g.max_blocks = 0;
+            // the 8-bit kernel keeps one "seen" bit per row in the slice's descriptor list
+            if (counts == epik_amd::kCounts8 && (plan.team_rows_pad + 7u) / 8u > desc_bytes) continue;
+            uint32_t per_cu = epik_amd::team_resident_blocks(plan.team_waves, g.lds_block_bytes);
+            if (per_cu == 0) continue;  // (make_plan made sure the 32-bit counts fit; narrower ones then do too)
+            CREATE_TRY(epik_amd::set_team_lds_limit(plan.team_waves, counts, g.lds_block_bytes));
+            int by_query = 0;
+            CREATE_TRY(epik_amd::team_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
+            per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(per_cu, (uint32_t)std::max(by_query, 1)));
+            g.max_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
+            g.resident_waves = per_cu * (uint32_t)plan.team_waves;
         }
-        if (g.lds_wave_bytes > kMaxLdsPerBlock) {
-            epik_amd_placer_destroy(p);
-            return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the LDS-resident score vector");
-        }
-        // Workgroup of 4, 2 or 1 independent waves: whichever keeps the most waves resident on a
-        // CU (ties: the larger workgroup).  LDS is handed out in units of 1280 bytes (160 KiB / 128;
-        // measured: 5 x 32512 B did not fit a CU, 5 x 30976 B do), which the occupancy query does not
-        // know -- and a workgroup that is not resident with the others runs behind them: with this
-        // kernel's fixed stride over the reads that doubles the launch time.  The grid is exactly the
-        // resident workgroups (registers, LDS and the waves-per-CU cap decide), each striding over the reads.
-        uint32_t best_waves = 0;
-        for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
-            const uint32_t block_bytes = wpb * g.lds_wave_bytes;
-            if (block_bytes > kMaxLdsPerBlock) continue;
-            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, block_bytes));
-            int per_cu = 0;
-            CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, counts, (int)(wpb * 64u), block_bytes, &per_cu));
-            const uint32_t lds_units = (block_bytes + 1279u) / 1280u;
-            per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
-            if (per_cu < 1) per_cu = 1;
-            if ((uint32_t)per_cu * wpb > best_waves) {
-                best_waves = (uint32_t)per_cu * wpb;
-                g.waves_per_block = wpb;
-                g.lds_block_bytes = block_bytes;
-                g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    } else {
+        for (int counts = 0; counts < 3; ++counts) {
+            auto &g = p->geo[counts];
+            // per wave: float32 scores + 8/16/32-bit counts + the chunk descriptors of one round
+            // + one trip of spare entries (the kernel prefetches a trip ahead)
+            const uint32_t desc_bytes = epik_amd::kWaveDescBytes;
+            g.lds_wave_bytes = epik_amd::wave_lds_bytes(pp.n_pad, counts);
+            if (counts == epik_amd::kCounts8 && (pp.n_pad + 7u) / 8u > desc_bytes) {
+                g.max_blocks = 0;  // the 8-bit kernel keeps one flag bit per row in the descriptor area: no room
+                continue;
             }
+            if (g.lds_wave_bytes > kMaxLdsPerBlock) {
+                return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the one-wavefront-per-read kernel");
+            }
+            // Workgroup of 4, 2 or 1 independent waves: whichever keeps the most waves resident on a
+            // CU (ties: the larger workgroup).  LDS is handed out in units of 1280 bytes (160 KiB / 128;
+            // measured: 5 x 32512 B did not fit a CU, 5 x 30976 B do), which the occupancy query does not
+            // know -- and a workgroup that is not resident with the others runs behind them: with this
+            // kernel's fixed stride over the reads that doubles the launch time.  The grid is exactly the
+            // resident workgroups (registers, LDS and the waves-per-CU cap decide), each striding over the reads.
+            uint32_t best_waves = 0;
+            for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
+                const uint32_t block_bytes = wpb * g.lds_wave_bytes;
+                if (block_bytes > kMaxLdsPerBlock) continue;
+                CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, block_bytes));
+                int per_cu = 0;
+                CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, counts, (int)(wpb * 64u), block_bytes, &per_cu));
+                const uint32_t lds_units = (block_bytes + epik_amd::kLdsGranule - 1u) / epik_amd::kLdsGranule;
+                per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
+                if (per_cu < 1) per_cu = 1;
+                if ((uint32_t)per_cu * wpb > best_waves) {
+                    best_waves = (uint32_t)per_cu * wpb;
+                    g.waves_per_block = wpb;
+                    g.lds_block_bytes = block_bytes;
+                    g.max_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+                }
+            }
+            g.resident_waves = best_waves;
+            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, g.lds_block_bytes));
+            CREATE_TRY(epik_amd::set_finish_reads_lds_limit(counts, g.lds_block_bytes));
         }
-        g.resident_waves = best_waves;
-        CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, g.lds_block_bytes));
-        CREATE_TRY(epik_amd::set_finish_reads_lds_limit(counts, g.lds_block_bytes));
     }
     // EPIK_AMD_WIDE_COUNTS=0|1|2: 16-, 32-, 8-bit counts whatever the reads (tests, experiments)
     if (const char *w = std::getenv("EPIK_AMD_WIDE_COUNTS")) {
@@ -493,8 +401,105 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard
     }
 #undef CREATE_TRY
 
+    owner.p = nullptr;
     *out = p;
     return EPIK_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int epik_amd_placer_create_sharded(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count,
+                                   epik_amd_placer **out)
+{
+    try {  // std::string, std::vector: nothing may leave through the C ABI
+        return create_impl(d, shard_index, shard_count, out);
+    } catch (const std::exception &e) {
+        return fail(EPIK_AMD_ERR_INVALID, std::string("create: ") + e.what());
+    }
+}
+
+// ---- capacity planning and the image itself, on the host (no device) ---------------------------------
+namespace {
+// image::Sink into a host buffer (or nowhere): epik_amd_placer_build_image
+class HostSink final : public epik_amd::image::Sink {
+public:
+    HostSink(void *dst, uint64_t total) : _dst(static_cast<uint8_t *>(dst)), _total(total) {}
+    uint8_t *reserve(size_t n) override
+    {
+        uint8_t *p;
+        if (_dst && _done + n <= _total) {
+            p = _dst + _done;
+        } else {  // dropped (or, after a size mismatch, kept off the caller's buffer)
+            if (_scratch.size() < n) _scratch.resize(n);
+            p = _scratch.data();
+        }
+        std::memset(p, 0, n);
+        _done += n;
+        return p;
+    }
+    bool size_ok() const { return _done == _total; }
+
+private:
+    uint8_t *_dst;
+    uint64_t _total, _done = 0;
+    std::vector<uint8_t> _scratch;
+};
+}  // namespace
+
+int epik_amd_placer_plan(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count,
+                         uint64_t free_bytes, epik_amd_plan *out)
+{
+    namespace image = epik_amd::image;
+    if (!out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    try {
+        std::string err;
+        if (const int rc = image::validate(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
+        image::Plan plan;
+        if (const int rc = image::make_plan(image::Source{d, shard_index, shard_count}, (size_t)free_bytes,
+                                            std::getenv("EPIK_AMD_LAYOUT"), std::getenv("EPIK_AMD_KERNEL"), plan, err);
+            rc != EPIK_AMD_OK)
+            return fail(rc, err);
+        *out = epik_amd_plan{};
+        out->kernel = plan.layout == epik_amd::DbLayout::kTeam ? 1u : 0u;
+        out->layout = (uint32_t)plan.layout;
+        out->team_waves = (uint32_t)plan.team_waves;
+        out->team_passes = plan.team_passes;
+        out->slice_rows = plan.team_slice_rows;
+        for (int c = 0; c < 3; ++c) out->resident_waves[c] = plan.wave_resident[c];
+        out->table_bytes = plan.table_bytes;
+        out->filter_bytes = plan.filter_bytes;
+        out->posting_bytes = plan.posting_bytes;
+        out->kept_entries = plan.kept_entries;
+        return EPIK_AMD_OK;
+    } catch (const std::exception &e) {
+        return fail(EPIK_AMD_ERR_INVALID, std::string("plan: ") + e.what());
+    }
+}
+
+int epik_amd_placer_build_image(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count,
+                                uint64_t free_bytes, void *table, void *filter, void *postings)
+{
+    namespace image = epik_amd::image;
+    try {
+        std::string err;
+        if (const int rc = image::validate(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
+        image::Plan plan;
+        const image::Source src{d, shard_index, shard_count};
+        if (const int rc = image::make_plan(src, (size_t)free_bytes, std::getenv("EPIK_AMD_LAYOUT"),
+                                            std::getenv("EPIK_AMD_KERNEL"), plan, err);
+            rc != EPIK_AMD_OK)
+            return fail(rc, err);
+        HostSink t(table, plan.table_bytes), f(filter, plan.filter_bytes), ps(postings, plan.posting_bytes);
+        if (const int rc = image::build(src, plan, t, plan.filter_bytes ? &f : nullptr, ps, err); rc != EPIK_AMD_OK)
+            return fail(rc, err);
+        if (!t.size_ok() || !ps.size_ok() || (plan.filter_bytes && !f.size_ok()))
+            return fail(EPIK_AMD_ERR_INVALID, "internal: the database image does not have the planned size");
+        return EPIK_AMD_OK;
+    } catch (const std::exception &e) {
+        return fail(EPIK_AMD_ERR_INVALID, std::string("build_image: ") + e.what());
+    }
 }
 
 // The narrowest counts that hold the k-mers of a read of `longest` characters, 8 bits only when
@@ -508,14 +513,28 @@ static int counts_for(const epik_amd_placer *p, uint64_t longest)
     return epik_amd::kCounts16;
 }
 
-static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets, uint64_t n,
-                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream,
-                  float *partial_scores = nullptr, uint32_t *partial_counts = nullptr)
+// What a launch works on besides the read batch: the partial vectors of a k-mer-space shard
+// (accumulate writes them, finish reads them) and the records of the reads' ambiguous k-mers.
+struct shard_buffers {
+    float *scores = nullptr;
+    uint16_t *counts = nullptr;
+    const int32_t *amb_slot = nullptr;
+    uint32_t *amb_order = nullptr;
+    float *amb_avg = nullptr;
+};
+enum launch_mode { kPlace = epik_amd::kTeamModePlace, kAccumulate = epik_amd::kTeamModeAccumulate,
+                   kFinish = epik_amd::kTeamModeFinish };
+
+static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, const void *d_seq_offsets, uint64_t n,
+                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream, const shard_buffers &shard = {})
 {
     if (n == 0) return EPIK_AMD_OK;
     epik_amd::PlaceParams pp = p->params;
-    pp.partial_scores = partial_scores;  // non-null: accumulate only
-    pp.partial_counts = partial_counts;
+    pp.partial_scores = shard.scores;  // non-null in the placement kernels: accumulate only
+    pp.partial_counts = shard.counts;
+    pp.amb_slot = shard.amb_slot;
+    pp.amb_order = shard.amb_order;
+    pp.amb_avg = shard.amb_avg;
     pp.seqs = static_cast<const uint8_t *>(d_seqs);
     pp.seq_offsets = static_cast<const uint64_t *>(d_seq_offsets);
     pp.n_reads = n;
@@ -523,15 +542,36 @@ static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offs
     pp.n_rows = static_cast<uint32_t *>(d_n_rows);
     pp.kmer_counts = static_cast<uint32_t *>(d_counts);
     const auto &g = p->geo[p->counts];
+    if (g.max_blocks == 0) return fail(EPIK_AMD_ERR_UNSUPPORTED, "no kernel of this count width for this tree size");
     pp.lds_wave_bytes = g.lds_wave_bytes;
-    uint64_t blocks = (n + g.waves_per_block - 1) / g.waves_per_block;
+    // the team kernel places one read per workgroup, the others one per wave
+    uint64_t blocks = p->team ? n : (n + g.waves_per_block - 1) / g.waves_per_block;
     if (blocks > g.max_blocks) blocks = g.max_blocks;
     p->last_blocks = (uint32_t)blocks;
     p->last_geo = (uint32_t)p->counts;
-    if (p->timing) HIP_TRY(hipEventRecord(p->ev_start, stream));
-    HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->counts, dim3((unsigned)blocks),
-                                         dim3(g.waves_per_block * 64u), g.lds_block_bytes, stream));
-    if (p->timing) {
+    const bool timed = p->timing && mode != kFinish;
+    if (timed) HIP_TRY(hipEventRecord(p->ev_start, stream));
+    if (p->team) {
+        epik_amd::TeamParams tp{};
+        tp.base = pp;
+        tp.team_table = p->team_table;
+        tp.num_keys = p->num_keys;
+        tp.passes = p->team_passes;
+        tp.slice_rows = p->team_slice_rows;
+        tp.rows_pad = p->team_rows_pad;
+        tp.desc_cap = epik_amd::kTeamDescCap;
+        tp.slice_bytes = g.lds_wave_bytes;
+        tp.desc_bytes = epik_amd::team_desc_bytes(pp.keep_at_most);
+        HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,
+                                      stream));
+    } else if (mode == kFinish) {
+        HIP_TRY(epik_amd::launch_finish_reads(pp, p->counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
+                                              g.lds_block_bytes, stream));
+    } else {
+        HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->counts, dim3((unsigned)blocks),
+                                             dim3(g.waves_per_block * 64u), g.lds_block_bytes, stream));
+    }
+    if (timed) {
         HIP_TRY(hipEventRecord(p->ev_stop, stream));
         p->ev_recorded = true;
     }
@@ -539,40 +579,43 @@ static int launch(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offs
 }
 
 int epik_amd_placer_accumulate_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
-                                      uint64_t n, void *d_scores, void *d_counts, void *stream)
+                                      uint64_t n, void *d_scores, void *d_counts, const void *d_amb_slot,
+                                      void *d_amb_order, void *d_amb_avg, void *stream)
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
     if (n && (!d_seqs || !d_seq_offsets || !d_scores || !d_counts))
         return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    if (d_amb_slot && (!d_amb_order || !d_amb_avg))
+        return fail(EPIK_AMD_ERR_INVALID, "d_amb_slot without d_amb_order / d_amb_avg");
     HIP_TRY(hipSetDevice(p->device));
-    return launch(p, d_seqs, d_seq_offsets, n, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream),
-                  static_cast<float *>(d_scores), static_cast<uint32_t *>(d_counts));
+    shard_buffers shard;
+    shard.scores = static_cast<float *>(d_scores);
+    shard.counts = static_cast<uint16_t *>(d_counts);
+    shard.amb_slot = static_cast<const int32_t *>(d_amb_slot);
+    shard.amb_order = static_cast<uint32_t *>(d_amb_order);
+    shard.amb_avg = static_cast<float *>(d_amb_avg);
+    return launch(p, kAccumulate, d_seqs, d_seq_offsets, n, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream),
+                  shard);
 }
 
 int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets, uint64_t n,
-                                  const void *d_scores, const void *d_counts, void *d_rows, void *d_n_rows,
-                                  void *d_kmer_counts, void *stream)
+                                  const void *d_scores, const void *d_counts, const void *d_amb_slot,
+                                  const void *d_amb_avg, void *d_rows, void *d_n_rows, void *d_kmer_counts,
+                                  void *stream)
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
     if (n == 0) return EPIK_AMD_OK;
     if (!d_seq_offsets || !d_scores || !d_counts || !d_rows || !d_n_rows)
         return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    if (d_amb_slot && !d_amb_avg) return fail(EPIK_AMD_ERR_INVALID, "d_amb_slot without d_amb_avg");
     HIP_TRY(hipSetDevice(p->device));
-    epik_amd::PlaceParams pp = p->params;
-    pp.seq_offsets = static_cast<const uint64_t *>(d_seq_offsets);
-    pp.n_reads = n;
-    pp.rows = static_cast<epik_amd_placement *>(d_rows);
-    pp.n_rows = static_cast<uint32_t *>(d_n_rows);
-    pp.kmer_counts = static_cast<uint32_t *>(d_kmer_counts);
-    pp.partial_scores = const_cast<float *>(static_cast<const float *>(d_scores));
-    pp.partial_counts = const_cast<uint32_t *>(static_cast<const uint32_t *>(d_counts));
-    const auto &g = p->geo[p->counts];
-    pp.lds_wave_bytes = g.lds_wave_bytes;
-    uint64_t blocks = (n + g.waves_per_block - 1) / g.waves_per_block;
-    if (blocks > g.max_blocks) blocks = g.max_blocks;
-    HIP_TRY(epik_amd::launch_finish_reads(pp, p->counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
-                                          g.lds_block_bytes, static_cast<hipStream_t>(stream)));
-    return EPIK_AMD_OK;
+    shard_buffers shard;
+    shard.scores = const_cast<float *>(static_cast<const float *>(d_scores));
+    shard.counts = const_cast<uint16_t *>(static_cast<const uint16_t *>(d_counts));
+    shard.amb_slot = static_cast<const int32_t *>(d_amb_slot);
+    shard.amb_avg = const_cast<float *>(static_cast<const float *>(d_amb_avg));
+    return launch(p, kFinish, nullptr, d_seq_offsets, n, d_rows, d_n_rows, d_kmer_counts,
+                  static_cast<hipStream_t>(stream), shard);
 }
 
 int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
@@ -583,7 +626,7 @@ int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const v
     if (n && (!d_seqs || !d_seq_offsets || !d_rows || !d_n_rows))
         return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
     HIP_TRY(hipSetDevice(p->device));
-    return launch(p, d_seqs, d_seq_offsets, n, d_rows, d_n_rows, d_kmer_counts,
+    return launch(p, kPlace, d_seqs, d_seq_offsets, n, d_rows, d_n_rows, d_kmer_counts,
                   static_cast<hipStream_t>(stream));
 }
 
@@ -597,9 +640,27 @@ static uint64_t host_chunk_reads(uint64_t n, size_t seq_bytes)
     return std::max<uint64_t>((n + chunks - 1) / chunks, 1);
 }
 
+static int place_impl(epik_amd_placer *p, const char *seqs, const uint64_t *seq_offsets, uint64_t n,
+                      epik_amd_placement *rows, uint32_t *n_rows, uint32_t *kmer_counts);
+
 int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *seq_offsets,
                           uint64_t n, epik_amd_placement *rows, uint32_t *n_rows,
                           uint32_t *kmer_counts)
+{
+    try {  // std::thread, std::vector: nothing may leave through the C ABI
+        return place_impl(p, seqs, seq_offsets, n, rows, n_rows, kmer_counts);
+    } catch (const std::exception &e) {
+        if (p) {
+            (void)hipStreamSynchronize(p->stream_in);
+            (void)hipStreamSynchronize(p->stream);
+            (void)hipStreamSynchronize(p->stream_out);
+        }
+        return fail(EPIK_AMD_ERR_INVALID, std::string("place: ") + e.what());
+    }
+}
+
+static int place_impl(epik_amd_placer *p, const char *seqs, const uint64_t *seq_offsets, uint64_t n,
+                      epik_amd_placement *rows, uint32_t *n_rows, uint32_t *kmer_counts)
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
     if (n == 0) return EPIK_AMD_OK;
@@ -656,11 +717,16 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
     const size_t keep = p->params.keep_at_most;
     const uint64_t per_chunk = host_chunk_reads(n, seq_bytes);
     const uint64_t n_chunks = (n + per_chunk - 1) / per_chunk;
-    while (p->ev_in.size() < n_chunks) {
+    p->ev_in.reserve(n_chunks);  // (may throw: caught at the boundary below)
+    p->ev_kernel.reserve(n_chunks);
+    while (p->ev_in.size() < n_chunks) {  // the two vectors always grow together
         hipEvent_t a = nullptr, b = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        if (const hipError_t e = hipEventCreateWithFlags(&b, hipEventDisableTiming); e != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return fail_hip(e, "hipEventCreateWithFlags");
+        }
         p->ev_in.push_back(a);
-        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         p->ev_kernel.push_back(b);
     }
     std::atomic<uint64_t> launched{0};
@@ -710,7 +776,7 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
             in_err = e;
             break;
         }
-        rc = launch(p, p->d_seqs, p->d_seq_offsets + r0, cnt, p->d_rows + r0 * keep, p->d_n_rows + r0,
+        rc = launch(p, kPlace, p->d_seqs, p->d_seq_offsets + r0, cnt, p->d_rows + r0 * keep, p->d_n_rows + r0,
                     p->d_counts + r0 * keep, p->stream);
         if (rc != EPIK_AMD_OK) break;
         e = hipEventRecord(p->ev_kernel[c], p->stream);
@@ -725,8 +791,10 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
         copy_out.join();
     else
         copy_out_fn();
+    // whatever happened, nothing of this call may still be writing into the caller's buffers on return
     (void)hipStreamSynchronize(p->stream_in);
     (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamSynchronize(p->stream_out);
     if (rc != EPIK_AMD_OK) return rc;
     if (in_err != hipSuccess) return fail_hip(in_err, "copy-in / launch of the host-buffer pipeline");
     if (out_err != hipSuccess) return fail_hip(out_err, "copy-out of the host-buffer pipeline");
@@ -748,7 +816,16 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
     pp.n_reads = n;
     pp.n_rows = const_cast<uint32_t *>(static_cast<const uint32_t *>(d_n_rows));
     HIP_TRY(hipMemsetAsync(p->d_total, 0, sizeof(unsigned long long), s));
-    HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->layout, p->d_total, s));
+    if (p->team) {
+        epik_amd::TeamParams tp{};
+        tp.base = pp;
+        tp.team_table = p->team_table;
+        tp.num_keys = p->num_keys;
+        tp.passes = p->team_passes;
+        HIP_TRY(epik_amd::launch_team_algorithmic_bytes(tp, p->team_waves, p->d_total, s));
+    } else {
+        HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->layout, p->d_total, s));
+    }
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, p->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

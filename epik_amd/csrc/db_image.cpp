@@ -1,0 +1,419 @@
+// db_image.cpp -- see db_image.hpp.
+#include "db_image.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace epik_amd::image {
+
+namespace {
+
+// Fixed-size records into a Sink, a batch at a time (one virtual call per 64 KiB, not per record).
+class RecordWriter {
+public:
+    RecordWriter(Sink &sink, size_t record_bytes, uint64_t total_records)
+        : _sink(sink), _record(record_bytes), _left(total_records) {}
+    uint8_t *next()
+    {
+        if (_at == _end) {
+            const uint64_t n = std::min<uint64_t>(_left, std::max<size_t>(1, (64u << 10) / _record));
+            _at = _sink.reserve((size_t)n * _record);
+            _end = _at + (size_t)n * _record;
+            _left -= n;
+        }
+        uint8_t *r = _at;
+        _at += _record;
+        return r;
+    }
+
+private:
+    Sink &_sink;
+    size_t _record;
+    uint64_t _left;
+    uint8_t *_at = nullptr, *_end = nullptr;
+};
+
+inline void put_u32(uint8_t *dst, uint32_t v) { std::memcpy(dst, &v, 4); }
+
+// One list of the packed layouts: chunks of <= 64 postings, each f32 score[cnt] then u16 cell[cnt]
+// with cell = top - branch (top = the dummy row's cell 0 seen from the other end).
+void write_chunks(uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len, uint32_t top)
+{
+    for (uint64_t c0 = 0; c0 < len; c0 += 64) {
+        const uint32_t cnt = (uint32_t)((len - c0 < 64) ? len - c0 : 64);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint16_t cell = (uint16_t)(top - src[c0 + j].branch);
+            std::memcpy(dst + 4u * j, &src[c0 + j].score, 4);
+            std::memcpy(dst + 4u * cnt + 2u * j, &cell, 2);
+        }
+        dst += (size_t)cnt * 6u;
+    }
+}
+
+inline uint64_t packed_lines(uint64_t len) { return (len * 6u + 127u) / 128u; }
+inline uint32_t pad4(uint32_t bytes) { return (bytes + 3u) & ~3u; }
+
+struct TeamChoice {
+    int waves = 0;
+    uint32_t passes = 0, slice_rows = 0, rows_pad = 0, resident = 0;
+};
+
+// (W, P) of the team kernel for a tree of `n` branches: most resident waves per CU with 16-bit
+// counts, then fewer passes, then fewer waves; the 32-bit-count kernel must still fit a CU.
+TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
+{
+    TeamChoice best;
+    for (int waves : {4, 8}) {
+        if (forced_waves && waves != forced_waves) continue;
+        for (uint32_t passes = forced_passes ? forced_passes : 1; passes <= 4096; ++passes) {
+            const uint32_t slices = (uint32_t)waves * passes;
+            const uint32_t rows = (n + slices - 1) / slices;
+            const uint32_t rows_pad = (rows + 1u + 63u) & ~63u;
+            const uint32_t desc = team_desc_bytes(keep);
+            const size_t wide = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts32), desc, keep);
+            if (wide > kLdsPerCu) continue;
+            const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts16), desc, keep);
+            const uint32_t resident = team_resident_blocks(waves, normal) * (uint32_t)waves;
+            if (resident > best.resident) best = TeamChoice{waves, passes, rows, rows_pad, resident};
+            break;  // more passes only cost: the first number that fits is the one for this W
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count, std::string &err)
+{
+    auto fail = [&](int code, const char *msg) {
+        err = msg;
+        return code;
+    };
+    if (!d) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    if (shard_count == 0 || shard_index >= shard_count)
+        return fail(EPIK_AMD_ERR_INVALID, "shard_index must be below shard_count");
+    if (d->abi_version != EPIK_AMD_ABI_VERSION) return fail(EPIK_AMD_ERR_INVALID, "abi_version mismatch");
+    if (d->kmer_size < 1 || d->kmer_size > 32) return fail(EPIK_AMD_ERR_UNSUPPORTED, "kmer_size must be in [1, 32]");
+    if (d->alphabet_size < 2 || d->alphabet_size > 32)
+        return fail(EPIK_AMD_ERR_INVALID, "alphabet_size must be in [2, 32]");
+    if (d->num_branches == 0 || d->num_branches >= (1u << 24))
+        return fail(EPIK_AMD_ERR_INVALID, "num_branches out of range");
+    if (d->num_entries >= (1ull << 40)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "more than 2^40 postings");
+    if (d->keep_at_most == 0 || d->keep_at_most > 64)
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "keep_at_most must be in [1, 64]");
+    if (d->offset_bits != 32 && d->offset_bits != 64) return fail(EPIK_AMD_ERR_INVALID, "offset_bits must be 32 or 64");
+    if (!d->offsets || !d->char_class || (!d->values && d->num_entries))
+        return fail(EPIK_AMD_ERR_INVALID, "null database pointer");
+    // dense key space: num_keys == sigma^k, and codes are 32-bit on the device (nucl k <= 15, amino k <= 7)
+    {
+        uint64_t nk = 1;
+        for (uint32_t i = 0; i < d->kmer_size; ++i) {
+            nk *= d->alphabet_size;
+            if (nk > 0xffffffffull) return fail(EPIK_AMD_ERR_UNSUPPORTED, "alphabet_size^kmer_size exceeds 2^32 keys");
+        }
+        if (nk != d->num_keys) return fail(EPIK_AMD_ERR_INVALID, "num_keys != alphabet_size^kmer_size");
+    }
+    const Source src{d, 0, 1};
+    if (d->offset_bits == 32 && d->num_entries > 0xffffffffull)
+        return fail(EPIK_AMD_ERR_INVALID, "num_entries needs 64-bit offsets");
+    if (src.offset_at(0) != 0 || src.offset_at(d->num_keys) != d->num_entries)
+        return fail(EPIK_AMD_ERR_INVALID, "offsets[0] != 0 or offsets[num_keys] != num_entries");
+    // The lists themselves: monotone offsets, lists shorter than 2^24, every branch below num_branches,
+    // finite scores, and -- what the kernels' lane-parallel read-add-write of a list relies on -- no
+    // branch twice in one list (the reference's lists are built per branch, one score each: main.cpp:257).
+    std::vector<uint32_t> seen_in;  // seen_in[b] = 1 + the last list that held branch b
+    try {
+        seen_in.assign(d->num_branches, 0);
+    } catch (const std::bad_alloc &) {
+        return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
+    }
+    uint32_t list_id = 0;
+    for (uint64_t key = 0; key < d->num_keys; ++key) {
+        const uint64_t b = src.offset_at(key), e = src.offset_at(key + 1);
+        if (e < b || e > d->num_entries) return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
+        if (e - b >= (1ull << 24)) return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
+        if (e == b) continue;
+        if (++list_id == 0) {  // the list counter wrapped (> 4 G non-empty lists): start a new epoch
+            std::fill(seen_in.begin(), seen_in.end(), 0u);
+            list_id = 1;
+        }
+        for (uint64_t i = b; i < e; ++i) {
+            const uint32_t branch = d->values[i].branch;
+            if (branch >= d->num_branches) return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
+            if (!std::isfinite(d->values[i].score))  // the kernels mark "no edge" with -inf
+                return fail(EPIK_AMD_ERR_INVALID, "posting with a non-finite score");
+            if (seen_in[branch] == list_id)
+                return fail(EPIK_AMD_ERR_INVALID, "a posting list names the same branch twice");
+            seen_in[branch] = list_id;
+        }
+    }
+    return EPIK_AMD_OK;
+}
+
+int make_plan(const Source &src, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
+              std::string &err)
+{
+    const epik_amd_placer_desc *d = src.d;
+    auto fail = [&](int code, const char *msg) {
+        err = msg;
+        return code;
+    };
+    plan = Plan{};
+    plan.n_pad = (d->num_branches + 1u + 63u) & ~63u;
+    const bool wave_fits = wave_lds_bytes(plan.n_pad, kCounts32) <= kLdsPerCu;
+    for (int c = 0; c < 3; ++c) plan.wave_resident[c] = wave_fits ? wave_kernel_resident_waves(plan.n_pad, c) : 0;
+
+    // ---- kernel: one wavefront per read while enough of them fit a CU, else a workgroup per read ----
+    bool team = !wave_fits || plan.wave_resident[kCounts16] < 12;
+    int forced_waves = 0;
+    uint32_t forced_passes = 0;
+    if (forced_kernel && forced_kernel[0]) {
+        if (std::strcmp(forced_kernel, "wave") == 0) {
+            if (!wave_fits) return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the one-wavefront-per-read kernel");
+            team = false;
+        } else if (std::strcmp(forced_kernel, "team") == 0) {
+            team = true;
+        } else if (std::strncmp(forced_kernel, "team4", 5) == 0 || std::strncmp(forced_kernel, "team8", 5) == 0) {
+            team = true;  // teamW or teamWxP: W waves, (tests) at least P passes
+            forced_waves = forced_kernel[4] - '0';
+            if (forced_kernel[5] == 'x') forced_passes = (uint32_t)std::strtoul(forced_kernel + 6, nullptr, 10);
+            if (forced_kernel[5] != 0 && (forced_kernel[5] != 'x' || forced_passes == 0 || forced_passes > 64))
+                return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team4[xP] or team8[xP]");
+        } else {
+            return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team4[xP] or team8[xP]");
+        }
+    }
+    if (forced_layout && forced_layout[0] && std::strcmp(forced_layout, "compact") != 0 &&
+        std::strcmp(forced_layout, "packed") != 0 && std::strcmp(forced_layout, "paired") != 0 &&
+        std::strcmp(forced_layout, "filtered") != 0)
+        return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed, paired or filtered");
+
+    for (uint64_t key = 0; key < d->num_keys; ++key) {
+        const uint64_t len = src.kept_len(key);
+        plan.kept_entries += len;
+        plan.present_codes += len != 0;
+    }
+
+    if (team) {
+        const TeamChoice c = choose_team(d->num_branches, d->keep_at_most, forced_waves, forced_passes);
+        if (c.waves == 0) return fail(EPIK_AMD_ERR_UNSUPPORTED, "no team geometry fits this tree");
+        plan.layout = DbLayout::kTeam;
+        plan.team_waves = c.waves;
+        plan.team_passes = c.passes;
+        plan.team_slice_rows = c.slice_rows;
+        plan.team_rows_pad = c.rows_pad;
+        // size of the sliced posting region: every (code, pass) on 128-byte lines of its own
+        const uint32_t slices = (uint32_t)c.waves * c.passes;
+        std::vector<uint32_t> cnt(slices);
+        uint64_t lines = 0;
+        for (uint64_t key = 0; key < d->num_keys; ++key) {
+            const uint64_t len = src.kept_len(key);
+            if (len == 0) continue;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+            for (uint64_t i = 0; i < len; ++i) ++cnt[v[i].branch / c.slice_rows];
+            for (uint32_t p = 0; p < c.passes; ++p) {
+                uint32_t bytes = 0;
+                for (int w = 0; w < c.waves; ++w) bytes += pad4(cnt[p * c.waves + w] * 6u);
+                lines += (bytes + 127u) / 128u;
+            }
+        }
+        if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
+        plan.posting_bytes = lines * 128u + 512u;  // +512: room behind the last list (descriptors are exact)
+        plan.table_bytes = (uint64_t)c.passes * d->num_keys * (uint64_t)team_entry_bytes(c.waves);
+        return EPIK_AMD_OK;
+    }
+
+    // ---- layouts of the one-wavefront-per-read kernels (place_kernel.hip) -------------------------------
+    //  packed  : an 8-byte {len, line} entry per k-mer code + every list on 128-byte lines of its own;
+    //  paired  : the same lists behind a table keyed by the (k-1)-mer that two consecutive k-mers of a read
+    //            share: one table line per two lookups, 16 bytes per code; 4-letter alphabets -- their default;
+    //  filtered: packed behind a presence filter keyed like the paired table: the other alphabets when at
+    //            most a quarter of the codes have a list;
+    //  compact : the CSR (4- or 8-byte offsets), 8-byte postings back to back: when the table would take
+    //            more than a quarter of the device's free memory.
+    const bool sparse = plan.present_codes * 4u <= d->num_keys;
+    const bool can_pair = d->alphabet_size == 4, can_filter = d->alphabet_size <= 32;
+    const bool table_fits = d->num_keys * 16u <= free_mem / 4;
+    bool paired = false, filtered = false, packed = false;
+    if (forced_layout && forced_layout[0]) {
+        filtered = can_filter && (std::strcmp(forced_layout, "filtered") == 0 ||
+                                  (!can_pair && std::strcmp(forced_layout, "paired") == 0));
+        paired = can_pair && std::strcmp(forced_layout, "paired") == 0;
+        packed = paired || filtered || std::strcmp(forced_layout, "compact") != 0;
+    } else if (table_fits) {
+        paired = can_pair;
+        filtered = !paired && can_filter && sparse;
+        packed = true;
+    }
+    if (!packed) {
+        plan.layout = d->offset_bits == 64 ? DbLayout::kCompact64 : DbLayout::kCompact32;
+        plan.table_bytes = (d->num_keys + 1) * (d->offset_bits / 8u);
+        plan.posting_bytes = plan.kept_entries * 8u + 512u;
+        return EPIK_AMD_OK;
+    }
+    plan.layout = paired ? DbLayout::kPaired : filtered ? DbLayout::kFiltered : DbLayout::kPacked;
+    uint64_t lines = 0;
+    const uint64_t quarter = d->num_keys / 4;
+    for (uint64_t key = 0; key < d->num_keys; ++key) {
+        if (paired && quarter && key % quarter == 0 && key / quarter < 4) plan.quarter_lines[key / quarter] = lines;
+        lines += packed_lines(src.kept_len(key));
+    }
+    if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
+    plan.posting_bytes = lines * 128u + 512u;
+    plan.table_bytes = d->num_keys * (paired ? 16u : 8u) + 8u;
+    plan.filter_bytes = filtered ? (d->num_keys / d->alphabet_size) * 8u : 0;
+    return EPIK_AMD_OK;
+}
+
+int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &postings, std::string &err)
+{
+    const epik_amd_placer_desc *d = src.d;
+    const uint64_t num_keys = d->num_keys;
+    try {
+        if (plan.layout == DbLayout::kTeam) {
+            const int W = plan.team_waves;
+            const uint32_t rows = plan.team_slice_rows, top = plan.team_rows_pad - 1u;
+            const size_t entry_bytes = (size_t)team_entry_bytes(W);
+            std::vector<std::vector<epik_amd_pkdb_value>> sub((size_t)W);
+            uint64_t line = 0;
+            for (uint32_t pass = 0; pass < plan.team_passes; ++pass) {
+                RecordWriter entries(table, entry_bytes, num_keys);
+                const uint32_t first_slice = pass * (uint32_t)W;
+                for (uint64_t key = 0; key < num_keys; ++key) {
+                    uint8_t *entry = entries.next();  // zero-filled: an absent code has len[] = 0
+                    const uint64_t len = src.kept_len(key);
+                    if (len == 0) continue;
+                    for (auto &s : sub) s.clear();
+                    const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+                    for (uint64_t i = 0; i < len; ++i) {  // stable: a sublist keeps the list's order
+                        const uint32_t slice = v[i].branch / rows;
+                        if (slice >= first_slice && slice < first_slice + (uint32_t)W)
+                            sub[slice - first_slice].push_back({v[i].branch - slice * rows, v[i].score});
+                    }
+                    uint32_t bytes = 0;
+                    for (int w = 0; w < W; ++w) bytes += pad4((uint32_t)sub[w].size() * 6u);
+                    if (bytes == 0) continue;
+                    const uint64_t n_lines = (bytes + 127u) / 128u;
+                    uint8_t *dst = postings.reserve((size_t)n_lines * 128u);
+                    put_u32(entry, (uint32_t)line);
+                    for (int w = 0; w < W; ++w) {
+                        const uint16_t n = (uint16_t)sub[w].size();
+                        std::memcpy(entry + 4 + 2 * w, &n, 2);
+                        write_chunks(dst, sub[w].data(), sub[w].size(), top);
+                        dst += pad4((uint32_t)sub[w].size() * 6u);
+                    }
+                    line += n_lines;
+                }
+            }
+            postings.reserve(512);
+            return EPIK_AMD_OK;
+        }
+        if (plan.layout == DbLayout::kCompact32 || plan.layout == DbLayout::kCompact64) {
+            // the kept lists back to back as {f32 score, u32 cell}; offsets over the kept lists
+            const size_t off_bytes = d->offset_bits / 8u;
+            const uint32_t top = plan.n_pad - 1u;
+            RecordWriter offsets(table, off_bytes, num_keys + 1);
+            uint64_t at = 0;
+            for (uint64_t key = 0; key <= num_keys; ++key) {
+                uint8_t *o = offsets.next();
+                if (off_bytes == 8) {
+                    std::memcpy(o, &at, 8);
+                } else {
+                    const uint32_t at32 = (uint32_t)at;
+                    std::memcpy(o, &at32, 4);
+                }
+                if (key == num_keys) break;
+                const uint64_t len = src.kept_len(key);
+                if (len == 0) continue;
+                const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+                for (uint64_t c0 = 0; c0 < len; c0 += 4096) {
+                    const uint64_t n = std::min<uint64_t>(4096, len - c0);
+                    uint8_t *dst = postings.reserve((size_t)n * 8u);
+                    for (uint64_t j = 0; j < n; ++j) {
+                        const uint32_t cell = top - v[c0 + j].branch;
+                        std::memcpy(dst + 8u * j, &v[c0 + j].score, 4);
+                        std::memcpy(dst + 8u * j + 4u, &cell, 4);
+                    }
+                }
+                at += len;
+            }
+            postings.reserve(512);
+            return EPIK_AMD_OK;
+        }
+        // ---- packed lists; plain, paired or filtered table -----------------------------------------------
+        const uint32_t top = plan.n_pad - 1u;
+        for (uint64_t key = 0; key < num_keys; ++key) {
+            const uint64_t len = src.kept_len(key);
+            if (len == 0) continue;
+            uint8_t *dst = postings.reserve((size_t)packed_lines(len) * 128u);
+            write_chunks(dst, d->values + src.offset_at(key), len, top);
+        }
+        postings.reserve(512);
+        if (plan.layout == DbLayout::kPaired) {
+            // Block X (a (k-1)-mer) holds the entries of the four codes a.X (slots 0-3) and the four X.b
+            // (slots 4-7).  The line of a code is the number of lines of all codes in front of it: five
+            // cursors walk the key space in step -- one per quarter (a.X, a fixed, X rising) and one over
+            // all codes (X.b) -- so no per-code array is needed.
+            const uint64_t blocks = num_keys / 4;  // 4^(k-1)
+            RecordWriter out(table, 64, blocks);
+            uint64_t quarter_line[4] = {plan.quarter_lines[0], plan.quarter_lines[1], plan.quarter_lines[2],
+                                        plan.quarter_lines[3]};
+            uint64_t seq_line = 0;
+            for (uint64_t x = 0; x < blocks; ++x) {
+                uint8_t *block = out.next();
+                for (uint32_t a = 0; a < 4; ++a) {
+                    const uint64_t len = src.kept_len(a * blocks + x);
+                    put_u32(block + 8 * a, (uint32_t)len);
+                    put_u32(block + 8 * a + 4, (uint32_t)quarter_line[a]);
+                    quarter_line[a] += packed_lines(len);
+                }
+                for (uint32_t b = 0; b < 4; ++b) {
+                    const uint64_t len = src.kept_len(x * 4 + b);
+                    put_u32(block + 32 + 8 * b, (uint32_t)len);
+                    put_u32(block + 32 + 8 * b + 4, (uint32_t)seq_line);
+                    seq_line += packed_lines(len);
+                }
+            }
+            table.reserve(8);
+        } else {
+            RecordWriter out(table, 8, num_keys);
+            uint64_t line = 0;
+            for (uint64_t key = 0; key < num_keys; ++key) {
+                uint8_t *e = out.next();
+                const uint64_t len = src.kept_len(key);
+                put_u32(e, (uint32_t)len);
+                put_u32(e + 4, (uint32_t)line);
+                line += packed_lines(len);
+            }
+            table.reserve(8);
+        }
+        if (plan.layout == DbLayout::kFiltered) {
+            if (!filter) {
+                err = "no sink for the presence filter";
+                return EPIK_AMD_ERR_INVALID;
+            }
+            // filter[X], X a (k-1)-mer: bit a <=> code a.X has a list, bit sigma + b <=> code X.b has one
+            const uint64_t sigma = d->alphabet_size, blocks = num_keys / sigma;  // sigma^(k-1)
+            RecordWriter out(*filter, 8, blocks);
+            for (uint64_t x = 0; x < blocks; ++x) {
+                uint64_t word = 0;
+                for (uint64_t a = 0; a < sigma; ++a)
+                    if (src.kept_len(a * blocks + x) != 0) word |= 1ull << a;
+                for (uint64_t b = 0; b < sigma; ++b)
+                    if (src.kept_len(x * sigma + b) != 0) word |= 1ull << (sigma + b);
+                std::memcpy(out.next(), &word, 8);
+            }
+        }
+        return EPIK_AMD_OK;
+    } catch (const std::bad_alloc &) {
+        err = "out of host memory building the device database";
+        return EPIK_AMD_ERR_INVALID;
+    }
+}
+
+}  // namespace epik_amd::image

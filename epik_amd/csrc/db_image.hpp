@@ -1,0 +1,75 @@
+// db_image.hpp -- from the caller's CSR database (epik_amd_placer_desc) to the device image,
+// on the host, streaming.
+//
+// Replaces what i2l::load + the hash map behind phylo_kmer_db::search are to the reference
+// (main.cpp:277, place.cpp:300): the posting lists re-laid for the kernels (db_layout.h).  The
+// image is never materialised on the host: every part (table, presence filter, postings) is
+// produced front to back, in k-mer-code order, into a Sink that hands out the next few bytes --
+// pinned staging buffers on the way to HBM in create() (capi.hip), a checksum in the CPU tests.
+// Host memory beyond the caller's own arrays: one uint32 per branch (validation) and the sinks'
+// buffers.  Plain C++, no HIP.  Internal; the public boundary is include/epik_amd.h.
+#ifndef EPIK_AMD_DB_IMAGE_HPP
+#define EPIK_AMD_DB_IMAGE_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "db_layout.h"
+#include "epik_amd.h"
+
+namespace epik_amd::image {
+
+// The caller's database, and which part of it this placer keeps (k-mer-space shard: the lists of the
+// codes with code % shard_count == shard_index; 0 of 1 = everything).
+struct Source {
+    const epik_amd_placer_desc *d = nullptr;
+    uint32_t shard_index = 0, shard_count = 1;
+    uint64_t offset_at(uint64_t key) const
+    {
+        return d->offset_bits == 64 ? static_cast<const uint64_t *>(d->offsets)[key]
+                                    : static_cast<const uint32_t *>(d->offsets)[key];
+    }
+    uint64_t kept_len(uint64_t key) const
+    {
+        return (shard_count == 1 || key % shard_count == shard_index) ? offset_at(key + 1) - offset_at(key) : 0;
+    }
+};
+
+// What create() decided and how large the parts are.
+struct Plan {
+    DbLayout layout = DbLayout::kCompact32;
+    uint32_t n_pad = 0;  // one-wavefront-per-read kernels: LDS rows per wave (branches + the dummy row, to 64)
+    // team kernel (layout == kTeam)
+    int team_waves = 0;
+    uint32_t team_passes = 0, team_slice_rows = 0, team_rows_pad = 0;
+    // device image
+    uint64_t table_bytes = 0, filter_bytes = 0, posting_bytes = 0;
+    uint64_t kept_entries = 0, present_codes = 0;
+    uint64_t quarter_lines[4] = {0, 0, 0, 0};  // paired table: posting lines in front of each quarter of the key space
+    uint32_t wave_resident[3] = {0, 0, 0};     // resident waves per CU by count width (what chose the kernel)
+};
+
+// Sequential writer of one part of the image.
+struct Sink {
+    virtual ~Sink() = default;
+    // `n` writable bytes that follow everything reserved before, zero-filled; valid until the next call.
+    virtual uint8_t *reserve(size_t n) = 0;
+};
+
+// Argument and consistency checks of create() that need no device: sizes, monotone offsets,
+// branches in range and distinct inside a list, finite scores.  Returns an epik_amd_status.
+int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count, std::string &err);
+
+// Chooses kernel and layout (forced_layout: EPIK_AMD_LAYOUT; forced_kernel: EPIK_AMD_KERNEL =
+// wave | team | team4 | team8; either may be null) for a device with `free_mem` bytes free and sizes
+// the parts.  Reads every offset, and for the team layout every posting, once.
+int make_plan(const Source &src, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
+              std::string &err);
+
+// Produces the image: exactly plan.table_bytes into `table`, plan.filter_bytes into `filter` (may be
+// null when 0), plan.posting_bytes into `postings`.
+int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &postings, std::string &err);
+
+}  // namespace epik_amd::image
+#endif

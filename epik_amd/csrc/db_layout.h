@@ -1,0 +1,89 @@
+// db_layout.h -- how the phylo-k-mer database lies in HBM, and the LDS arithmetic that decides it.
+// Plain C++ (no HIP): shared by the kernels (place_kernel.h), the host-side image builder
+// (db_image.cpp) and its CPU tests.  Internal; the public boundary is include/epik_amd.h.
+#ifndef EPIK_AMD_DB_LAYOUT_H
+#define EPIK_AMD_DB_LAYOUT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define EPIK_AMD_TILES_PER_PASS 3
+#ifndef EPIK_AMD_RING
+#define EPIK_AMD_RING 8  // posting-chunk loads kept in flight per wave (power of two)
+#endif
+
+namespace epik_amd {
+
+// Layouts of the one-wavefront-per-read kernels (place_kernel.hip documents them).
+enum class DbLayout : int {
+    kCompact32 = 0,  // CSR: 32-bit offsets[num_keys + 1], 8-byte {f32 score, u32 cell} postings back to back
+    kCompact64 = 1,  // same with 64-bit offsets
+    kPacked = 2,     // 8-byte {len, first 128-byte line} entry per k-mer code, lists on whole lines,
+                     // 6 bytes per posting: f32 score[cnt] then u16 cell[cnt] per chunk of <= 64
+    kPaired = 3,     // the same lists; the table keyed by the (k-1)-mer two consecutive k-mers share
+                     // (4-letter alphabets): one table line per two lookups, 16 bytes per code
+    kFiltered = 4,   // kPacked behind a presence filter keyed the same way (other alphabets, sparse
+                     // databases): one filter word per two lookups, the table only for present codes
+    kTeam = 5,       // the team kernel's layout (team_kernel.hip): every list pre-split into one
+                     // sublist per slice of the branch range, a {line, len[W]} entry per code and pass
+};
+
+// Width of the per-branch k-mer counts in LDS: 16 bits by default (reads of up to 32767 k-mers),
+// 32 for longer reads, 8 (reads of up to 255 k-mers) when that lets more waves share a CU.
+enum CountBits : int { kCounts8 = 0, kCounts16 = 1, kCounts32 = 2 };
+
+// ---- gfx950 numbers the geometry is computed from -------------------------------------------
+constexpr uint32_t kLdsPerCu = 160u * 1024u;  // bytes
+constexpr uint32_t kLdsGranule = 1280u;       // LDS is handed out in 128ths of a CU's 160 KiB (measured)
+constexpr uint32_t kWaveKernelWavesPerCu = 20u;  // place_reads_kernel: __launch_bounds__(256, 5)
+constexpr uint32_t kTeamKernelWavesPerCu = 16u;  // team_place_kernel: __launch_bounds__(W * 64, 4)
+
+constexpr uint32_t kWaveDescBytes = (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
+// LDS bytes of one wave of the one-wavefront-per-read kernels: scores + counts + chunk descriptors
+constexpr uint32_t wave_lds_bytes(uint32_t n_pad, int counts)
+{
+    return (n_pad * (4u + (1u << counts)) + kWaveDescBytes + 15u) & ~15u;
+}
+// Resident waves per CU of those kernels: workgroups of 4, 2 or 1 independent waves, whichever keeps most
+constexpr uint32_t wave_kernel_resident_waves(uint32_t n_pad, int counts)
+{
+    uint32_t best = 0;
+    for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
+        const uint32_t block = wpb * wave_lds_bytes(n_pad, counts);
+        if (block > kLdsPerCu) continue;
+        const uint32_t units = (block + kLdsGranule - 1) / kLdsGranule;
+        uint32_t blocks = 128u / (units ? units : 1u);
+        if (blocks * wpb > kWaveKernelWavesPerCu) blocks = kWaveKernelWavesPerCu / wpb;
+        if (blocks * wpb > best) best = blocks * wpb;
+    }
+    return best;
+}
+
+// ---- team kernel ---------------------------------------------------------------------------------
+constexpr uint32_t kTeamDescCap = 64;  // chunk descriptors per slice and round
+// bytes of one table entry {u32 line, u16 len[W]}
+constexpr int team_entry_bytes(int waves) { return waves <= 6 ? 16 : waves <= 14 ? 32 : 64; }
+constexpr uint32_t team_slice_bytes(uint32_t rows_pad, int counts) { return (rows_pad * (4u + (1u << counts)) + 15u) & ~15u; }
+// a slice's descriptor list also holds its top-k candidates (64 + 4 entries of 8 bytes) and, with
+// one pass, its ranked rows for the merge (keep_at_most entries of 16 bytes)
+constexpr uint32_t team_desc_bytes(uint32_t keep)
+{
+    const uint32_t list = (kTeamDescCap + EPIK_AMD_RING) * 8u, rows = keep * 16u;
+    return ((list > rows ? list : rows) + 15u) & ~15u;
+}
+// LDS bytes of a workgroup: slices, descriptor lists, tile totals + flags, partial sums, (P > 1) ranked rows
+constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes, uint32_t desc_bytes, uint32_t keep)
+{
+    return (size_t)waves * slice_bytes + (size_t)waves * desc_bytes + ((size_t)waves * waves + 4) * 4 +
+           (size_t)waves * passes * 24 + (passes > 1 ? (size_t)waves * passes * keep * 16 : 0);
+}
+constexpr uint32_t team_resident_blocks(int waves, size_t lds_bytes)
+{
+    if (lds_bytes > kLdsPerCu) return 0;
+    const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
+    const uint32_t by_lds = 128u / (units ? units : 1u), by_regs = kTeamKernelWavesPerCu / (uint32_t)waves;
+    return by_lds < by_regs ? by_lds : by_regs;
+}
+
+}  // namespace epik_amd
+#endif

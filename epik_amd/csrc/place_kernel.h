@@ -8,24 +8,9 @@
 
 #include "epik_amd.h"
 
-#define EPIK_AMD_TILES_PER_PASS 3
-#ifndef EPIK_AMD_RING
-#define EPIK_AMD_RING 8  // posting-chunk loads kept in flight per wave (power of two)
-#endif
+#include "db_layout.h"
 
 namespace epik_amd {
-
-// How the phylo-k-mer database is laid out in HBM (place_kernel.hip documents both).
-enum class DbLayout : int {
-    kCompact32 = 0,  // CSR: 32-bit offsets[num_keys + 1], 8-byte {f32 score, u32 cell} postings back to back
-    kCompact64 = 1,  // same with 64-bit offsets
-    kPacked = 2,     // 8-byte {len, first 128-byte line} entry per k-mer code, lists on whole lines,
-                     // 6 bytes per posting: f32 score[cnt] then u16 cell[cnt] per chunk of <= 64
-    kPaired = 3,     // the same lists; the table keyed by the (k-1)-mer two consecutive k-mers share
-                     // (4-letter alphabets): one table line per two lookups, 16 bytes per code
-    kFiltered = 4,   // kPacked behind a presence filter keyed the same way (other alphabets, sparse
-                     // databases): one filter word per two lookups, the table only for present codes
-};
 
 // Kernel arguments: the database in HBM, the placer constants of place.cpp:83-96, and
 // one batch of reads.
@@ -45,7 +30,16 @@ struct PlaceParams {
     // k-mer-space shard: raw per-branch sums, [n_reads][num_branches].  Non-null in
     // place_reads_kernel = accumulate only (no epilogue); the input of finish_reads_kernel.
     float *partial_scores;
-    uint32_t *partial_counts;
+    uint16_t *partial_counts;        // (a read of a k-mer-space shard has at most 65535 k-mers)
+    // ... and how its ambiguous k-mers cross the shards (place.cpp:385-388 holds over the whole
+    // database): amb_slot[read] >= 0 names the read's row in amb_order / amb_avg,
+    // [slots][num_branches]: accumulate records there, per branch, the order of the first ambiguous
+    // key of ITS lists that reached the branch and that key's average probability; the caller keeps,
+    // per branch, the record of smallest order over the shards; finish adds it.  Null: a shard
+    // scores its ambiguous k-mers by itself (right with one shard only).
+    const int32_t *amb_slot;
+    uint32_t *amb_order;
+    float *amb_avg;
     uint32_t kmer_size;
     uint32_t alphabet_size;
     uint32_t num_branches;
@@ -59,9 +53,28 @@ struct PlaceParams {
     unsigned long long *dbg;         // phase cycle sums (-DEPIK_AMD_ABLATION builds, EPIK_AMD_STAMPS=1)
 };
 
-// Width of the per-branch k-mer counts in LDS: 16 bits by default (reads of up to 32767 k-mers),
-// 32 for longer reads, 8 (reads of up to 255 k-mers) when that lets more waves share a CU.
-enum CountBits : int { kCounts8 = 0, kCounts16 = 1, kCounts32 = 2 };
+// n_rows of a read with more k-mers than the launch's count width holds (EPIK_AMD_ROWS_COUNTS_TOO_NARROW)
+constexpr uint32_t kCountsTooNarrow = 0xffffffffu;
+
+// ---- team kernel (team_kernel.hip): one workgroup of W waves per read, the branch range in slices ----
+struct TeamParams {
+    PlaceParams base;            // first member: the out-of-line device functions get &base
+                                 // (base.postings = the sliced posting region; base.table / filter unused)
+    const uint8_t *team_table;   // [passes][num_keys] entries of team_entry_bytes(W)
+    uint64_t num_keys;
+    uint32_t passes;             // P: the tree is placed in P passes of W slices each
+    uint32_t slice_rows;         // branches per slice; slice s = pass * W + wave starts at branch s * slice_rows
+    uint32_t rows_pad;           // LDS rows per slice: slice_rows + the dummy row, rounded up to 64
+    uint32_t desc_cap;           // chunk descriptors per slice and round (a multiple of the ring, >= 64)
+    uint32_t slice_bytes;        // LDS bytes of one slice's rows (scores then counts), a multiple of 16
+    uint32_t desc_bytes;         // LDS bytes of one slice's descriptor list, a multiple of 16
+};
+enum : int { kTeamModePlace = 0, kTeamModeAccumulate = 1, kTeamModeFinish = 2 };
+hipError_t launch_team(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
+                       hipStream_t stream);
+hipError_t set_team_lds_limit(int waves, int counts, size_t lds_bytes);
+hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
+hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream);
 
 hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream);

@@ -22,756 +22,9 @@
 
 #include <type_traits>
 
-#include "place_kernel.h"
+#include "place_device.hpp"
 
 namespace epik_amd {
-
-namespace {
-
-constexpr int kWave = 64;
-constexpr int kTilesPerPass = EPIK_AMD_TILES_PER_PASS;  // 64-character tiles encoded per pass
-constexpr int kRing = EPIK_AMD_RING;  // posting-chunk loads kept in flight per wave
-static_assert((kRing & (kRing - 1)) == 0 && kRing >= 4 && kRing <= 32, "kRing: power of two, one descriptor lane per stage");
-constexpr uint32_t kChunkCap = (uint32_t)kTilesPerPass * 64u;  // chunk descriptors per round (LDS)
-
-typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
-
-// float -> unsigned that sorts like the float
-__device__ __forceinline__ uint32_t ord_f32(float f)
-{
-    const uint32_t u = __float_as_uint(f);
-    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
-}
-
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
-{
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m);
-    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// Cross-lane moves inside a row of 16 lanes (DPP, no LDS round trip):
-// 0xB1 = quad_perm[1,0,3,2], 0x4E = quad_perm[2,3,0,1], 0x141 = row_half_mirror, 0x140 = row_mirror.
-// Applying them in this order leaves every lane of a row with the row's reduction.
-template <int kCtrl>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, 0xf, 0xf, false);
-}
-template <int kCtrl>
-__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
-{
-    return ((uint64_t)dpp_u32<kCtrl>((uint32_t)(v >> 32)) << 32) | dpp_u32<kCtrl>((uint32_t)v);
-}
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
-{
-    // the builtin returns int: cast before widening, or the low half sign-extends
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// Wave reductions; the result is wave-uniform (combined from the four rows' lane 0/16/32/48).
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    v = max(v, dpp_u32<0xB1>(v));
-    v = max(v, dpp_u32<0x4E>(v));
-    v = max(v, dpp_u32<0x141>(v));
-    v = max(v, dpp_u32<0x140>(v));
-    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return max(max(a, b), max(c, d));
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-    v += dpp_u32<0xB1>(v);
-    v += dpp_u32<0x4E>(v);
-    v += dpp_u32<0x141>(v);
-    v += dpp_u32<0x140>(v);
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
-           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-}
-__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v)
-{
-    v |= dpp_u64<0xB1>(v);
-    v |= dpp_u64<0x4E>(v);
-    v |= dpp_u64<0x141>(v);
-    v |= dpp_u64<0x140>(v);
-    return readlane_u64(v, 0) | readlane_u64(v, 16) | readlane_u64(v, 32) | readlane_u64(v, 48);
-}
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-    auto mv = [](double x, auto tag) {
-        return __longlong_as_double((long long)dpp_u64<decltype(tag)::value>((uint64_t)__double_as_longlong(x)));
-    };
-    v += mv(v, std::integral_constant<int, 0xB1>{});
-    v += mv(v, std::integral_constant<int, 0x4E>{});
-    v += mv(v, std::integral_constant<int, 0x141>{});
-    v += mv(v, std::integral_constant<int, 0x140>{});
-    auto rl = [&](int l) { return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), l)); };
-    return (rl(0) + rl(16)) + (rl(32) + rl(48));
-}
-
-// Inclusive prefix sum over the 64 lanes (row_shr DPP inside rows of 16, then the row totals).
-template <int kCtrl>
-__device__ __forceinline__ uint32_t dpp_zero_u32(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xf, 0xf, true);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
-{
-    v += dpp_zero_u32<0x111>(v);  // row_shr:1
-    v += dpp_zero_u32<0x112>(v);  // row_shr:2
-    v += dpp_zero_u32<0x114>(v);  // row_shr:4
-    v += dpp_zero_u32<0x118>(v);  // row_shr:8
-    const uint32_t r0 = __builtin_amdgcn_readlane(v, 15);
-    const uint32_t r1 = __builtin_amdgcn_readlane(v, 31);
-    const uint32_t r2 = __builtin_amdgcn_readlane(v, 47);
-    const uint32_t row = (uint32_t)__lane_id() >> 4;
-    return v + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
-}
-
-// inverse of ord_f32
-__device__ __forceinline__ float unord_f32(uint32_t o)
-{
-    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
-}
-
-// 10^x in double.  The reference calls glibc pow(10.0, x) (place.cpp:46,181,254);
-// the device routine differs from it by ulps, which is far inside the 1e-5 LWR bar.
-__device__ __forceinline__ double pow10_f64(double x) { return exp10(x); }
-
-// Everything a wave knows about the 64-character tile it is encoding.
-struct Tile {
-    uint32_t key;       // k-mer code of the window starting at this lane (ambiguous position = state 0)
-    uint32_t prefix;    // code of the window's first k-1 letters ...
-    uint32_t last;      // ... and the state of its last letter: key = prefix * sigma + last
-    uint32_t first;     // state of its first letter (this lane's character)
-    uint32_t cls;       // char_class of this lane's character
-    uint64_t inv_mask;  // wave-uniform: lanes whose character is invalid
-    uint64_t amb_mask;  // wave-uniform: lanes whose character is ambiguous
-    bool in_range;      // this lane starts a window of the read (p < n_kmers, lane < tile stride)
-};
-
-// ---------------------------------------------------------------------------------
-// Database layouts in HBM.  Both answer phylo_kmer_db::search (place.cpp:300,311): a
-// k-mer code -> (byte offset of its posting list in p.postings, list length).
-//
-// A posting is i2l::pkdb_value with the branch id replaced by the LDS row that accumulates
-// it, stored as cell = n_pad - 1 - branch.  The wave streams a list in chunks of <= 64
-// postings through RANGE-CHECKED buffer loads: the chunk's buffer descriptor holds its
-// byte length, lane l reads posting l, and a lane past the end reads 0 -- cell 0 = row
-// n_pad - 1, a dummy row no branch owns.  So a stage needs no address clamp, no exec mask
-// and no branch, and a padding chunk is a descriptor of zero bytes that touches no memory.
-// (tools/probe_buffer.hip: the range check includes soffset; 6-byte {score, cell} structs
-// read as 2-byte-aligned dwords work too but halve the load throughput.)
-//
-// A chunk descriptor {address (48 bits) | count << 48} is unpacked by every lane at once,
-// once per trip of the ring (vector work), into the kFields variable words of the chunk's
-// loads; a stage then pulls its chunk's words out with v_readlane: the CU's single scalar
-// unit does no unpacking.  `issue` puts one chunk's loads in flight from inline asm (hipcc
-// must not count them, see the ring below); `load_posting` is the plain, compiler-counted
-// access of the cold ambiguous path and returns {LDS row, score bits}.
-// ---------------------------------------------------------------------------------
-constexpr int kRawBufferFormat = 0x00020000;  // 4th descriptor word: untyped 32-bit raw buffer
-
-// Compact CSR: offsets[code .. code+1] delimit the list in units of one posting; the lists
-// lie back to back as 8-byte {f32 score, u32 cell} (4 or 8 bytes per code + 8 per posting;
-// chosen when the table of the layout below would not fit).
-template <typename OffT>
-struct CompactLayout {
-    static constexpr int kLoads = 1;  // vector-memory instructions per chunk
-    static constexpr uint32_t kChunkBytes = 64u * 8u;
-    static constexpr int kFields = 3;  // base lo, base hi, bytes
-    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t /*position*/,
-                                                  uint64_t &addr, uint32_t &len)
-    {
-        const OffT *__restrict__ offsets = static_cast<const OffT *>(p.table);
-        const OffT b = offsets[key];
-        const OffT e = offsets[(uint64_t)key + 1];
-        addr = (uint64_t)b * 8u;
-        len = (uint32_t)(e - b);
-    }
-    __device__ static __forceinline__ void lookup_window(const PlaceParams &p, const Tile &t, uint32_t position,
-                                                         bool wanted, uint64_t &addr, uint32_t &len)
-    {
-        if (wanted) lookup(p, t.key, position, addr, len);
-    }
-    __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
-    {
-        const uint32_t hi = (uint32_t)(d >> 32);
-        f[0] = (uint32_t)d;
-        f[1] = hi & 0xffffu;
-        f[2] = (hi >> 16) * 8u;
-    }
-    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
-                                                 uint32_t &score)
-    {
-        const v4i srd = {(int)f[0], (int)f[1], (int)f[2], kRawBufferFormat};
-        v2u out;
-        // s_nop 4: the descriptor comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen"
-                     : "=&v"(out)
-                     : "v"(lane * 8u), "s"(srd)
-                     : "memory");
-        score = out.x;
-        cell = out.y;
-    }
-    __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
-                                                         uint32_t j)
-    {
-        (void)len;
-        const uint2 e = *reinterpret_cast<const uint2 *>(p.postings + addr + (uint64_t)j * 8u);
-        return make_uint2(p.n_pad - 1u - e.y, e.x);
-    }
-};
-
-// Packed (default): a direct-index table of 8-byte entries {u32 len, u32 line} per k-mer
-// code and every list on whole 128-byte lines of its own.  A list is stored chunk by chunk
-// (<= 64 postings): f32 score[cnt] then u16 cell[cnt] -- 6 bytes per posting, a full chunk is
-// exactly three lines, no line is shared between lists.
-//
-// A random 8-byte lookup costs a whole 128-byte line of fabric traffic (tools/probe_sector.hip),
-// a third of what a read fetches.  kPaired (4-letter alphabets) halves the number of lines:
-// the table is keyed by the (k-1)-mer X that two CONSECUTIVE k-mers of a read share -- a.X and
-// X.b -- and block X holds the entries of all eight k-mers that have X as their suffix (slots
-// 0..3, by first letter a) or as their prefix (slots 4..7, by last letter b).  Every k-mer is
-// therefore stored twice; the k-mer at an even position of the read is looked up as a.X in
-// the block of its suffix, the next one as X.b in the block of its prefix -- the same block,
-// the same line, one fetch for the two lanes.  16 bytes of table per code instead of 8.
-//
-// kFiltered (other alphabets, sparse databases -- a protein database holds a small fraction of
-// the 20^k codes): the same pairing applied to a presence filter.  filter[X] is one 64-bit
-// word per (k-1)-mer X: bit a says whether a.X has a list, bit sigma + b whether X.b has one.
-// Two consecutive k-mers read the same word; only the k-mers that are present go on to the
-// table (keyed by code, as in the plain layout).  8 bytes of filter per (k-1)-mer.
-enum : int { kPlainTable = 0, kPairedTable = 1, kFilteredTable = 2 };
-template <int kTable>
-struct PackedLayout {
-    static constexpr int kLoads = 2;
-    static constexpr uint32_t kChunkBytes = 64u * 6u;
-    static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk
-    // by code alone (the cold paths; the filter only saves traffic, the table is complete)
-    __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t position,
-                                                  uint64_t &addr, uint32_t &len)
-    {
-        uint64_t entry = key;
-        if (kTable == kPairedTable) {
-            const uint32_t shift = 2u * p.kmer_size - 2u;  // X = k-1 letters of 2 bits
-            const bool as_prefix = (position & 1u) != 0;
-            const uint32_t block = as_prefix ? key >> 2 : key & ((1u << shift) - 1u);
-            const uint32_t slot = as_prefix ? 4u + (key & 3u) : key >> shift;
-            entry = (uint64_t)block * 8u + slot;
-        }
-        const uint2 h = static_cast<const uint2 *>(p.table)[entry];
-        len = h.x;
-        addr = (uint64_t)h.y * 128u;
-    }
-    // the hot path: the window of lane `position` of the read, `wanted` = it is an exact k-mer
-    __device__ static __forceinline__ void lookup_window(const PlaceParams &p, const Tile &t, uint32_t position,
-                                                         bool wanted, uint64_t &addr, uint32_t &len)
-    {
-        if (kTable == kFilteredTable) {
-            const bool as_prefix = (position & 1u) != 0;
-            const uint32_t shared = as_prefix ? t.prefix : t.key - t.first * p.sigma_pow_km1;  // X
-            const uint32_t bit = as_prefix ? p.alphabet_size + t.last : t.first;
-            const uint64_t word = wanted ? p.filter[shared] : 0ull;
-            wanted = ((word >> bit) & 1ull) != 0;
-        }
-        if (wanted) lookup(p, t.key, position, addr, len);
-    }
-    __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
-    {
-        const uint32_t hi = (uint32_t)(d >> 32);
-        f[0] = (uint32_t)d;
-        f[1] = hi & 0xffffu;
-        f[2] = hi >> 16;
-    }
-    // One descriptor over the whole chunk; the cell load adds the scalar offset 4*cnt, which
-    // takes part in the range check: lane l < cnt reads score l and cell l, every other lane
-    // reads cell 0 (and, up to lane 1.5*cnt, a score made of cell bytes that lands on the dummy row).
-    __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
-                                                 uint32_t &score)
-    {
-        // f[2] sits in a scalar register (v_readlane): the two products are scalar instructions
-        const v4i srd = {(int)f[0], (int)f[1], (int)(f[2] * 6u), kRawBufferFormat};
-        asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
-                     : "=&v"(score), "=&v"(cell)
-                     : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[2] * 4u)
-                     : "memory");
-    }
-    __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint64_t addr, uint32_t len,
-                                                         uint32_t j)
-    {
-        const uint32_t chunk = j >> 6, r = j & 63u;
-        const uint32_t rest = len - (chunk << 6);
-        const uint32_t cnt = rest < 64u ? rest : 64u;
-        const uint8_t *base = p.postings + addr + (uint64_t)chunk * kChunkBytes;
-        const uint32_t cell = *reinterpret_cast<const uint16_t *>(base + 4u * cnt + 2u * r);
-        return make_uint2(p.n_pad - 1u - cell, *reinterpret_cast<const uint32_t *>(base + 4u * r));
-    }
-};
-
-// absolute address of chunk c (64 postings each) of the list at byte offset `addr`
-template <typename Layout>
-__device__ __forceinline__ uint64_t chunk_address(const PlaceParams &p, uint64_t addr, uint32_t c)
-{
-    return (uint64_t)(p.postings + addr + (uint64_t)c * Layout::kChunkBytes);
-}
-// the padding chunk: zero bytes at a valid address
-__device__ __forceinline__ uint64_t null_chunk(const PlaceParams &p) { return (uint64_t)p.postings; }
-
-// i2l::to_kmers<one_ambiguity_policy> for one tile (place.cpp:294) in three steps, so that a
-// pass can issue the loads of all its tiles together: the character of this lane (branch-free:
-// positions past the end re-read the last character and are masked later), its class through
-// the 256-entry table, and the window code gathered from the next k-1 lanes.
-__device__ __forceinline__ uint32_t tile_char(const uint8_t *__restrict__ seq, uint64_t len, uint64_t tile_pos)
-{
-    const uint64_t pos = tile_pos + (uint64_t)lane_id();
-    return seq[pos < len ? pos : len - 1];  // len >= k >= 1
-}
-__device__ __forceinline__ uint32_t tile_class(uint32_t ch, uint64_t len, uint64_t tile_pos,
-                                               const uint32_t *__restrict__ char_class)
-{
-    const uint32_t cls = char_class[ch];
-    return tile_pos + (uint64_t)lane_id() < len ? cls : 0u;  // past the end: no character
-}
-__device__ __forceinline__ Tile tile_from_class(uint32_t cls, uint64_t len, uint64_t tile_pos, uint64_t n_kmers,
-                                                uint32_t k, uint32_t sigma, uint32_t stride)
-{
-    Tile t;
-    const int lane = lane_id();
-    const uint64_t pos = tile_pos + (uint64_t)lane;
-    const bool multi = (cls & (cls - 1)) != 0;
-    const uint32_t state = (cls && !multi) ? (uint32_t)(__ffs((int)cls) - 1) : 0u;
-    t.cls = cls;
-    t.inv_mask = __ballot(cls == 0 && pos < len);  // characters past the end belong to no window
-    t.amb_mask = __ballot(multi);
-    // Window code of the k characters from this lane on: the states of the next lanes come down
-    // one lane per step with a whole-wave DPP shift (wave_shl:1, lane i <- lane i+1, 0 behind lane
-    // 63) -- a few cycles per step, where an LDS shuffle per step costs a round trip each.
-    uint32_t prefix = state, next = state;  // the first k-1 letters, then the last one separately
-    const uint32_t steps = __builtin_amdgcn_readfirstlane(k) - 1u;
-    if (sigma == 4u) {  // wave-uniform
-        for (uint32_t j = 1; j < steps; ++j) {
-            next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
-            prefix = (prefix << 2) | next;
-        }
-    } else {
-        for (uint32_t j = 1; j < steps; ++j) {
-            next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
-            prefix = prefix * sigma + next;
-        }
-    }
-    if (steps == 0) {  // k == 1: no prefix
-        t.prefix = 0;
-        t.last = state;
-        t.key = state;
-    } else {
-        t.prefix = prefix;
-        t.last = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)next, 0x130, 0xf, 0xf, true);
-        t.key = prefix * sigma + t.last;
-    }
-    t.first = state;
-    t.in_range = ((uint32_t)lane < stride) && (pos < n_kmers);
-    return t;
-}
-__device__ __forceinline__ Tile encode_tile(const uint8_t *__restrict__ seq, uint64_t len,
-                                            uint64_t tile_pos, uint64_t n_kmers, uint32_t k,
-                                            uint32_t sigma, uint32_t stride,
-                                            const uint32_t *__restrict__ char_class)
-{
-    const uint32_t cls = tile_class(tile_char(seq, len, tile_pos), len, tile_pos, char_class);
-    return tile_from_class(cls, len, tile_pos, n_kmers, k, sigma, stride);
-}
-
-// Wave-private LDS: score[b] = _scores[thread][b] (float32), count[b] = _counts[thread][b]
-// (place.h:126-131) in two arrays -- counts are 16-bit by default (reads of up to 32767
-// k-mers; 6 bytes per branch let 20 waves share a CU's 160 KiB), 32-bit in the "wide"
-// kernels the host selects for longer reads.  The top bit of a count is the
-// "already scored by an ambiguous key" flag.  `desc` holds the chunk descriptors of the
-// current round and is reused by the epilogue for its top-k candidates.
-template <typename CountT>
-struct WaveLds {
-    // 16- and 32-bit counts keep the ambiguous path's "seen" flag in their top bit; 8-bit counts
-    // use all their bits (reads of up to 255 k-mers) and the flags live in a bitmap (place_ambiguous)
-    static constexpr uint32_t kSeen = sizeof(CountT) == 1 ? 0u : 1u << (8 * sizeof(CountT) - 1);
-    static constexpr uint64_t kMaxKmers = sizeof(CountT) == 1 ? 255u : (1ull << (8 * sizeof(CountT) - 1)) - 1u;
-    float *score;    // [n_pad]
-    CountT *count;   // [n_pad]
-    uint64_t *desc;  // [kTilesPerPass * 64 + kRing]
-    __device__ __forceinline__ uint2 load(uint32_t i) const
-    {
-        return make_uint2(__float_as_uint(score[i]), (uint32_t)count[i]);
-    }
-    __device__ __forceinline__ void store(uint32_t i, uint32_t score_bits, uint32_t c) const
-    {
-        score[i] = __uint_as_float(score_bits);
-        count[i] = (CountT)c;
-    }
-};
-
-// ---------------------------------------------------------------------------------
-// The two parts of a read's placement that need many registers -- the cold ambiguous-k-mer
-// sweep (double-precision pow) and the epilogue (double-precision exp10, unrolled sweeps) --
-// are real functions, not inlined: inlined, they set the register allocation of the whole
-// kernel (~125 VGPRs) although the streaming loop itself needs ~70.  `kp` points at the
-// kernel's own argument block.
-// ---------------------------------------------------------------------------------
-template <typename Layout, typename CountT>
-__device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
-                                                          const uint8_t *__restrict__ seq, uint64_t len,
-                                                          uint64_t n_kmers)
-{
-    const PlaceParams &p = *kp;
-    const int lane = lane_id();
-    const uint32_t k = p.kmer_size;
-    const uint32_t sigma = p.alphabet_size;
-    const uint32_t stride = kWave - (k - 1);
-    const float k_f = (float)k;
-    // 8-bit counts: one "already scored by an ambiguous key" bit per row, in the chunk-descriptor
-    // area (idle between the stream and the epilogue; the host offers this kernel only when it fits)
-    uint32_t *seen_bitmap = reinterpret_cast<uint32_t *>(lds.desc);
-    if (sizeof(CountT) == 1)
-        for (uint32_t i = lane; i < (p.n_pad + 31u) / 32u; i += kWave) seen_bitmap[i] = 0u;
-    // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
-    {
-        const float thr = p.threshold;
-        for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
-            const Tile t = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
-            if (t.amb_mask == 0) continue;
-            const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-            const uint64_t inv_w = (t.inv_mask >> lane) & wmask;
-            const uint64_t amb_w = (t.amb_mask >> lane) & wmask;
-            const bool is_amb = t.in_range && inv_w == 0 && __popcll(amb_w) == 1;
-            uint64_t todo = __ballot(is_amb);
-            while (todo) {
-                const int m = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint64_t amb_w_m = (t.amb_mask >> m) & wmask;
-                const int j = __builtin_ctzll(amb_w_m);          // ambiguous position in the window
-                const uint32_t cls = __builtin_amdgcn_readlane(t.cls, m + j);
-                const uint32_t key0 = __builtin_amdgcn_readlane(t.key, m);
-                uint32_t weight = 1;
-                for (uint32_t q = (uint32_t)j + 1; q < k; ++q) weight *= sigma;
-                // every resolved key, ascending state order, is searched on its own (:308-312)
-                for (uint32_t st = 0; st < sigma; ++st) {
-                    if (!((cls >> st) & 1u)) continue;
-                    const uint32_t key = key0 + st * weight;
-                    uint64_t b0;
-                    uint32_t n;
-                    Layout::lookup(p, key, 0u, b0, n);
-                    for (uint32_t off = 0; off < n; off += kWave) {
-                        if (off + (uint32_t)lane < n) {
-                            const uint2 e = Layout::load_posting(p, b0, n, off + (uint32_t)lane);  // {row, score bits}
-                            uint2 cv = lds.load(e.x);
-                            const uint32_t c = cv.y;
-                            // Only the first ambiguous key that reaches a branch scores it:
-                            // later ones find counts_amb[b] != 0 and stay out of l_amb (:385-388).
-                            bool seen = (c & lds.kSeen) != 0;
-                            if (sizeof(CountT) == 1) {  // no flag bit in the count: a bitmap in the descriptor area
-                                const uint32_t bit = 1u << (e.x & 31u);
-                                seen = (__hip_atomic_fetch_or(&seen_bitmap[e.x >> 5], bit, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_WAVEFRONT) & bit) != 0;
-                            }
-                            if (!seen) {
-                                // counts_amb[b] == 1, scores_amb[b] == float(pow(10, score)) (:390-391)
-                                const float prob = (float)pow(10.0, (double)__uint_as_float(e.y));
-                                const float avg = __fdiv_rn(
-                                    __fadd_rn(prob, __fmul_rn((float)(k - 1u), thr)), k_f);  // :400-402
-                                cv.y = (c | lds.kSeen) + 1u;                                   // :409
-                                cv.x = __float_as_uint(__fadd_rn(__uint_as_float(cv.x), avg)); // :410
-                                lds.store(e.x, cv.x, cv.y);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-
-}
-
-template <typename Layout, typename CountT>
-__device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
-                                                         uint64_t read, uint64_t n_kmers)
-{
-    const PlaceParams &p = *kp;
-    const int lane = lane_id();
-    const uint32_t N = p.num_branches;
-    const float k_f = (float)p.kmer_size;
-    const float log_thr = p.log_threshold;
-    // ---- score correction (:418-422), dense over N --------------------------------------
-    // score[i] becomes the corrected score (-inf = "not an edge"); count[i] keeps the count
-    // (and the ambiguous path's flag bit).
-    const float nk_f = (float)n_kmers;
-    const uint32_t nk_u = (uint32_t)n_kmers;  // the host rejects reads of 2^32 characters or more
-    const float inv_k = __fdiv_rn(1.0f, k_f);
-    // x / k in three instructions: y = RN(1/k); q = RN(x*y); r = fma(-q, k, x) (exact);
-    // q' = fma(r, y, q).  Bit-identical to the IEEE quotient for every k <= 32 and every
-    // finite x with |x| >= 2^-102 (tools/test_div.hip sweeps all 2^32 floats); a trip that
-    // meets a smaller |x| (or a database with k > 32) is redone with v_div.
-    auto div_k = [&](float x) {
-        const float q = __fmul_rn(x, inv_k);
-        const float r = __fmaf_rn(-q, k_f, x);
-        return __fmaf_rn(r, inv_k, q);
-    };
-    const bool fast_div = p.kmer_size <= 32u;
-    uint32_t touched = 0;
-    float lane_best_f = -INFINITY;  // this lane's best score
-    // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 64: cells behind N hold
-    // no count (the dummy row of the out-of-range lanes was cleared by the caller), so there is no
-    // bounds test.  Four rows per lane and trip while they last (the four LDS reads go out
-    // together), one per trip for the remainder; the arithmetic is branch-free.
-    constexpr int kUnroll = 4;
-    const uint32_t n_rows_pad = p.n_pad;
-    auto correct_rows = [&](auto unroll, uint32_t base) {
-        constexpr int kRows = decltype(unroll)::value;
-        uint2 cv[kRows];
-        float pre[kRows], s[kRows];
-#pragma unroll
-        for (int u = 0; u < kRows; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
-        float smallest = INFINITY;
-#pragma unroll
-        for (int u = 0; u < kRows; ++u) {
-            const uint32_t c = cv[u].y & ~lds.kSeen;
-            pre[u] = __fadd_rn(__uint_as_float(cv[u].x), __fmul_rn((float)(nk_u - c), log_thr));  // :420
-            s[u] = div_k(pre[u]);                                                                 // :421
-            smallest = fminf(smallest, c ? fabsf(pre[u]) : INFINITY);
-        }
-        if (!fast_div || __ballot(smallest < 0x1p-100f) != 0) {  // wave-uniform, practically never
-#pragma unroll
-            for (int u = 0; u < kRows; ++u) s[u] = __fdiv_rn(pre[u], k_f);
-        }
-#pragma unroll
-        for (int u = 0; u < kRows; ++u) {
-            const uint32_t c = cv[u].y & ~lds.kSeen;
-            const float sc = c ? s[u] : -INFINITY;  // -inf = "not an edge"
-            touched += c ? 1u : 0u;
-            lane_best_f = fmaxf(lane_best_f, sc);
-            lds.score[base + (uint32_t)u * kWave + (uint32_t)lane] = sc;  // the count cell stays as it is
-        }
-    };
-    {
-        uint32_t base = 0;
-        for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave)
-            correct_rows(std::integral_constant<int, kUnroll>{}, base);
-        for (; base < n_rows_pad; base += kWave) correct_rows(std::integral_constant<int, 1>{}, base);
-    }
-    const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
-    touched = wave_sum_u32(touched);
-    const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
-
-    // ---- select_best_placements (:134-159) + sum_scores (:164-184) --------------------
-    // Candidates = every edge whose score reaches tau, the n_sel-th largest of the 64
-    // per-lane maxima: at least n_sel edges qualify, usually only a few more.  They are
-    // compacted into LDS and ranked by counting, rank = final row (score desc, branch asc).
-    // The same sweep accumulates sum_scores relative to the largest term, 10^ref_score:
-    //   score_sum = 10^ref_score * (sum_i 10^(score_i - ref_score) + (N - n) * 10^(thr - ref_score))
-    // with the relative terms in float32 (v_exp_f32): ~1e-7 relative on score_sum, i.e. on
-    // every like_weight_ratio (bar: 1e-5).  Row scores and 10^ref_score stay in double, and
-    // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
-    const uint32_t keep = p.keep_at_most;
-    uint2 *cand = reinterpret_cast<uint2 *>(lds.desc);  // {ord(score), branch}
-    constexpr uint32_t kCandCap = (uint32_t)kTilesPerPass * kWave;
-    constexpr float kLog2Of10 = 3.32192809488736f;
-    uint32_t n_sel, n_cand;
-    float best_score;
-    float rel_sum = 0.0f;          // this lane's share of sum_i 10^(score_i - ref_score)
-    bool ranked_in_place = false;  // cand[] already sorted: rank == index
-    uint32_t tau = 1;
-    if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
-        n_sel = n_cand = keep;
-        best_score = thr_score;
-        if ((uint32_t)lane < keep) cand[lane] = make_uint2(ord_f32(thr_score), (uint32_t)lane);
-        ranked_in_place = true;
-    } else {
-        n_sel = keep < touched ? keep : touched;  // :137
-        uint32_t cur = lane_best, got = 0, top = 0;
-        while (got < n_sel) {
-            const uint32_t m = wave_max_u32(cur);
-            if (m == 0) {  // fewer lanes hold edges than rows wanted: every edge is a candidate
-                tau = 1;
-                break;
-            }
-            if (got == 0) top = m;
-            got += (uint32_t)__popcll(__ballot(cur == m));
-            tau = m;
-            if (cur == m) cur = 0;
-        }
-        best_score = unord_f32(top);
-    }
-    const float ref_score = fmaxf(best_score, thr_score);
-    const bool relative_sum = ref_score > -280.0f;  // wave-uniform
-    if (touched != 0) {
-        n_cand = 0;
-        const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
-        auto scan_rows = [&](auto unroll, uint32_t base) {
-            constexpr int kRows = decltype(unroll)::value;
-            float row[kRows];
-#pragma unroll
-            for (int u = 0; u < kRows; ++u) row[u] = lds.score[base + (uint32_t)u * kWave + (uint32_t)lane];
-#pragma unroll
-            for (int u = 0; u < kRows; ++u) {
-                const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
-                const float sc = row[u];             // -inf where there is no edge (a sum of finite
-                const bool edge = sc != -INFINITY;   // log10 scores never is)
-                // exp2(-inf) = 0: rows without an edge add nothing
-                rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
-                const bool is_cand = edge && sc >= tau_f;
-                const uint64_t m = __ballot(is_cand);
-                if (m) {
-                    const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (is_cand && slot < kCandCap) cand[slot] = make_uint2(ord_f32(sc), i);
-                    n_cand += (uint32_t)__popcll(m);
-                }
-            }
-        };
-        {
-            uint32_t base = 0;
-            for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave)
-                scan_rows(std::integral_constant<int, kUnroll>{}, base);
-            for (; base < n_rows_pad; base += kWave) scan_rows(std::integral_constant<int, 1>{}, base);
-        }
-        if (n_cand > kCandCap) {
-            // Too many ties at tau for the candidate buffer: repeated selection over all
-            // edges instead (slow, rare).  Leaves cand[0..n_sel) sorted.
-            uint64_t prev = ~0ull;
-            for (uint32_t r = 0; r < n_sel; ++r) {
-                uint64_t best = 0;
-                for (uint32_t i = lane; i < N; i += kWave) {
-                    const uint2 cv = lds.load(i);
-                    const uint64_t key = ((uint64_t)ord_f32(__uint_as_float(cv.x)) << 32) | (uint64_t)(~i);
-                    if (cv.y != 0 && key < prev && key > best) best = key;
-                }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    const uint64_t o = shfl_xor_u64(best, m);
-                    best = o > best ? o : best;
-                }
-                if (lane == 0) cand[r] = make_uint2((uint32_t)(best >> 32), ~(uint32_t)best);
-                prev = best;
-            }
-            n_cand = n_sel;
-            ranked_in_place = true;
-        }
-    }
-    // ---- rank: <= 3 candidates per lane, rank = number of candidates with a larger key --------
-    const uint32_t n_q = (n_cand + kWave - 1) / kWave;
-    uint64_t my_key[kTilesPerPass];
-    uint32_t my_rank[kTilesPerPass];
-#pragma unroll
-    for (int q = 0; q < kTilesPerPass; ++q) {
-        const uint32_t idx = (uint32_t)q * kWave + (uint32_t)lane;
-        my_key[q] = 0;
-        my_rank[q] = ranked_in_place ? idx : 0u;
-        if ((uint32_t)q < n_q && idx < n_cand) {
-            const uint2 c = cand[idx];
-            my_key[q] = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
-        }
-    }
-    if (!ranked_in_place) {
-        // cand[j] is read at the same address by every lane (LDS broadcast); four per trip.
-        // Entries past n_cand are stale: their key is forced to 0, which outranks nothing.
-        for (uint32_t j0 = 0; j0 < n_cand; j0 += kUnroll) {
-            uint2 c[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) c[u] = cand[j0 + (uint32_t)u];  // < kCandCap + kUnroll: spare entries exist
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const uint64_t kj =
-                    (j0 + (uint32_t)u < n_cand) ? (((uint64_t)c[u].x << 32) | (uint64_t)(~c[u].y)) : 0ull;
-                my_rank[0] += kj > my_key[0] ? 1u : 0u;
-                if (n_q > 1) {
-#pragma unroll
-                    for (int q = 1; q < kTilesPerPass; ++q) my_rank[q] += kj > my_key[q] ? 1u : 0u;
-                }
-            }
-        }
-    }
-    // ---- 10^score of every row that will be reported (:254), the lanes side by side.  The row of
-    // rank 0 carries best_score: its power is rows[0]'s (:191) and, whenever best_score is the
-    // reference point of the relative sum, 10^ref_score as well -- one exp10 instead of three.
-    double my_power[kTilesPerPass];
-    double best_power = 0.0;
-#pragma unroll
-    for (int q = 0; q < kTilesPerPass; ++q) {
-        my_power[q] = 0.0;
-        if ((uint32_t)q < n_q) {
-            const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-            if (has_row) my_power[q] = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));
-            const uint64_t first = __ballot(has_row && my_rank[q] == 0);
-            if (first)
-                best_power = __longlong_as_double(
-                    (long long)readlane_u64((uint64_t)__double_as_longlong(my_power[q]), __builtin_ctzll(first)));
-        }
-    }
-    double score_sum;
-    {
-        const float not_placed = (float)N - (float)touched;  // :174
-        if (relative_sum) {
-            double rel = wave_sum_f64((double)rel_sum);
-            if (not_placed != 0.0f)
-                rel += (double)(not_placed *
-                                __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
-            const double ref_power = (ref_score == best_score) ? best_power : pow10_f64((double)ref_score);
-            score_sum = ref_power * rel;
-        } else {
-            // everything in double, term by term, as place.cpp:174-183
-            double sum_placed = 0.0;
-            for (uint32_t i = lane; i < N; i += kWave) {
-                const uint2 cv = lds.load(i);
-                if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
-            }
-            sum_placed = wave_sum_f64(sum_placed);
-            score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
-        }
-    }
-    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
-
-    // ---- LWR (:241-264), filter_by_ratio (:188-199) ---------------------------------------------
-    const double best_ratio =
-        (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191, rows[0]
-    const double ratio_threshold = best_ratio * keep_factor;                      // :192
-    double my_lwr[kTilesPerPass];
-    uint64_t kept_ranks = 0;  // bit r set <=> the row of rank r passes the filter
-#pragma unroll
-    for (int q = 0; q < kTilesPerPass; ++q) {
-        my_lwr[q] = 0.0;
-        if ((uint32_t)q < n_q) {
-            const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-            if (has_row && score_sum != 0.0 && my_power[q] != 0.0) my_lwr[q] = my_power[q] / score_sum;  // :255-262
-            if (has_row && my_lwr[q] >= ratio_threshold) kept_ranks |= 1ull << my_rank[q];            // :197
-        }
-    }
-    kept_ranks = wave_or_u64(kept_ranks);
-#pragma unroll
-    for (int q = 0; q < kTilesPerPass; ++q) {
-        if ((uint32_t)q < n_q) {
-            const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-            if (has_row && ((kept_ranks >> my_rank[q]) & 1ull)) {
-                const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << my_rank[q]) - 1ull));
-                const uint32_t branch = ~(uint32_t)my_key[q];
-                epik_amd_placement out;
-                out.branch = branch;
-                out.score = unord_f32((uint32_t)(my_key[q] >> 32));
-                out.lwr = my_lwr[q];
-                p.rows[read * keep + slot] = out;
-                if (p.kmer_counts)
-                    p.kmer_counts[read * keep + slot] = (touched && branch < N) ? ((uint32_t)lds.count[branch] & ~(uint32_t)lds.kSeen) : 0u;
-            }
-        }
-    }
-    if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
-
-    // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
-    for (uint32_t i = lane; i < n_rows_pad; i += kWave) lds.store(i, 0u, 0u);
-}
-
-}  // namespace
 
 template <typename Layout, typename CountT>
 __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
@@ -784,17 +37,12 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
     WaveLds<CountT> lds;
     {
         unsigned char *base = lds_raw + (size_t)wave_in_block * p.lds_wave_bytes;
-        lds.score = reinterpret_cast<float *>(base);
-        lds.count = reinterpret_cast<CountT *>(base + (size_t)p.n_pad * 4);
-        lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * (4 + sizeof(CountT)));  // n_pad % 256 == 0
+        lds.carve(base, p.n_pad);
     }
     // LDS byte addresses of the dummy row (cell 0) in the two vectors: row = n_pad - 1 - cell
-    typedef __attribute__((address_space(3))) float lds_f32;
-    typedef __attribute__((address_space(3))) CountT lds_count;
-    const uint32_t score_top = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(lds_f32 *)lds.score + (p.n_pad - 1u) * 4u);
-    const uint32_t count_top = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(lds_count *)lds.count + (p.n_pad - 1u) * (uint32_t)sizeof(CountT));
+    const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (p.n_pad - 1u) * 4u);
+    const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
+                                                              (p.n_pad - 1u) * (uint32_t)sizeof(CountT));
     // the argument block itself, for the out-of-line parts (no private copy of `p`)
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
     for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.store(i, 0u, 0u);
@@ -825,6 +73,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         const uint8_t *__restrict__ seq = p.seqs + seq_begin;
         // place.cpp:322 underflows for len < k; we report "no placement" -- also for a read whose
         // k-mers could overflow this kernel's count type (the host then uses the wide kernel)
+        // (n_rows = kCountsTooNarrow tells the caller, who chose the count width, which case it was)
         if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers) {
             if (p.partial_scores) {  // accumulate-only launch: an all-zero partial vector
                 for (uint32_t i = lane; i < p.num_branches; i += kWave) {
@@ -832,7 +81,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     p.partial_counts[read * p.num_branches + i] = 0u;
                 }
             } else if (lane == 0) {
-                p.n_rows[read] = 0;
+                p.n_rows[read] = len < k ? 0u : kCountsTooNarrow;
             }
             continue;
         }
@@ -906,7 +155,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
 #ifdef EPIK_AMD_ABLATION
             if (p.ablate & 8u) total = 0;   // lookups done, nothing streamed
 #endif
-            uint64_t *chunks = lds.desc;
+            auto *chunks = lds.desc;
             EPIK_STAMP(1)  // lookups landed, scan done
             for (uint32_t w0 = 0; w0 < total; w0 += kChunkCap) {  // one round unless > kChunkCap chunks
                 const uint32_t n_round = min(total - w0, kChunkCap);
@@ -946,85 +195,17 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                 }
                 if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = null_chunk(p);
 
-                // (3) stream the chunks through a ring of kRing in-flight loads.  The loads are
-                // issued from inline asm (Layout::issue): hipcc must not count them, or it would
-                // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
-                // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that
-                // point and loads retire in issue order --, consumes the slot's two registers
-                // inside asm statements only, and refills the slot with the next chunk.
-                // (Letting hipcc read a slot register itself, even behind a "+v" wait, is not
-                // safe: it is free to copy it into another register AHEAD of the wait.)
-                uint32_t ring_c[kRing], ring_s[kRing];
-#pragma unroll
-                for (int i = 0; i < kRing; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
-                // One stage: (1) asm: wait for the slot, turn its cell into the two LDS addresses;
-                // (2) hipcc: both LDS reads, and meanwhile the next chunk's descriptor words out of
-                // the lanes; (3) asm: the float add, reading the score straight from the slot
-                // register (place.cpp:366); (4) hipcc: count + 1 (:365), both LDS writes;
-                // (5) asm: refill the slot.  Every lane updates the row of its posting: branches
-                // are distinct inside a list, and the lanes past the chunk's end all hold the
-                // dummy row, whose content nobody reads.
-                auto stage = [&](uint32_t &slot_cell, uint32_t &slot_score, auto wait_count, auto &&refill_words,
-                                 auto &&refill) {
-                    uint32_t score_addr, count_addr;
-                    asm volatile("s_waitcnt vmcnt(%5)\n\t"
-                                 "v_mad_i32_i24 %0, %2, -4, %3\n\t"
-                                 "v_mad_i32_i24 %1, %2, %6, %4"
-                                 : "=&v"(score_addr), "=&v"(count_addr)
-                                 : "v"(slot_cell), "s"(score_top), "s"(count_top), "n"(decltype(wait_count)::value),
-                                   "n"(-(int)sizeof(CountT))
-                                 : "memory");
-                    lds_f32 *score_cell = (lds_f32 *)(uintptr_t)score_addr;
-                    lds_count *count_cell = (lds_count *)(uintptr_t)count_addr;
-#ifdef EPIK_AMD_ABLATION
-                    const bool skip_acc = (p.ablate & 1u) != 0;
-                    if (skip_acc) asm volatile("" ::"v"(score_addr), "v"(count_addr));
-#else
-                    constexpr bool skip_acc = false;
-#endif
-                    float old_score = 0.0f;
-                    uint32_t old_count = 0;
-                    if (!skip_acc) {
-                        old_score = *score_cell;
-                        old_count = (uint32_t)*count_cell;
-                    }
-                    refill_words();
-                    __builtin_amdgcn_sched_barrier(0);  // the v_readlanes above overlap the LDS reads' latency
-                    float new_score;
-                    asm volatile("v_add_f32 %0, %1, %2" : "=v"(new_score) : "v"(old_score), "v"(slot_score) : "memory");
-                    if (!skip_acc) {
-                        *score_cell = new_score;
-                        *count_cell = (CountT)(old_count + 1u);
-                    }
-                    refill();
-                };
-                uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
-                for (uint32_t c0 = 0; c0 < n_padded; c0 += kRing) {
-                    uint32_t field[Layout::kFields];
-                    Layout::prepare(d_next, field);
-                    d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
-#pragma unroll
-                    for (int i = 0; i < kRing; ++i) {
-                        uint32_t f[Layout::kFields];
-                        stage(
-                            ring_c[i], ring_s[i], std::integral_constant<int, Layout::kLoads *(kRing - 1)>{},
-                            [&]() {
-#pragma unroll
-                                for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
-                            },
-                            [&]() { Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]); });
-                    }
-                }
-                // tail: nothing more to issue; retire the ring (the first stage waits for all of it)
-#pragma unroll
-                for (int i = 0; i < kRing; ++i)
-                    stage(ring_c[i], ring_s[i], std::integral_constant<int, 0>{}, []() {}, []() {});
+                // (3) stream the chunks through the ring of kRing in-flight loads (place_device.hpp)
+                stream_round<Layout, CountT>(p, chunks, n_padded, score_top, count_top);
             }
         }
 
         EPIK_STAMP(2)  // expansion + stream
         // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ------
-        if (any_amb) place_ambiguous<Layout, CountT>(kp, lds, seq, len, n_kmers);
+        if (any_amb) {
+            const int64_t amb_slot = (p.partial_scores && p.amb_slot) ? (int64_t)p.amb_slot[read] : -1;
+            place_ambiguous<Layout, CountT>(kp, lds, seq, len, n_kmers, amb_slot, WaveCtx{});
+        }
 
 #ifdef EPIK_AMD_ABLATION
         if (p.ablate & 2u) {  // skip the whole epilogue
@@ -1042,7 +223,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                 const uint2 cv = lds.load(i);
                 if (i < p.num_branches) {
                     p.partial_scores[read * p.num_branches + i] = __uint_as_float(cv.x);
-                    p.partial_counts[read * p.num_branches + i] = cv.y & ~(uint32_t)WaveLds<CountT>::kSeen;
+                    p.partial_counts[read * p.num_branches + i] = (uint16_t)(cv.y & ~(uint32_t)WaveLds<CountT>::kSeen);
                 }
                 lds.store(i, 0u, 0u);
             }
@@ -1050,7 +231,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         }
         // ---- correction, sum_scores, top-k, LWR, rows out, reset of the wave's vectors ----------
         if (lane == 0) lds.store(p.n_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
-        place_epilogue<Layout, CountT>(kp, lds, read, n_kmers);
+        place_epilogue<Layout, CountT>(kp, lds, read, n_kmers, WaveCtx{});
         EPIK_STAMP(4)  // top-k, LWR, rows out, reset
     }
 #ifdef EPIK_AMD_ABLATION
@@ -1072,9 +253,7 @@ __global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
     WaveLds<CountT> lds;
     {
         unsigned char *base = lds_raw + (size_t)wave_in_block * p.lds_wave_bytes;
-        lds.score = reinterpret_cast<float *>(base);
-        lds.count = reinterpret_cast<CountT *>(base + (size_t)p.n_pad * 4);
-        lds.desc = reinterpret_cast<uint64_t *>(base + (size_t)p.n_pad * (4 + sizeof(CountT)));
+        lds.carve(base, p.n_pad);
     }
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();
     for (uint32_t i = lane; i < p.n_pad; i += kWave) lds.store(i, 0u, 0u);
@@ -1084,77 +263,39 @@ __global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
     for (uint64_t read = wave_global; read < p.n_reads; read += total_waves) {
         const uint64_t len = p.seq_offsets[read + 1] - p.seq_offsets[read];
         if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers) {
-            if (lane == 0) p.n_rows[read] = 0;
+            if (lane == 0) p.n_rows[read] = len < k ? 0u : kCountsTooNarrow;
             continue;
         }
-        for (uint32_t i = lane; i < p.num_branches; i += kWave)
-            lds.store(i, __float_as_uint(p.partial_scores[read * p.num_branches + i]),
-                      p.partial_counts[read * p.num_branches + i]);
-        place_epilogue<PackedLayout<kPlainTable>, CountT>(kp, lds, read, len - k + 1);  // also clears the vectors
+        // the read's one ambiguous-key record per branch (place.cpp:400-410), already reduced over the
+        // shards to the key of smallest order: its average probability joins the sum after all exact
+        // scores, as in the one-pass loop, and counts as one k-mer
+        const int64_t slot = p.amb_slot ? (int64_t)p.amb_slot[read] : -1;
+        for (uint32_t i = lane; i < p.num_branches; i += kWave) {
+            float sc = p.partial_scores[read * p.num_branches + i];
+            uint32_t c = p.partial_counts[read * p.num_branches + i];
+            if (slot >= 0) {
+                const float avg = p.amb_avg[(uint64_t)slot * p.num_branches + i];
+                if (avg > 0.0f) {
+                    sc = __fadd_rn(sc, avg);
+                    c += 1u;
+                }
+            }
+            lds.store(i, __float_as_uint(sc), c);
+        }
+        place_epilogue<PackedLayout<kPlainTable>, CountT>(kp, lds, read, len - k + 1, WaveCtx{});  // also clears the vectors
     }
 }
 
-// Algorithmic bytes of SURVEY.md 8(d): one thread per read, plain loops.
+// Algorithmic bytes of SURVEY.md 8(d): one thread per read, plain loops (place_device.hpp).
 template <typename Layout>
 __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *total)
 {
-    const uint64_t read = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long bytes = 0;
-    if (read < p.n_reads) {
-        const uint64_t b = p.seq_offsets[read];
-        const uint64_t len = p.seq_offsets[read + 1] - b;
-        const uint8_t *seq = p.seqs + b;
-        const uint32_t k = p.kmer_size;
-        bytes = len;
-        if (len >= k) {
-            const uint64_t n_kmers = len - k + 1;
-            bytes += 8ull * n_kmers;
-            unsigned long long entries = 0;
-            for (uint64_t pos = 0; pos < n_kmers; ++pos) {
-                uint64_t key = 0, weight = 0;
-                uint32_t n_amb = 0, amb_cls = 0, amb_pos = 0;
-                bool ok = true;
-                for (uint32_t j = 0; j < k; ++j) {
-                    const uint32_t cls = p.char_class[seq[pos + j]];
-                    if (cls == 0) { ok = false; break; }
-                    uint32_t st = 0;
-                    if (cls & (cls - 1)) { ++n_amb; amb_cls = cls; amb_pos = j; }
-                    else st = (uint32_t)(__ffs((int)cls) - 1);
-                    key = key * p.alphabet_size + st;
-                }
-                if (!ok || n_amb > 1) continue;
-                uint64_t addr;
-                uint32_t llen;
-                if (n_amb == 0) {
-                    Layout::lookup(p, (uint32_t)key, 0u, addr, llen);
-                    entries += llen;
-                } else {
-                    weight = 1;
-                    for (uint32_t j = amb_pos + 1; j < k; ++j) weight *= p.alphabet_size;
-                    for (uint32_t st = 0; st < p.alphabet_size; ++st)
-                        if ((amb_cls >> st) & 1u) {
-                            const uint64_t kk = key + (uint64_t)st * weight;
-                            Layout::lookup(p, (uint32_t)kk, 0u, addr, llen);
-                            entries += llen;
-                        }
-                }
-            }
-            bytes += 8ull * entries;
-            if (p.n_rows) bytes += 16ull * p.n_rows[read];
-        }
-    }
-    // block reduce then one atomic
-    __shared__ unsigned long long partial[64];
-    unsigned long long v = bytes;
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) partial[w] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long s = 0;
-        for (unsigned i = 0; i < (blockDim.x >> 6); ++i) s += partial[i];
-        atomicAdd(total, s);
-    }
+    algorithmic_bytes_block(p, total, [&](uint32_t key) {
+        uint64_t addr;
+        uint32_t llen;
+        Layout::lookup(p, key, 0u, addr, llen);
+        return llen;
+    });
 }
 
 namespace {
@@ -1179,6 +320,7 @@ hipError_t dispatch(DbLayout layout, int counts, F &&f)
         case DbLayout::kPacked: return dispatch_counts<PackedLayout<kPlainTable>>(counts, f);
         case DbLayout::kPaired: return dispatch_counts<PackedLayout<kPairedTable>>(counts, f);
         case DbLayout::kFiltered: return dispatch_counts<PackedLayout<kFilteredTable>>(counts, f);
+        case DbLayout::kTeam: break;  // team_kernel.hip
     }
     return hipErrorInvalidValue;
 }

@@ -1,0 +1,538 @@
+// team_kernel.hip -- large trees: ONE WORKGROUP PLACES ONE READ, the branch range split over
+// its wavefronts.
+//
+// Reference path: the same as place_kernel.hip (epik/src/epik/place.cpp:278-440, 134-199, 241-267).
+// place.cpp:92-96 sizes the per-thread score and count vectors by tree.get_node_count() without any
+// bound.  With one wavefront per read (place_kernel.hip) a wave owns a whole vector in LDS: at
+// N ~ 10 000 branches three waves fit a CU, and beyond ~20 000 none does.  Here the W waves of a
+// workgroup place ONE read together: wave w owns the rows of slice w of the branch range, and the
+// database is stored pre-split the same way -- every posting list as W sublists, one per slice,
+// in the list's original order (create(), capi.hip).  A branch still receives its float32 adds in
+// exactly the k-mer order of place.cpp:349-371, because every wave walks the read's k-mers in
+// order and the postings of one list are distinct branches: bit-identical sums, as before.
+// Trees too large even for that are placed in P passes over S = W * P slices (pass p = slices
+// p*W .. p*W + W-1, a table of its own), so there is no upper bound on the tree.
+//
+//   front end   wave t encodes tile t of a group of W tiles, looks the k-mers up (one table entry
+//               {line, len[W]} gives all W sublists) and, after the tile totals have crossed LDS,
+//               writes the chunk descriptors of every slice into that slice's list, in read order;
+//   stream      wave w runs its own list through the ring of place_device.hpp into its rows;
+//   ambiguous   (cold) every wave sweeps the read's ambiguous keys for its slice;
+//   epilogue    every wave: correction, its slice's best rows and share of sum_scores -> LDS;
+//   merge       the last wave (idle in the front end of short reads): the slices' rows ranked
+//               together, sum_scores, like-weight-ratios, filter, rows out -- while the other
+//               waves already encode the next read.
+//
+// HBM-bandwidth bound gather / scatter-add; no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "place_device.hpp"
+
+namespace epik_amd {
+
+namespace {
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) v4u lds_u32x4;
+typedef __attribute__((address_space(3))) TeamPartial lds_partial;
+
+// Table entry of the team layout: {u32 line, u16 len[W]}, padded to 16 / 32 / 64 bytes.  The W
+// sublists lie back to back from byte line * 128 on, each in chunks of <= 64 postings (f32 score[cnt]
+// then u16 cell[cnt], cell local to the slice, 0 = the slice's dummy row) and padded to 4 bytes.
+template <int W>
+struct TeamEntry {
+    static constexpr int kWords = team_entry_bytes(W) / 4;
+    uint32_t line;
+    uint32_t len[W];
+    __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key)
+    {
+        const uint4 *e = reinterpret_cast<const uint4 *>(tp.team_table + ((uint64_t)pass * tp.num_keys + key) * (kWords * 4u));
+        uint32_t w[kWords];
+#pragma unroll
+        for (int i = 0; i < kWords / 4; ++i) {
+            const uint4 v = e[i];
+            w[4 * i] = v.x;
+            w[4 * i + 1] = v.y;
+            w[4 * i + 2] = v.z;
+            w[4 * i + 3] = v.w;
+        }
+        line = w[0];
+#pragma unroll
+        for (int s = 0; s < W; ++s) len[s] = (w[1 + s / 2] >> (16 * (s & 1))) & 0xffffu;
+    }
+    // byte offset of sublist s in the posting region
+    __device__ __forceinline__ uint64_t start(int s) const
+    {
+        uint32_t off = 0;
+#pragma unroll
+        for (int q = 0; q < W; ++q)
+            if (q < s) off += (len[q] * 6u + 3u) & ~3u;
+        return (uint64_t)line * 128u + off;
+    }
+};
+
+// The slice of the branch range one wave of a team accumulates (see WaveCtx in place_device.hpp).
+template <int W>
+struct TeamCtx {
+    static constexpr bool kTeam = true;
+    static constexpr int kCandGroups = 1;  // top-k candidates of a slice: one per lane
+    uint32_t rows_pad_, rows_, base_, slice_, pass_;
+    lds_u32x4 *cand;       // [keep_at_most] ranked rows of this slice for the merge
+    lds_partial *partial;  // this slice's share of sum_scores
+    __device__ __forceinline__ uint32_t rows_pad(const PlaceParams &) const { return rows_pad_; }
+    __device__ __forceinline__ uint32_t rows(const PlaceParams &) const { return rows_; }
+    __device__ __forceinline__ uint32_t branch_base() const { return base_; }
+    template <typename Layout>
+    __device__ __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr, uint32_t &len) const
+    {
+        const TeamParams &tp = reinterpret_cast<const TeamParams &>(p);  // PlaceParams is its first member
+        TeamEntry<W> e;
+        e.load(tp, pass_, key);
+        addr = e.line * 128ull;
+        len = 0;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            if ((uint32_t)s < slice_) addr += (e.len[s] * 6u + 3u) & ~3u;
+            if ((uint32_t)s == slice_) len = e.len[s];
+        }
+    }
+};
+
+typedef PackedLayout<kPlainTable> TeamChunks;  // the chunk format (and its loads) of the packed layout
+
+// ---------------------------------------------------------------------------------
+// The merge of a team placement, by one wave: the slices' ranked rows (S * keep_at_most slots of
+// {ord(score), branch, count, -}, empty slots 0) ranked together, then exactly the tail of
+// place_epilogue: sum_scores (:164-184) from the slices' partial sums, like-weight-ratios
+// (:241-264), filter_by_ratio (:188-199), rows out.
+// ---------------------------------------------------------------------------------
+__device__ __attribute__((noinline)) void team_merge(const PlaceParams *__restrict__ kp, lds_u32x4 *cand,
+                                                     uint32_t cand_stride, lds_partial *partials, uint32_t n_slices,
+                                                     uint64_t read, uint64_t n_kmers)
+{
+    const PlaceParams &p = *kp;
+    const int lane = lane_id();
+    const uint32_t keep = p.keep_at_most;
+    const uint32_t M = n_slices * keep;
+    const float k_f = (float)p.kmer_size;
+    const float thr_score = __fdiv_rn(__fmul_rn((float)n_kmers, p.log_threshold), k_f);  // :175 / :146-147
+    constexpr float kLog2Of10 = 3.32192809488736f;
+    uint32_t touched = 0;
+    for (uint32_t s = 0; s < n_slices; ++s) touched += partials[s].touched;
+    uint32_t n_sel;
+    float best_score;
+    if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
+        n_sel = keep;
+        best_score = thr_score;
+        for (uint32_t i = lane; i < M; i += kWave)
+            cand[(i / keep) * cand_stride + i % keep] =
+                i < keep ? v4u{ord_f32(thr_score), i, 0u, i} : v4u{0u, 0u, 0u, 0u};
+    } else {
+        n_sel = keep < touched ? keep : touched;  // :137
+        uint32_t best_ord = 0;
+        for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint64_t key = 0;
+            if (i < M) {
+                const v4u c = cand[(i / keep) * cand_stride + i % keep];
+                key = c.x ? (((uint64_t)c.x << 32) | (uint64_t)(~c.y)) : 0ull;
+            }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < M; ++j) {  // the same address in every lane: an LDS broadcast
+                const v4u c = cand[(j / keep) * cand_stride + j % keep];
+                const uint64_t kj = c.x ? (((uint64_t)c.x << 32) | (uint64_t)(~c.y)) : 0ull;
+                rank += kj > key ? 1u : 0u;
+            }
+            if (i < M) cand[(i / keep) * cand_stride + i % keep].w = rank;
+            const uint64_t first = __ballot(key != 0 && rank == 0);
+            if (first) best_ord = __builtin_amdgcn_readlane((uint32_t)(key >> 32), __builtin_ctzll(first));
+        }
+        best_score = unord_f32(best_ord);
+    }
+    // ---- sum_scores (:164-184) ------------------------------------------------------------------
+    const float ref_score = fmaxf(best_score, thr_score);
+    const double best_power = pow10_f64((double)best_score);
+    double score_sum;
+    {
+        double rel = 0.0, absolute = 0.0;
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            if (partials[s].touched == 0) continue;
+            const double sum = partials[s].sum;
+            if (partials[s].relative)
+                rel += sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(partials[s].ref_score, ref_score), kLog2Of10));
+            else
+                absolute += sum;
+        }
+        const float not_placed = (float)p.num_branches - (float)touched;  // :174
+        if (ref_score > -280.0f) {
+            if (not_placed != 0.0f)
+                rel += (double)(not_placed * __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
+            const double ref_power = (ref_score == best_score) ? best_power : pow10_f64((double)ref_score);
+            score_sum = ref_power * rel + absolute;
+        } else {
+            score_sum = (double)not_placed * pow10_f64((double)thr_score) + absolute;  // :174-183, all double
+        }
+    }
+    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
+    const double best_ratio = (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191
+    const double ratio_threshold = best_ratio * keep_factor;                                           // :192
+    // ---- LWR (:241-264), filter_by_ratio (:188-199): which ranks stay --------------------------
+    uint64_t kept_ranks = 0;
+    for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        if (i < M) {
+            const v4u c = cand[(i / keep) * cand_stride + i % keep];
+            if (c.x != 0 && c.w < n_sel) {
+                const double power = pow10_f64((double)unord_f32(c.x));
+                const double lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;  // :255-262
+                if (lwr >= ratio_threshold) kept_ranks |= 1ull << c.w;                              // :197
+            }
+        }
+    }
+    kept_ranks = wave_or_u64(kept_ranks);
+    for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        if (i < M) {
+            const v4u c = cand[(i / keep) * cand_stride + i % keep];
+            if (c.x != 0 && c.w < n_sel && ((kept_ranks >> c.w) & 1ull)) {
+                const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << c.w) - 1ull));
+                const double power = pow10_f64((double)unord_f32(c.x));
+                epik_amd_placement out;
+                out.branch = c.y;
+                out.score = unord_f32(c.x);
+                out.lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;
+                p.rows[read * keep + slot] = out;
+                if (p.kmer_counts) p.kmer_counts[read * keep + slot] = c.z;
+            }
+        }
+    }
+    if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
+}
+
+}  // namespace
+
+enum : int { kTeamPlace = kTeamModePlace, kTeamAccumulate = kTeamModeAccumulate, kTeamFinish = kTeamModeFinish };
+
+template <int W, typename CountT, int kMode>
+__global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    typedef WaveLds<CountT> Lds;
+    const PlaceParams &p = tp.base;
+    const int lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rows_pad = tp.rows_pad;
+    // ---- LDS: the W slices' rows | the W descriptor lists | tile totals + flags | partial sums |
+    //      (more than one pass only) the slices' ranked rows.  With one pass a slice's ranked rows
+    //      lie at the start of its wave's descriptor list, idle by then.
+    Lds lds;
+    unsigned char *desc_base = lds_raw + (size_t)W * tp.slice_bytes;
+    lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave * tp.slice_bytes);
+    lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave * tp.slice_bytes + (size_t)rows_pad * 4);
+    lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave * tp.desc_bytes);
+    lds_u32 *totals = (lds_u32 *)reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes);  // [W tiles][W slices]
+    lds_u32 *flags = totals + W * W;                                                                      // [2]: any ambiguous k-mer, by read parity
+    lds_partial *partials = (lds_partial *)reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4);
+    const uint32_t n_slices = W * tp.passes;
+    lds_u32x4 *merge_cand;
+    uint32_t merge_stride;  // in entries of 16 bytes, from one slice's rows to the next
+    if (tp.passes == 1) {
+        merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(desc_base);
+        merge_stride = tp.desc_bytes / 16u;
+    } else {
+        merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4) + n_slices);
+        merge_stride = p.keep_at_most;
+    }
+    const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
+    const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
+                                                              (rows_pad - 1u) * (uint32_t)sizeof(CountT));
+    const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // = &tp.base
+    for (uint32_t i = lane; i < rows_pad; i += kWave) lds.store(i, 0u, 0u);
+    if (threadIdx.x < 2) flags[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const uint32_t k = p.kmer_size;
+    const uint32_t sigma = p.alphabet_size;
+    const uint32_t stride = kWave - (k - 1);  // windows per 64-character tile
+    const uint32_t cap = tp.desc_cap;
+
+    for (uint64_t read = blockIdx.x; read < p.n_reads; read += gridDim.x) {
+        const uint64_t seq_begin = readlane_u64(p.seq_offsets[read], 0);
+        const uint64_t len = readlane_u64(p.seq_offsets[read + 1], 0) - seq_begin;
+        const uint8_t *__restrict__ seq = p.seqs + seq_begin;
+        // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than
+        // this launch's counts hold is marked (the caller chose the count width).  Uniform over the
+        // workgroup: nobody is left waiting at a barrier.
+        if (len < k || len - k + 1 > Lds::kMaxKmers) {
+            if (kMode == kTeamAccumulate) {  // an all-zero partial vector
+                for (uint32_t i = threadIdx.x; i < p.num_branches; i += W * kWave) {
+                    p.partial_scores[read * p.num_branches + i] = 0.0f;
+                    p.partial_counts[read * p.num_branches + i] = 0u;
+                }
+            } else if (threadIdx.x == 0) {
+                p.n_rows[read] = len < k ? 0u : kCountsTooNarrow;
+            }
+            continue;
+        }
+        const uint64_t n_kmers = len - k + 1;  // :322
+        const uint32_t parity = (uint32_t)read & 1u;
+        bool any_amb = false;  // the same in every wave of the workgroup
+
+        for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+            TeamCtx<W> ctx;
+            ctx.rows_pad_ = rows_pad;
+            ctx.slice_ = wave;
+            ctx.pass_ = pass;
+            ctx.base_ = (pass * W + wave) * tp.slice_rows;
+            ctx.rows_ = ctx.base_ >= p.num_branches ? 0u : min(tp.slice_rows, p.num_branches - ctx.base_);
+            ctx.cand = merge_cand + (size_t)(pass * W + wave) * merge_stride;
+            ctx.partial = partials + (pass * W + wave);
+
+            if (kMode == kTeamFinish) {
+                // second half of a k-mer-space-sharded placement: the slice's totals come back from HBM
+                // (see finish_reads_kernel in place_kernel.hip for the ambiguous record)
+                const int64_t slot = p.amb_slot ? (int64_t)p.amb_slot[read] : -1;
+                for (uint32_t i = lane; i < ctx.rows_; i += kWave) {
+                    const uint64_t at = read * p.num_branches + ctx.base_ + i;
+                    float sc = p.partial_scores[at];
+                    uint32_t c = p.partial_counts[at];
+                    if (slot >= 0) {
+                        const float avg = p.amb_avg[(uint64_t)slot * p.num_branches + ctx.base_ + i];
+                        if (avg > 0.0f) {
+                            sc = __fadd_rn(sc, avg);
+                            c += 1u;
+                        }
+                    }
+                    lds.store(i, __float_as_uint(sc), c);
+                }
+            } else {
+                // ---- exact k-mers, read order (place.cpp:294-305, 349-371) ------------------------
+                for (uint64_t group_pos = 0; group_pos < n_kmers; group_pos += (uint64_t)W * stride) {
+                    const uint64_t tile_pos = group_pos + (uint64_t)wave * stride;
+                    const bool has_tile = tile_pos < n_kmers;  // wave-uniform
+                    uint64_t start[W];
+                    uint32_t llen[W], nch[W], first[W], tile_total[W];
+#pragma unroll
+                    for (int s = 0; s < W; ++s) {
+                        start[s] = 0;
+                        llen[s] = nch[s] = first[s] = tile_total[s] = 0;
+                    }
+                    if (has_tile) {
+                        const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
+                        bool exact = tl.in_range;
+                        if ((tl.inv_mask | tl.amb_mask) != 0) {  // wave-uniform, cold
+                            const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+                            const uint64_t inv_w = (tl.inv_mask >> lane) & wmask;
+                            const uint64_t amb_w = (tl.amb_mask >> lane) & wmask;
+                            const bool is_amb = tl.in_range && inv_w == 0 && __popcll(amb_w) == 1;
+                            exact = tl.in_range && inv_w == 0 && amb_w == 0;
+                            if (__ballot(is_amb) != 0 && lane == 0) flags[parity] = 1u;
+                        }
+                        if (exact) {
+                            TeamEntry<W> e;
+                            e.load(tp, pass, tl.key);
+#pragma unroll
+                            for (int s = 0; s < W; ++s) {
+                                llen[s] = e.len[s];
+                                start[s] = e.start(s);
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < W; ++s) {
+                            nch[s] = (llen[s] + (uint32_t)kWave - 1u) >> 6;
+                            const uint32_t incl = wave_incl_scan_u32(nch[s]);
+                            first[s] = incl - nch[s];
+                            tile_total[s] = __builtin_amdgcn_readlane(incl, 63);
+                        }
+                    }
+                    {   // chunks per (tile, slice) across the workgroup
+                        uint32_t mine = tile_total[0];
+#pragma unroll
+                        for (int s = 1; s < W; ++s) mine = (lane == s) ? tile_total[s] : mine;
+                        if (lane < W) totals[wave * W + (uint32_t)lane] = mine;
+                    }
+                    __syncthreads();
+                    any_amb = any_amb || flags[parity] != 0u;  // set before the barrier; cleared two barriers later at the earliest
+                    uint32_t base[W];       // chunks of the earlier tiles of this group, per slice
+                    uint32_t my_total = 0;  // chunks of this wave's slice in the group
+                    uint32_t max_total = 0;
+                    {   // the W x W table comes out of LDS once, one entry per lane; the sums are scalar work
+                        constexpr int kRegs = (W * W + kWave - 1) / kWave;
+                        uint32_t held[kRegs];
+#pragma unroll
+                        for (int q = 0; q < kRegs; ++q)
+                            held[q] = (q * kWave + lane < W * W) ? totals[q * kWave + lane] : 0u;
+#pragma unroll
+                        for (int s = 0; s < W; ++s) {
+                            uint32_t sum = 0;
+                            base[s] = 0;
+#pragma unroll
+                            for (int t = 0; t < W; ++t) {
+                                const uint32_t v = __builtin_amdgcn_readlane(held[(t * W + s) / kWave], (t * W + s) % kWave);
+                                base[s] += (uint32_t)t < wave ? v : 0u;
+                                sum += v;
+                            }
+                            my_total = (uint32_t)s == wave ? sum : my_total;
+                            max_total = max(max_total, sum);
+                        }
+                    }
+                    // rounds of at most `cap` chunks per slice (one, unless a list is very long)
+                    for (uint32_t w0 = 0; w0 < max_total || w0 == 0; w0 += cap) {
+                        if (has_tile) {
+                            // Every lane writes the first kOwnChunks chunks of its own sublists; the rest of
+                            // a longer sublist is written by the whole wave, lane j writing chunk kOwnChunks + j.
+                            constexpr uint32_t kOwnChunks = 3;
+#pragma unroll
+                            for (int s = 0; s < W; ++s) {
+                                auto *list = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)s * tp.desc_bytes);
+                                const uint32_t at = base[s] + first[s];
+#pragma unroll
+                                for (uint32_t c = 0; c < kOwnChunks; ++c) {
+                                    const uint32_t idx = at + c - w0;  // wraps when in front of the window
+                                    if (nch[s] > c && idx < cap) {
+                                        const uint32_t rest = llen[s] - (c << 6);
+                                        const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                                        list[idx] = chunk_address<TeamChunks>(p, start[s], c) | (cnt << 48);
+                                    }
+                                }
+                                uint64_t long_lists = __ballot(nch[s] > kOwnChunks);
+                                while (long_lists) {
+                                    const int m = __builtin_ctzll(long_lists);
+                                    long_lists &= long_lists - 1;
+                                    const uint32_t l_first = __builtin_amdgcn_readlane(at, m);
+                                    const uint32_t l_len = __builtin_amdgcn_readlane(llen[s], m);
+                                    const uint64_t l_start = readlane_u64(start[s], m);
+                                    for (uint32_t c = (uint32_t)lane + kOwnChunks; (c << 6) < l_len; c += kWave) {
+                                        const uint32_t idx = l_first + c - w0;
+                                        if (idx < cap) {
+                                            const uint32_t rest = l_len - (c << 6);
+                                            const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                                            list[idx] = chunk_address<TeamChunks>(p, l_start, c) | (cnt << 48);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        if (my_total > w0) {
+                            const uint32_t n_round = min(my_total - w0, cap);
+                            const uint32_t n_padded = (n_round + (uint32_t)kRing - 1u) & ~((uint32_t)kRing - 1u);
+                            if ((uint32_t)lane < n_padded - n_round) lds.desc[n_round + lane] = null_chunk(p);
+                            stream_round<TeamChunks, CountT>(p, lds.desc, n_padded, score_top, count_top);
+                        }
+                        __syncthreads();
+                    }
+                }
+                // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ----------
+                if (any_amb) {
+                    const int64_t amb_slot = (kMode == kTeamAccumulate && p.amb_slot) ? (int64_t)p.amb_slot[read] : -1;
+                    place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, amb_slot, ctx);
+                }
+            }
+            if (kMode == kTeamAccumulate) {
+                // k-mer-space shard: the slice's raw sums and counts leave for HBM (see place_kernel.hip)
+                for (uint32_t i = lane; i < rows_pad; i += kWave) {
+                    const uint2 cv = lds.load(i);
+                    if (i < ctx.rows_) {
+                        const uint64_t at = read * p.num_branches + ctx.base_ + i;
+                        p.partial_scores[at] = __uint_as_float(cv.x);
+                        p.partial_counts[at] = (uint16_t)(cv.y & ~(uint32_t)Lds::kSeen);
+                    }
+                    lds.store(i, 0u, 0u);
+                }
+            } else {
+                // ---- correction, the slice's best rows and share of sum_scores, reset of the rows ----
+                if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
+                place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
+            }
+        }
+        if (kMode != kTeamAccumulate) {
+            __syncthreads();  // every slice's rows and sums are in LDS
+            if (wave == W - 1) team_merge(kp, merge_cand, merge_stride, partials, n_slices, read, n_kmers);
+            // placing, the barriers of the next read's front end keep the other waves' next epilogue
+            // off the merge area until the merge is done; finishing, there is no front end
+            if (kMode == kTeamFinish) __syncthreads();
+        }
+        if (kMode != kTeamFinish && wave == 0 && lane == 0) flags[parity] = 0u;  // read again two reads on
+    }
+}
+
+// Algorithmic bytes of SURVEY.md 8(d) on the sliced database: a code's list is its sublists of all passes.
+template <int W>
+__global__ void team_algorithmic_bytes_kernel(TeamParams tp, unsigned long long *total)
+{
+    algorithmic_bytes_block(tp.base, total, [&](uint32_t key) {
+        uint32_t n = 0;
+        for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+            TeamEntry<W> e;
+            e.load(tp, pass, key);
+#pragma unroll
+            for (int s = 0; s < W; ++s) n += e.len[s];
+        }
+        return n;
+    });
+}
+
+namespace {
+
+template <typename F>
+hipError_t team_dispatch(int waves, int counts, int mode, F &&f)
+{
+#define EPIK_TEAM_CASE(W, C, M) \
+    if (waves == W && counts == C && mode == M) \
+        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M>();
+#define EPIK_TEAM_MODES(W, C) EPIK_TEAM_CASE(W, C, kTeamPlace) EPIK_TEAM_CASE(W, C, kTeamAccumulate) EPIK_TEAM_CASE(W, C, kTeamFinish)
+#define EPIK_TEAM_COUNTS(W) EPIK_TEAM_MODES(W, kCounts8) EPIK_TEAM_MODES(W, kCounts16) EPIK_TEAM_MODES(W, kCounts32)
+    EPIK_TEAM_COUNTS(4)
+    EPIK_TEAM_COUNTS(8)
+#undef EPIK_TEAM_COUNTS
+#undef EPIK_TEAM_MODES
+#undef EPIK_TEAM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t launch_team(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
+                       hipStream_t stream)
+{
+    return team_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
+        hipLaunchKernelGGL((team_place_kernel<W, C, M>), grid, dim3(W * 64), lds_bytes, stream, tp);
+        return hipGetLastError();
+    });
+}
+
+hipError_t set_team_lds_limit(int waves, int counts, size_t lds_bytes)
+{
+    hipError_t err = hipSuccess;
+    for (int mode = 0; mode < 3 && err == hipSuccess; ++mode)
+        err = team_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_place_kernel<W, C, M>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        });
+    return err;
+}
+
+hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
+{
+    return team_dispatch(waves, counts, kTeamPlace, [&]<int W, typename C, int M>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_place_kernel<W, C, M>, W * 64, lds_bytes);
+    });
+}
+
+hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream)
+{
+    const dim3 block(256), grid((unsigned)((tp.base.n_reads + 255) / 256));
+    if (waves == 4)
+        hipLaunchKernelGGL((team_algorithmic_bytes_kernel<4>), grid, block, 0, stream, tp, d_total);
+    else if (waves == 8)
+        hipLaunchKernelGGL((team_algorithmic_bytes_kernel<8>), grid, block, 0, stream, tp, d_total);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace epik_amd

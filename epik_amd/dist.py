@@ -93,38 +93,97 @@ def owner_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return min(n_items, rank * per), min(n_items, (rank + 1) * per)
 
 
-def place_kmer_sharded(accumulate: Callable, finish: Callable, n_reads: int, dist, gather_to: int | None = 0):
+AMB_NONE = 0xFFFFFFFF  # amb_order of a branch no ambiguous key of the shard reached
+
+
+def amb_slots(seqs: np.ndarray, seq_offsets: np.ndarray, char_class: np.ndarray, world: int):
+    """Slots for the reads that may hold an ambiguous k-mer (any character that is not one plain
+    state), laid out for the exchange of `place_kmer_sharded`: the reads of owner j (`owner_bounds`)
+    get the slots j * per_owner .. in read order.  Returns (int32 amb_slot[n] with -1 = none, per_owner);
+    identical on every rank, as all of them hold the same batch."""
+    n = len(seq_offsets) - 1
+    plain = np.array([bin(int(c)).count("1") == 1 for c in char_class], dtype=bool)
+    dirty = (~plain[np.asarray(seqs, dtype=np.uint8)]).astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(dirty)])
+    offs = np.asarray(seq_offsets, dtype=np.int64)
+    has = (csum[offs[1:]] - csum[offs[:-1]]) > 0
+    slot = np.full(n, -1, dtype=np.int32)
+    counts = []
+    for j in range(world):
+        b, e = owner_bounds(n, j, world)
+        counts.append(int(has[b:e].sum()))
+    per_owner = max(counts) if counts else 0
+    for j in range(world):
+        b, e = owner_bounds(n, j, world)
+        idx = np.nonzero(has[b:e])[0] + b
+        slot[idx] = j * per_owner + np.arange(len(idx), dtype=np.int32)
+    return slot, per_owner
+
+
+def combine_amb(order, avg):
+    """[shards, rows, N] records of the shards -> per branch the average probability of the ambiguous
+    key of smallest order over the shards, 0 where no shard has one (place.cpp:385-388: only the first
+    ambiguous key that reaches a branch scores it -- first over the whole database)."""
+    import torch
+    order = order.to(torch.int64) & 0xFFFFFFFF
+    best = order.min(dim=0).values
+    chosen = (order == best.unsqueeze(0)) & (order != AMB_NONE)
+    # a key lives in exactly one shard, so at most one shard is chosen per branch
+    return torch.where(chosen, avg, torch.zeros_like(avg)).sum(dim=0)
+
+
+def place_kmer_sharded(accumulate: Callable, finish: Callable, n_reads: int, dist, gather_to: int | None = 0,
+                       amb_slot: np.ndarray | None = None, amb_per_owner: int = 0):
     """K-mer-space-sharded placement of one batch that every rank holds in full.
 
-    accumulate(n_rows_padded) -> (scores float32 [n_rows_padded, N], counts int32 [n_rows_padded, N])
+    accumulate(n_rows_padded, amb_slot, amb_rows) -> (scores float32 [n_rows_padded, N], counts int16
+        [n_rows_padded, N] (the bits of uint16 counts), amb_order int32 [amb_rows, N] (the bits of uint32
+        orders), amb_avg float32 [amb_rows, N]) -- the last two None when amb_rows == 0 --
         torch tensors on this rank's device: the raw per-branch sums of THIS rank's lists for reads
-        0..n_reads-1; the padding rows behind n_reads must be zero
-        (Placer.accumulate_device on a placer created with shard_index=rank, shard_count=world);
-    finish(begin, end, scores, counts) -> (rows, n_rows, kmer_counts) numpy arrays for the reads
-        [begin, end) this rank owns, from their totals (Placer.finish_device).
+        0..n_reads-1 (the padding rows behind n_reads must be zero) and the records of their ambiguous
+        k-mers (Placer.accumulate_device on a placer created with shard_index=rank, shard_count=world);
+    finish(begin, end, scores, counts, amb_slot, amb_avg) -> (rows, n_rows, kmer_counts) numpy arrays for
+        the reads [begin, end) this rank owns, from their totals; amb_slot (int32 [end - begin], -1 = none)
+        indexes the rows of amb_avg (Placer.finish_device).
+    amb_slot / amb_per_owner: from `amb_slots` (None: no read of the batch can hold an ambiguous k-mer).
 
     Returns like `place_sharded`: the rank's own rows, or everything on `gather_to`.
     """
     rank, _, world = env_rank_world()
+    if amb_slot is None or amb_per_owner == 0:
+        amb_slot, amb_per_owner = None, 0
     if dist is None:
-        scores, counts = accumulate(n_reads)
-        return finish(0, n_reads, scores, counts)
+        scores, counts, _, amb_avg = accumulate(n_reads, amb_slot, amb_per_owner)
+        if amb_avg is not None:  # one shard: the record is the total; AMB_NONE rows carry avg 0 already
+            pass
+        return finish(0, n_reads, scores, counts, amb_slot, amb_avg)
     import torch
     per = -(-n_reads // world)
-    scores, counts = accumulate(per * world)
+    scores, counts, amb_order, amb_avg = accumulate(per * world, amb_slot, amb_per_owner * world)
     assert scores.shape[0] == per * world and counts.shape == scores.shape
     begin, end = owner_bounds(n_reads, rank, world)
+
+    def exchange(part):
+        # slice j of `part` goes to rank j; what arrives is every rank's partial of MY slice.  The rows
+        # cross as bytes: the collectives of some backends do not take 16-bit integers.
+        sent = part.contiguous().view(torch.uint8)
+        received = torch.empty_like(sent)
+        dist.all_to_all_single(received, sent)
+        return received.view(part.dtype).view(world, part.shape[0] // world, -1)
+
     totals = []
     for part in (scores, counts):
-        # slice j of `part` goes to rank j; what arrives is every rank's partial of MY slice
-        received = torch.empty_like(part)
-        dist.all_to_all_single(received, part.contiguous())
-        received = received.view(world, per, -1)
+        received = exchange(part)
         total = received[0].clone()
         for g in range(1, world):  # fixed order: the float32 sums do not depend on the transport
             total += received[g]
         totals.append(total)
-    mine = finish(begin, end, totals[0][:end - begin], totals[1][:end - begin])
+    my_slot = my_avg = None
+    if amb_per_owner:
+        my_avg = combine_amb(exchange(amb_order), exchange(amb_avg))
+        my_slot = amb_slot[begin:end].copy()
+        my_slot[my_slot >= 0] -= rank * amb_per_owner
+    mine = finish(begin, end, totals[0][:end - begin], totals[1][:end - begin], my_slot, my_avg)
     if gather_to is None:
         return mine
     parts = [None] * world if rank == gather_to else None
@@ -141,19 +200,31 @@ def kmer_sharded_gpu_fns(placer, seqs: np.ndarray, seq_offsets: np.ndarray, devi
     import torch
     from . import capi
     n = len(seq_offsets) - 1
+    seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
     d_seqs = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.uint8)).to(device)
-    d_offs = torch.from_numpy(np.ascontiguousarray(seq_offsets, dtype=np.uint64).view(np.int64)).to(device)
+    d_offs = torch.from_numpy(seq_offsets.view(np.int64)).to(device)
     stream = torch.cuda.current_stream(device).cuda_stream
     N, keep = placer.num_branches, placer.keep_at_most
+    # the count width the batch needs: the device entry points do not choose it themselves
+    placer.choose_counts(int(np.diff(seq_offsets.astype(np.int64)).max()) if n else 0)
 
-    def accumulate(n_rows_padded):
+    def accumulate(n_rows_padded, amb_slot, amb_rows):
         scores = torch.zeros((n_rows_padded, N), dtype=torch.float32, device=device)
-        counts = torch.zeros((n_rows_padded, N), dtype=torch.int32, device=device)
-        placer.accumulate_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, scores.data_ptr(), counts.data_ptr(), stream)
+        counts = torch.zeros((n_rows_padded, N), dtype=torch.int16, device=device)
+        d_slot = order = avg = None
+        if amb_rows:
+            d_slot = torch.from_numpy(np.ascontiguousarray(amb_slot, dtype=np.int32)).to(device)
+            order = torch.full((amb_rows, N), -1, dtype=torch.int32, device=device)  # AMB_NONE
+            avg = torch.zeros((amb_rows, N), dtype=torch.float32, device=device)
+        placer.accumulate_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, scores.data_ptr(), counts.data_ptr(), stream,
+                                 d_amb_slot=d_slot.data_ptr() if amb_rows else 0,
+                                 d_amb_order=order.data_ptr() if amb_rows else 0,
+                                 d_amb_avg=avg.data_ptr() if amb_rows else 0)
         torch.cuda.synchronize(device)
-        return (scores.cpu(), counts.cpu()) if host_staging else (scores, counts)
+        out = (scores, counts, order, avg)
+        return tuple(None if x is None else x.cpu() for x in out) if host_staging else out
 
-    def finish(begin, end, scores, counts):
+    def finish(begin, end, scores, counts, amb_slot, amb_avg):
         m = end - begin
         rows = np.zeros((m, keep), dtype=capi.PLACEMENT)
         n_rows = np.zeros(m, dtype=np.uint32)
@@ -161,12 +232,18 @@ def kmer_sharded_gpu_fns(placer, seqs: np.ndarray, seq_offsets: np.ndarray, devi
         if m == 0:
             return rows, n_rows, kmer_counts
         scores, counts = scores.to(device).contiguous(), counts.to(device).contiguous()
+        d_slot = d_avg = None
+        if amb_avg is not None and amb_slot is not None:
+            d_slot = torch.from_numpy(np.ascontiguousarray(amb_slot, dtype=np.int32)).to(device)
+            d_avg = amb_avg.to(device).contiguous()
         d_rows = torch.zeros(m * keep * 2, dtype=torch.float64, device=device)   # 16 B per row
         d_n_rows = torch.zeros(m, dtype=torch.int32, device=device)
         d_kc = torch.zeros(m * keep, dtype=torch.int32, device=device)
         # lengths come from the offsets of the owned reads (absolute offsets are fine: only differences are used)
         placer.finish_device(d_offs.data_ptr() + 8 * begin, m, scores.data_ptr(), counts.data_ptr(),
-                             d_rows.data_ptr(), d_n_rows.data_ptr(), d_kc.data_ptr(), stream)
+                             d_rows.data_ptr(), d_n_rows.data_ptr(), d_kc.data_ptr(), stream,
+                             d_amb_slot=d_slot.data_ptr() if d_slot is not None else 0,
+                             d_amb_avg=d_avg.data_ptr() if d_avg is not None else 0)
         torch.cuda.synchronize(device)
         rows[:] = d_rows.cpu().numpy().view(capi.PLACEMENT).reshape(m, keep)
         n_rows[:] = d_n_rows.cpu().numpy().view(np.uint32)

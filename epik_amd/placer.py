@@ -66,6 +66,64 @@ def pendant_lengths(branch_length: np.ndarray, subtree_num_nodes: np.ndarray,
     return distal, mean + distal                    # :123
 
 
+def make_desc(offsets, values, *, states: str, kmer_size: int, num_branches: int, threshold, log_threshold=None,
+              keep_at_most: int = 7, keep_factor: float = 0.01, device: int = 0, char_class=None):
+    """`epik_amd_placer_desc` over host arrays (uint32 / uint64 offsets are handed over as they are, no
+    copy).  Returns (desc, the arrays it points into -- keep them alive as long as the descriptor)."""
+    sigma = alphabet.alphabet_size(states)
+    if log_threshold is None:
+        log_threshold = alphabet.log_threshold(np.float32(threshold))
+    offsets = np.asarray(offsets)
+    num_entries = int(offsets[-1])
+    if offsets.dtype == np.uint64 and offsets.flags.c_contiguous:
+        off, bits = offsets, 64
+    elif num_entries <= 0xFFFFFFFF:
+        off, bits = np.ascontiguousarray(offsets, dtype=np.uint32), 32
+    else:
+        off, bits = np.ascontiguousarray(offsets, dtype=np.uint64), 64
+    vals = np.ascontiguousarray(values)
+    if vals.dtype.itemsize != 8:
+        raise ValueError("values must be 8-byte {uint32 branch, float32 score} records")
+    cls = np.ascontiguousarray(
+        alphabet.char_class_table(states) if char_class is None else char_class, dtype=np.uint32)
+    desc = capi.PlacerDesc(
+        abi_version=capi.ABI_VERSION, kmer_size=int(kmer_size), alphabet_size=sigma,
+        num_branches=int(num_branches), keep_at_most=int(keep_at_most), offset_bits=bits,
+        keep_factor=float(keep_factor), threshold=float(threshold),
+        log_threshold=float(log_threshold), num_keys=int(off.shape[0] - 1),
+        num_entries=num_entries, offsets=off.ctypes.data, values=vals.ctypes.data,
+        char_class=cls.ctypes.data, device=int(device), reserved=0)
+    return desc, (off, vals, cls)
+
+
+def plan(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 288 << 30, **kw) -> capi.Plan:
+    """`epik_amd_placer_plan`: kernel, layout and device-image sizes create() would choose for a
+    synthetic / loaded database `db` -- no device needed."""
+    desc, keep = make_desc(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
+                           num_branches=db.num_branches, threshold=db.threshold, log_threshold=db.log_threshold, **kw)
+    out = capi.Plan()
+    capi.check(capi.load().epik_amd_placer_plan(ctypes.byref(desc), shard_index, shard_count, int(free_bytes),
+                                                ctypes.byref(out)))
+    del keep
+    return out
+
+
+def build_image(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 288 << 30, discard=False, **kw):
+    """`epik_amd_placer_build_image`: the device image as three uint8 arrays (table, filter, postings);
+    with `discard` the image is produced and dropped (returns the plan only).  Host only."""
+    desc, keep = make_desc(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
+                           num_branches=db.num_branches, threshold=db.threshold, log_threshold=db.log_threshold, **kw)
+    lib = capi.load()
+    p = capi.Plan()
+    capi.check(lib.epik_amd_placer_plan(ctypes.byref(desc), shard_index, shard_count, int(free_bytes), ctypes.byref(p)))
+    parts = [None, None, None] if discard else [np.zeros(int(n), dtype=np.uint8)
+                                                for n in (p.table_bytes, p.filter_bytes, p.posting_bytes)]
+    ptr = [None if a is None or a.size == 0 else a.ctypes.data for a in parts]
+    capi.check(lib.epik_amd_placer_build_image(ctypes.byref(desc), shard_index, shard_count, int(free_bytes), *ptr))
+    del keep
+    return (p, *parts)
+
+
 class Placer:
     """MI355X placer.  `offsets`/`values` are the CSR database (host arrays),
     `branch_length`/`subtree_*` the per-post-order-id tree data (may be None when
@@ -84,34 +142,17 @@ class Placer:
         self.keep_at_most = int(keep_at_most)
         self.keep_factor = float(keep_factor)
         self.device = int(device)
-        if log_threshold is None:
-            log_threshold = alphabet.log_threshold(np.float32(threshold))
-        offsets = np.asarray(offsets)
-        num_entries = int(offsets[-1])
-        if num_entries <= 0xFFFFFFFF:
-            off = np.ascontiguousarray(offsets, dtype=np.uint32)
-            bits = 32
-        else:
-            off = np.ascontiguousarray(offsets, dtype=np.uint64)
-            bits = 64
-        vals = np.ascontiguousarray(values)
-        if vals.dtype.itemsize != 8:
-            raise ValueError("values must be 8-byte {uint32 branch, float32 score} records")
-        cls = np.ascontiguousarray(
-            alphabet.char_class_table(states) if char_class is None else char_class, dtype=np.uint32)
-        desc = capi.PlacerDesc(
-            abi_version=capi.ABI_VERSION, kmer_size=self.kmer_size, alphabet_size=sigma,
-            num_branches=self.num_branches, keep_at_most=self.keep_at_most, offset_bits=bits,
-            keep_factor=self.keep_factor, threshold=float(threshold),
-            log_threshold=float(log_threshold), num_keys=int(off.shape[0] - 1),
-            num_entries=num_entries, offsets=off.ctypes.data, values=vals.ctypes.data,
-            char_class=cls.ctypes.data, device=self.device, reserved=0)
+        desc, keepalive = make_desc(
+            offsets, values, states=states, kmer_size=kmer_size, num_branches=num_branches, threshold=threshold,
+            log_threshold=log_threshold, keep_at_most=keep_at_most, keep_factor=keep_factor, device=device,
+            char_class=char_class)
         handle = ctypes.c_void_p()
         # shard_count > 1: this placer keeps the posting lists of the codes with
         # code % shard_count == shard_index (k-mer-space shard, `epik_amd_placer_create_sharded`)
         self.shard_index, self.shard_count = int(shard_index), int(shard_count)
         capi.check(lib.epik_amd_placer_create_sharded(ctypes.byref(desc), self.shard_index, self.shard_count,
                                                       ctypes.byref(handle)))
+        del keepalive  # create() has streamed the database to the device and keeps no host copy
         self._lib = lib
         self._handle = handle
         if branch_length is not None:
@@ -175,19 +216,22 @@ class Placer:
             stream or None))
 
     def accumulate_device(self, d_seqs: int, d_seq_offsets: int, n: int, d_scores: int, d_counts: int,
-                          stream: int = 0) -> None:
-        """First half of a k-mer-space-sharded placement: raw float32 score sums and k-mer counts of
-        this shard's lists, [n][num_branches] each (`epik_amd_placer_accumulate_device`)."""
+                          stream: int = 0, d_amb_slot: int = 0, d_amb_order: int = 0, d_amb_avg: int = 0) -> None:
+        """First half of a k-mer-space-sharded placement: raw float32 score sums and uint16 k-mer counts
+        of this shard's lists, [n][num_branches] each, and -- for the reads with a slot in d_amb_slot --
+        the records of their ambiguous k-mers (`epik_amd_placer_accumulate_device`)."""
         capi.check(self._lib.epik_amd_placer_accumulate_device(
-            self._handle, d_seqs, d_seq_offsets, int(n), d_scores, d_counts, stream or None))
+            self._handle, d_seqs, d_seq_offsets, int(n), d_scores, d_counts, d_amb_slot or None,
+            d_amb_order or None, d_amb_avg or None, stream or None))
 
     def finish_device(self, d_seq_offsets: int, n: int, d_scores: int, d_counts: int, d_rows: int,
-                      d_n_rows: int, d_kmer_counts: int = 0, stream: int = 0) -> None:
+                      d_n_rows: int, d_kmer_counts: int = 0, stream: int = 0, d_amb_slot: int = 0,
+                      d_amb_avg: int = 0) -> None:
         """Second half: correction, top-k and like-weight-ratio on the sums added over the shards
         (`epik_amd_placer_finish_device`)."""
         capi.check(self._lib.epik_amd_placer_finish_device(
-            self._handle, d_seq_offsets, int(n), d_scores, d_counts, d_rows, d_n_rows,
-            d_kmer_counts or None, stream or None))
+            self._handle, d_seq_offsets, int(n), d_scores, d_counts, d_amb_slot or None, d_amb_avg or None,
+            d_rows, d_n_rows, d_kmer_counts or None, stream or None))
 
     def choose_counts(self, longest_read: int) -> None:
         """Width of the per-branch counts for the device entry points, chosen as `place_packed`

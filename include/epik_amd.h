@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EPIK_AMD_ABI_VERSION 1
+#define EPIK_AMD_ABI_VERSION 2
 
 enum epik_amd_status {
     EPIK_AMD_OK = 0,
@@ -100,6 +100,35 @@ const char *epik_amd_last_error(void);
  * the device's HBM once and precomputes what the kernel needs. */
 int epik_amd_placer_create(const epik_amd_placer_desc *desc, epik_amd_placer **out);
 
+/*
+ * What create() would decide for this database on a device with `free_bytes` of free memory, and how
+ * large the device image is -- without a device (capacity planning against 288 GB; no reference
+ * counterpart: the reference keeps its hash map in host RAM, main.cpp:277).  `kernel` 0: one wavefront
+ * places a read (trees whose score vector leaves enough waves on a CU); 1: a workgroup of `team_waves`
+ * waves places a read, the branch range split into team_waves * team_passes slices of `slice_rows`
+ * branches (large trees; place.cpp:92-96 bounds the tree by nothing, and neither does this).
+ * The environment overrides of create() (EPIK_AMD_LAYOUT, EPIK_AMD_KERNEL) apply here too.
+ */
+typedef struct {
+    uint32_t kernel;         /* 0 = one wavefront per read, 1 = one workgroup per read */
+    uint32_t layout;         /* 0/1 compact CSR (32/64-bit offsets), 2 packed, 3 paired, 4 filtered, 5 sliced */
+    uint32_t team_waves;
+    uint32_t team_passes;
+    uint32_t slice_rows;
+    uint32_t resident_waves[3]; /* one-wavefront kernel: waves per CU with 8/16/32-bit counts (0: does not fit) */
+    uint64_t table_bytes;
+    uint64_t filter_bytes;
+    uint64_t posting_bytes;
+    uint64_t kept_entries;   /* postings this placer keeps (its shard) */
+} epik_amd_plan;
+int epik_amd_placer_plan(const epik_amd_placer_desc *desc, uint32_t shard_index, uint32_t shard_count,
+                         uint64_t free_bytes, epik_amd_plan *plan);
+/* The image create() uploads for that plan, written front to back into host buffers of
+ * plan->table_bytes / filter_bytes / posting_bytes (NULL = that part is produced and dropped).
+ * Host only; create() streams the same bytes to the device without holding them. */
+int epik_amd_placer_build_image(const epik_amd_placer_desc *desc, uint32_t shard_index, uint32_t shard_count,
+                                uint64_t free_bytes, void *table, void *filter, void *postings);
+
 /* Replaces ~placer (place.h:100). */
 void epik_amd_placer_destroy(epik_amd_placer *p);
 
@@ -142,8 +171,10 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
  * looks at the batch and chooses by itself; for the device-pointer entry points the caller chooses
  * here: enabled = 0 back to the default (16 bits, and place() chooses again), 1 = 32 bits, 2 = 8 bits
  * (EPIK_AMD_ERR_UNSUPPORTED for trees too large for that kernel).  A read with more k-mers than the
- * counts hold gets n_rows == 0, like a read shorter than k.
+ * counts of a device-pointer launch hold is not placed and says so: n_rows == EPIK_AMD_ROWS_COUNTS_TOO_NARROW
+ * (a read shorter than k has n_rows == 0).
  */
+#define EPIK_AMD_ROWS_COUNTS_TOO_NARROW 0xffffffffu
 int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled);
 /* The same choice epik_amd_placer_place() makes, for the device-pointer entry points: the counts
  * that fit a batch whose longest read has `longest_read` characters. */
@@ -153,33 +184,47 @@ int epik_amd_placer_choose_counts(epik_amd_placer *p, uint64_t longest_read);
  * Database larger than one GPU's memory: k-mer-space shard (BASELINE configs[4]).
  * No reference counterpart -- the reference keeps one database in host RAM (main.cpp:277).
  *
- * epik_amd_placer_create_sharded() is create() keeping only the posting lists of the k-mer codes
- * with code % shard_count == shard_index (the descriptor still describes the whole database;
- * create() == create_sharded(desc, 0, 1, out)).  Every shard then sees ALL reads of a batch:
+ * Shard g of G holds the posting lists of the k-mer codes with code % G == g.  Either hand create()
+ * a descriptor that holds only those lists (every other code an empty list: no process then ever
+ * holds the whole database -- create() streams what it is given to the device and keeps no copy), or
+ * let epik_amd_placer_create_sharded() pick them out of a whole database
+ * (create() == create_sharded(desc, 0, 1, out)).  Every shard then sees ALL reads of a batch:
  *
- *   accumulate_device : per read, the raw float32 score sums and the k-mer counts of this
- *                       shard's lists, d_scores / d_counts = [n][num_branches] (place.cpp:349-371
- *                       without 418-422);
- *   (caller)          : adds d_scores and d_counts over the shards -- a reduce-scatter over the
- *                       read dimension with RCCL, each GPU keeping the totals of its own reads;
+ *   accumulate_device : per read, the raw float32 score sums and the k-mer counts of this shard's
+ *                       lists, d_scores float32 / d_counts uint16 = [n][num_branches]
+ *                       (place.cpp:349-371 without 418-422); reads of up to 65535 k-mers;
+ *   (caller)          : adds d_scores and d_counts over the shards -- one all-to-all + a sum in rank
+ *                       order, each GPU keeping the totals of its own reads (epik_amd/dist.py);
  *   finish_device     : correction, top-k, like-weight-ratio and filter on the totals
  *                       (place.cpp:418-422, 134-199, 241-267); rows as epik_amd_placer_place_device.
  *
+ * Ambiguous k-mers (place.cpp:373-415): only the first ambiguous key that reaches a branch scores
+ * it, first over the WHOLE database (:385-388).  A read that may hold an ambiguous character gets a
+ * slot: d_amb_slot[i] >= 0 (int32, -1 = none) is its row in d_amb_order (uint32) and d_amb_avg
+ * (float32), both [slots][num_branches].  accumulate fills that row, per branch, with the order
+ * (k-mer position * alphabet_size + state) of the first ambiguous key of THIS shard that reached the
+ * branch (0xffffffff: none) and its average probability (:400-402); the caller keeps, per branch, the
+ * average of the smallest order over the shards (0 where there is none); finish adds it after the
+ * exact scores and counts one k-mer, as the one-pass loop does (:409-410).  With d_amb_slot == NULL a
+ * shard scores its ambiguous k-mers by itself -- the one-pass result with one shard only.
+ *
  * With one shard the two calls give exactly the rows of place_device.  With several, a branch's
  * float32 adds happen in a different order (per shard, then over shards): scores agree to float32
- * rounding, like-weight-ratios within the 1e-5 bar, and a read's ambiguous k-mers follow the
- * first-key-scores rule (place.cpp:385-388) inside each shard only.
+ * rounding, like-weight-ratios within the 1e-5 bar.
  */
 int epik_amd_placer_create_sharded(const epik_amd_placer_desc *desc, uint32_t shard_index,
                                    uint32_t shard_count, epik_amd_placer **out);
 int epik_amd_placer_accumulate_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
-                                      uint64_t n, void *d_scores, void *d_counts, void *stream);
+                                      uint64_t n, void *d_scores, void *d_counts, const void *d_amb_slot,
+                                      void *d_amb_order, void *d_amb_avg, void *stream);
 int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets, uint64_t n,
-                                  const void *d_scores, const void *d_counts, void *d_rows, void *d_n_rows,
-                                  void *d_kmer_counts, void *stream);
+                                  const void *d_scores, const void *d_counts, const void *d_amb_slot,
+                                  const void *d_amb_avg, void *d_rows, void *d_n_rows, void *d_kmer_counts,
+                                  void *stream);
 
-/* Launch geometry actually used (for reports): waves per workgroup, workgroups
- * of the last launch, dynamic LDS bytes per workgroup. */
+/* Launch geometry actually used (for reports): waves per workgroup (one read per wave with the
+ * one-wavefront kernel, one read per workgroup with the team kernel), workgroups of the last launch,
+ * dynamic LDS bytes per workgroup. */
 int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,
                                 uint32_t *blocks, uint32_t *lds_bytes);
 

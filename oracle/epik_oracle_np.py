@@ -80,6 +80,18 @@ class RefShapedPlacer:
                     keys.append(encode(ds))
                 yield p, keys
 
+    def to_kmers_positions(self, seq: bytes):
+        """`to_kmers` with the resolved state beside every key of an ambiguous window:
+        (position, [key]) or (position, [(state, key), ...])."""
+        k, sigma = self.k, self.sigma
+        for p, keys in self.to_kmers(seq):
+            if len(keys) == 1:
+                yield p, keys
+                continue
+            j = next(j for j in range(k) if bin(int(self.char_class[seq[p + j]])).count("1") > 1)
+            weight = sigma ** (k - 1 - j)
+            yield p, [((key // weight) % sigma, key) for key in keys]
+
     # --- query_kmers (:278-316) ---------------------------------------------
     def query_kmers(self, seq: bytes):
         exact, ambiguous = [], []

@@ -28,6 +28,7 @@ def amino_k7(gpu_available):
 def test_amino_k7_matches_the_oracle(amino_k7, oracle_lib, layout, monkeypatch):
     from epik_amd.placer import Placer
     db, data, offs = amino_k7
+    monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
     monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
     ref = oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0)
     assert (ref[2][:, 0] > 0).mean() > 0.9, "the reads must find their planted k-mers"
@@ -45,13 +46,17 @@ def large_tree(gpu_available):
 
 
 @pytest.mark.parametrize("counts", ["auto", "0", "1", "2"])
-@pytest.mark.parametrize("layout", ["paired", "compact"])
+@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team8"])
 def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     """150 bp reads (141 k-mers: the 8-bit counts apply), with ambiguous and invalid characters in a
     third of them; `auto` lets place() choose, 0 / 1 / 2 force 16- / 32- / 8-bit counts."""
     from epik_amd.placer import Placer
     _, db = large_tree
-    monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
+    if layout.startswith("team"):
+        monkeypatch.setenv("EPIK_AMD_KERNEL", layout)
+    elif layout != "default":  # default: what create() chooses for this tree (the team kernel)
+        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+        monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
     if counts != "auto":
         monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", counts)
     rng = np.random.default_rng(48)
@@ -64,11 +69,13 @@ def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     assert_rows_match(*got, *ref)
 
 
-def test_n9999_long_reads_leave_the_8_bit_counts(large_tree, oracle_lib):
+@pytest.mark.parametrize("kernel", ["wave", "team4", "team8"])
+def test_n9999_long_reads_leave_the_8_bit_counts(large_tree, oracle_lib, kernel, monkeypatch):
     """One read of more than 255 k-mers in the batch: place() must not pick the 8-bit counts; and
     reads long enough for several passes over the tiles."""
     from epik_amd.placer import Placer
     _, db = large_tree
+    monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
     rng = np.random.default_rng(49)
     reads = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(8, 150, size=400)]
     reads += ["".join(rng.choice(list("ACGTN"), size=int(n))) for n in (263, 700, 3000, 40000)]

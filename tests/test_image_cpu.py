@@ -1,0 +1,183 @@
+"""The host-side image builder (epik_amd/csrc/db_image.cpp) without a device: every layout byte for
+byte against a plain numpy / Python restatement of its description in place_kernel.hip /
+team_kernel.hip, the plan create() would make, and the memory the streaming build needs."""
+import os
+import threading
+import time
+
+import numpy as np
+import psutil
+import pytest
+
+from epik_amd import placer as eplacer, synth
+
+LINE = 128
+
+
+def _lists(db):
+    offs = db.offsets.astype(np.int64)
+    return [(int(offs[k]), int(offs[k + 1])) for k in range(db.num_keys)]
+
+
+def _chunks(values, b, e, top):
+    """f32 score[cnt] then u16 cell[cnt] per chunk of <= 64 postings, cell = top - branch."""
+    out = bytearray()
+    for c0 in range(b, e, 64):
+        part = values[c0:min(e, c0 + 64)]
+        out += part["score"].astype("<f4").tobytes()
+        out += (top - part["branch"].astype(np.int64)).astype("<u2").tobytes()
+    return bytes(out)
+
+
+def _pad(b, n):
+    return b + bytes(-len(b) % n)
+
+
+def _reference_packed(db, n_pad):
+    top = n_pad - 1
+    post, lens, lines = bytearray(), [], []
+    for b, e in _lists(db):
+        lens.append(e - b)
+        lines.append(len(post) // LINE)
+        post += _pad(_chunks(db.values, b, e, top), LINE)
+    post += bytes(512)
+    return np.array(lens, np.uint32), np.array(lines, np.uint32), bytes(post)
+
+
+@pytest.fixture(scope="module")
+def db():
+    tree = synth.make_tree(60, seed=7)                       # N = 119
+    return synth.make_db(tree.num_nodes, kmer_size=5, seed=8, p_present=0.5, lognormal=(2.5, 1.5))
+
+
+@pytest.fixture(scope="module")
+def amino_db():
+    tree = synth.make_tree(20, seed=9)
+    return synth.make_db(tree.num_nodes, states="amino", kmer_size=3, seed=10, p_present=0.1, lognormal=(1.0, 1.0))
+
+
+def test_packed_and_paired_tables(db, monkeypatch):
+    n_pad = (db.num_branches + 1 + 63) // 64 * 64
+    lens, lines, post = _reference_packed(db, n_pad)
+    monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+    monkeypatch.setenv("EPIK_AMD_LAYOUT", "packed")
+    plan, table, filt, postings = eplacer.build_image(db)
+    assert plan.kernel == 0 and plan.layout == 2 and plan.filter_bytes == 0
+    assert postings.tobytes() == post
+    assert table[:-8].view(np.uint32).reshape(-1, 2).tolist() == np.stack([lens, lines], 1).tolist()
+    # paired: block X = entries of a.X (slots 0-3) and X.b (slots 4-7), every code twice
+    monkeypatch.setenv("EPIK_AMD_LAYOUT", "paired")
+    plan, table, filt, postings = eplacer.build_image(db)
+    assert plan.layout == 3 and postings.tobytes() == post
+    blocks = table[:-8].view(np.uint32).reshape(-1, 8, 2)
+    q = db.num_keys // 4
+    for x in range(q):
+        for a in range(4):
+            assert blocks[x, a].tolist() == [lens[a * q + x], lines[a * q + x]]
+            assert blocks[x, 4 + a].tolist() == [lens[x * 4 + a], lines[x * 4 + a]]
+
+
+def test_filtered_layout_and_shard(amino_db, monkeypatch):
+    db = amino_db
+    monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+    monkeypatch.setenv("EPIK_AMD_LAYOUT", "filtered")
+    sigma, blocks = 20, db.num_keys // 20
+    for shard_index, shard_count in [(0, 1), (1, 3)]:
+        plan, table, filt, postings = eplacer.build_image(db, shard_index=shard_index, shard_count=shard_count)
+        assert plan.layout == 4
+        lens = np.diff(db.offsets.astype(np.int64))
+        lens[np.arange(db.num_keys) % shard_count != shard_index] = 0
+        assert plan.kept_entries == int(lens.sum())
+        assert table[:-8].view(np.uint32).reshape(-1, 2)[:, 0].tolist() == lens.tolist()
+        words = filt.view(np.uint64)
+        for x in range(blocks):
+            want = 0
+            for a in range(sigma):
+                want |= int(lens[a * blocks + x] != 0) << a
+                want |= int(lens[x * sigma + a] != 0) << (sigma + a)
+            assert int(words[x]) == want
+
+
+def test_compact_layout(db, monkeypatch):
+    monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+    monkeypatch.setenv("EPIK_AMD_LAYOUT", "compact")
+    n_pad = (db.num_branches + 1 + 63) // 64 * 64
+    plan, table, _, postings = eplacer.build_image(db, shard_index=1, shard_count=2)
+    lens = np.diff(db.offsets.astype(np.int64))
+    lens[np.arange(db.num_keys) % 2 != 1] = 0
+    assert table.view(np.uint64).tolist() == np.concatenate([[0], np.cumsum(lens)]).tolist()
+    rec = postings[:-512].view(np.dtype([("score", "<f4"), ("cell", "<u4")]))
+    keep = np.repeat(lens != 0, np.diff(db.offsets.astype(np.int64)))
+    assert rec["score"].tobytes() == db.values["score"][keep].tobytes()
+    assert rec["cell"].tolist() == (n_pad - 1 - db.values["branch"][keep].astype(np.int64)).tolist()
+
+
+@pytest.mark.parametrize("kernel,waves", [("team4", 4), ("team8", 8)])
+def test_team_layout(db, kernel, waves, monkeypatch):
+    """Every list as W sublists, one per slice of the branch range, in the list's order; cells local to
+    the slice; one {line, len[W]} entry per code."""
+    monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+    plan, table, _, postings = eplacer.build_image(db)
+    assert plan.kernel == 1 and plan.layout == 5 and plan.team_waves == waves and plan.team_passes == 1
+    rows = plan.slice_rows
+    assert rows * waves >= db.num_branches > rows * (waves - 1)
+    rows_pad = (rows + 1 + 63) // 64 * 64
+    entry_bytes = 16 if waves == 4 else 32
+    post, line = bytearray(), 0
+    for key, (b, e) in enumerate(_lists(db)):
+        entry = table[key * entry_bytes:(key + 1) * entry_bytes]
+        got_len = entry[4:4 + 2 * waves].view(np.uint16).tolist()
+        v = db.values[b:e]
+        region = bytearray()
+        for w in range(waves):
+            sub = v[(v["branch"] // rows) == w].copy()
+            assert got_len[w] == len(sub)
+            sub["branch"] -= w * rows
+            region += _pad(_chunks(sub, 0, len(sub), rows_pad - 1), 4)
+        if e > b:
+            assert int(entry[:4].view(np.uint32)[0]) == line
+        region = _pad(bytes(region), LINE)
+        post += region
+        line += len(region) // LINE
+    assert postings.tobytes() == bytes(post) + bytes(512)
+
+
+def test_plan_chooses_the_kernel_by_tree_size(monkeypatch):
+    monkeypatch.delenv("EPIK_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
+    small = synth.make_db(999, kmer_size=6, seed=1)
+    p = eplacer.plan(small)
+    assert p.kernel == 0 and p.layout == 3 and list(p.resident_waves) == [20, 20, 16]
+    large = synth.make_db(9999, kmer_size=6, seed=1)
+    p = eplacer.plan(large)
+    assert p.kernel == 1 and p.team_passes == 1 and p.team_waves * p.slice_rows >= 9999
+    assert list(p.resident_waves) == [3, 2, 1]    # what one wavefront per read would get
+    huge = synth.make_db(120_000, kmer_size=4, seed=1, lognormal=(6.0, 1.0))
+    p = eplacer.plan(huge)                       # beyond any single-pass geometry: several passes, no bound
+    assert p.kernel == 1 and p.team_passes > 1 and p.team_waves * p.team_passes * p.slice_rows >= 120_000
+
+
+def test_build_streams_without_a_host_copy():
+    """create() must not hold a second copy of the database on the host: the builder's own memory is
+    bounded by its staging, not by the image (here 230 MB of postings + 16 MB of table)."""
+    tree = synth.make_tree(500, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
+    proc = psutil.Process()
+    peak, stop = [0], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            peak[0] = max(peak[0], proc.memory_info().rss)
+            time.sleep(0.002)
+
+    before = proc.memory_info().rss
+    t = threading.Thread(target=sample)
+    t.start()
+    try:
+        plan = eplacer.build_image(db, discard=True)[0]
+    finally:
+        stop.set()
+        t.join()
+    assert plan.posting_bytes > 200 << 20
+    grown = peak[0] - before
+    assert grown < 32 << 20, f"the image build grew the process by {grown >> 20} MiB"

@@ -48,12 +48,16 @@ def _random_case(seed):
     return db, synth.pack_reads(reads)
 
 
-@pytest.mark.parametrize("layout", ["paired", "packed", "compact"])
+@pytest.mark.parametrize("layout", ["paired", "packed", "compact", "team4", "team8x2"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EPIK_AMD_RANDOM_SEEDS", "16"))))
 def test_random_database_and_reads(gpu_available, oracle_lib, seed, layout, monkeypatch):
     assert gpu_available
     from epik_amd.placer import Placer
-    monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
+    if layout.startswith("team"):
+        monkeypatch.setenv("EPIK_AMD_KERNEL", layout)
+    else:
+        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+        monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
     db, (data, offs) = _random_case(1000 + seed)
     keep = int(np.random.default_rng(seed).choice([1, 3, 7, 12]))
     factor = float(np.random.default_rng(seed + 7).choice([0.0, 0.01, 0.5]))
