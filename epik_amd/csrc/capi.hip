@@ -109,8 +109,27 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipSetDevice(p->device);
 #ifdef EPIK_AMD_ABLATION
     if (p->params.dbg) {  // diagnostic build: where the waves spent their cycles, by phase
-        unsigned long long t[8] = {0};
+        unsigned long long t[64] = {0};
         (void)hipDeviceSynchronize();
+        (void)hipMemcpy(t, p->params.dbg, sizeof t, hipMemcpyDeviceToHost);
+        if (p->team) {
+            const char *names[8] = {"encode+lookup", "wait-tiles", "descriptors", "wait-desc", "stream", "wait-streams",
+                                    "epilogue", "wait-epilogues(+merge)"};
+            double all = 0;
+            for (int w = 0; w < p->team_waves; ++w)
+                for (int i = 0; i < 8; ++i) all += (double)t[w * 8 + i];
+            for (int w = 0; w < p->team_waves; ++w) {
+                std::fprintf(stderr, "team wave %d:", w);
+                for (int i = 0; i < 8; ++i)
+                    std::fprintf(stderr, "  %s %.1f%%", names[i], 100.0 * t[w * 8 + i] * p->team_waves / all);
+                std::fprintf(stderr, "\n");
+            }
+            (void)hipFree(p->params.dbg);
+            p->params.dbg = nullptr;
+        }
+    }
+    if (p->params.dbg) {
+        unsigned long long t[8] = {0};
         (void)hipMemcpy(t, p->params.dbg, sizeof t, hipMemcpyDeviceToHost);
         double sum = 0;
         for (double x : t) sum += x;
@@ -319,8 +338,8 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
 #ifdef EPIK_AMD_ABLATION
     if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
     if (const char *st = std::getenv("EPIK_AMD_STAMPS"); st && st[0] == '1') {
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), 8 * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemset(pp.dbg, 0, 8 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), 64 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(pp.dbg, 0, 64 * sizeof(unsigned long long)));
     }
 #endif
     hipDeviceProp_t prop;

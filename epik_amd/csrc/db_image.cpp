@@ -62,27 +62,24 @@ struct TeamChoice {
     uint32_t passes = 0, slice_rows = 0, rows_pad = 0, resident = 0;
 };
 
-// (W, P) of the team kernel for a tree of `n` branches: most resident waves per CU with 16-bit
-// counts, then fewer passes, then fewer waves; the 32-bit-count kernel must still fit a CU.
+// (W, P) of the team kernel for a tree of `n` branches: as few passes as fit a CU's LDS (with the 32-bit
+// counts, the widest), and 4 waves rather than 8 when both do (measured at N = 9 999 and 19 999, r02:
+// a workgroup of 4 is 1.5 x faster -- fewer slices to merge, fewer idle waves in the front end).
 TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
 {
-    TeamChoice best;
-    for (int waves : {4, 8}) {
-        if (forced_waves && waves != forced_waves) continue;
-        for (uint32_t passes = forced_passes ? forced_passes : 1; passes <= 4096; ++passes) {
+    for (uint32_t passes = forced_passes ? forced_passes : 1; passes <= 4096; ++passes) {
+        for (int waves : {4, 8}) {
+            if (forced_waves && waves != forced_waves) continue;
             const uint32_t slices = (uint32_t)waves * passes;
             const uint32_t rows = (n + slices - 1) / slices;
             const uint32_t rows_pad = (rows + 1u + 63u) & ~63u;
             const uint32_t desc = team_desc_bytes(keep);
-            const size_t wide = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts32), desc, keep);
-            if (wide > kLdsPerCu) continue;
+            if (team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts32), desc, keep) > kLdsPerCu) continue;
             const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts16), desc, keep);
-            const uint32_t resident = team_resident_blocks(waves, normal) * (uint32_t)waves;
-            if (resident > best.resident) best = TeamChoice{waves, passes, rows, rows_pad, resident};
-            break;  // more passes only cost: the first number that fits is the one for this W
+            return TeamChoice{waves, passes, rows, rows_pad, team_resident_blocks(waves, normal) * (uint32_t)waves};
         }
     }
-    return best;
+    return TeamChoice{};
 }
 
 }  // namespace
@@ -168,7 +165,8 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     for (int c = 0; c < 3; ++c) plan.wave_resident[c] = wave_fits ? wave_kernel_resident_waves(plan.n_pad, c) : 0;
 
     // ---- kernel: one wavefront per read while enough of them fit a CU, else a workgroup per read ----
-    bool team = !wave_fits || plan.wave_resident[kCounts16] < 12;
+    // (measured, r02: the team kernel wins where fewer than 6 waves of the other fit a CU, N >~ 4 500)
+    bool team = !wave_fits || plan.wave_resident[kCounts16] < 6;
     int forced_waves = 0;
     uint32_t forced_passes = 0;
     if (forced_kernel && forced_kernel[0]) {

@@ -36,7 +36,9 @@ enum CountBits : int { kCounts8 = 0, kCounts16 = 1, kCounts32 = 2 };
 constexpr uint32_t kLdsPerCu = 160u * 1024u;  // bytes
 constexpr uint32_t kLdsGranule = 1280u;       // LDS is handed out in 128ths of a CU's 160 KiB (measured)
 constexpr uint32_t kWaveKernelWavesPerCu = 20u;  // place_reads_kernel: __launch_bounds__(256, 5)
-constexpr uint32_t kTeamKernelWavesPerCu = 16u;  // team_place_kernel: __launch_bounds__(W * 64, 4)
+// team_place_kernel: __launch_bounds__(256, 3) with 4 waves (no spills; LDS leaves 3 workgroups at most where
+// this kernel is chosen), (512, 4) with 8
+constexpr uint32_t team_kernel_waves_per_cu(int waves) { return waves == 4 ? 12u : 16u; }
 
 constexpr uint32_t kWaveDescBytes = (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
 // LDS bytes of one wave of the one-wavefront-per-read kernels: scores + counts + chunk descriptors
@@ -60,15 +62,18 @@ constexpr uint32_t wave_kernel_resident_waves(uint32_t n_pad, int counts)
 }
 
 // ---- team kernel ---------------------------------------------------------------------------------
-constexpr uint32_t kTeamDescCap = 64;  // chunk descriptors per slice and round
+constexpr uint32_t kTeamRing = 8;      // posting-chunk loads in flight per wave (16 measured slower: r02 notes in DESIGN.md)
+constexpr uint32_t kTeamDescCap = 56;  // chunk descriptors per slice and round (a multiple of the ring)
+constexpr uint32_t kTeamCandCap = 60;  // top-k candidates of a slice (+ 4 spare entries = the list's 64)
 // bytes of one table entry {u32 line, u16 len[W]}
 constexpr int team_entry_bytes(int waves) { return waves <= 6 ? 16 : waves <= 14 ? 32 : 64; }
 constexpr uint32_t team_slice_bytes(uint32_t rows_pad, int counts) { return (rows_pad * (4u + (1u << counts)) + 15u) & ~15u; }
-// a slice's descriptor list also holds its top-k candidates (64 + 4 entries of 8 bytes) and, with
-// one pass, its ranked rows for the merge (keep_at_most entries of 16 bytes)
+// a slice's descriptor list (one round + one trip of spare entries) also holds its top-k candidates
+// and, with one pass, its ranked rows for the merge (keep_at_most entries of 16 bytes)
 constexpr uint32_t team_desc_bytes(uint32_t keep)
 {
-    const uint32_t list = (kTeamDescCap + EPIK_AMD_RING) * 8u, rows = keep * 16u;
+    const uint32_t list = (kTeamDescCap + kTeamRing) * 8u, rows = keep * 16u;
+    static_assert((kTeamCandCap + 4u) * 8u <= (kTeamDescCap + kTeamRing) * 8u, "the candidates live in the descriptor list");
     return ((list > rows ? list : rows) + 15u) & ~15u;
 }
 // LDS bytes of a workgroup: slices, descriptor lists, tile totals + flags, partial sums, (P > 1) ranked rows
@@ -81,7 +86,7 @@ constexpr uint32_t team_resident_blocks(int waves, size_t lds_bytes)
 {
     if (lds_bytes > kLdsPerCu) return 0;
     const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
-    const uint32_t by_lds = 128u / (units ? units : 1u), by_regs = kTeamKernelWavesPerCu / (uint32_t)waves;
+    const uint32_t by_lds = 128u / (units ? units : 1u), by_regs = team_kernel_waves_per_cu(waves) / (uint32_t)waves;
     return by_lds < by_regs ? by_lds : by_regs;
 }
 

@@ -417,15 +417,47 @@ struct WaveLds {
         score[i] = __uint_as_float(score_bits);
         count[i] = (CountT)c;
     }
+    // Four consecutive rows from i0 (a multiple of 4) at once: one 16-byte LDS access for the scores,
+    // one of 4 / 8 / 16 bytes for the counts.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef CountT v4c __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f f32x4_t;
+    typedef __attribute__((address_space(3))) v4c countx4_t;
+    __device__ __forceinline__ void load4(uint32_t i0, float (&s)[4], uint32_t (&c)[4]) const
+    {
+        const v4f sv = *reinterpret_cast<f32x4_t *>(score + i0);
+        const v4c cv = *reinterpret_cast<countx4_t *>(count + i0);
+        s[0] = sv.x, s[1] = sv.y, s[2] = sv.z, s[3] = sv.w;
+        c[0] = (uint32_t)cv.x, c[1] = (uint32_t)cv.y, c[2] = (uint32_t)cv.z, c[3] = (uint32_t)cv.w;
+    }
+    __device__ __forceinline__ void load_scores4(uint32_t i0, float (&s)[4]) const
+    {
+        const v4f sv = *reinterpret_cast<f32x4_t *>(score + i0);
+        s[0] = sv.x, s[1] = sv.y, s[2] = sv.z, s[3] = sv.w;
+    }
+    __device__ __forceinline__ void store_scores4(uint32_t i0, const float (&s)[4]) const
+    {
+        *reinterpret_cast<f32x4_t *>(score + i0) = v4f{s[0], s[1], s[2], s[3]};
+    }
+    // place.cpp:335-342: all rows back to zero for the wave's next read, 16 bytes per lane and store
+    __device__ __forceinline__ void clear(uint32_t n_pad) const
+    {
+        typedef __attribute__((address_space(3))) v4u u32x4_t;
+        const uint32_t lane = __lane_id();
+        auto *s16 = reinterpret_cast<u32x4_t *>(score);
+        for (uint32_t i = lane; i < n_pad / 4u; i += 64u) s16[i] = v4u{0u, 0u, 0u, 0u};
+        auto *c16 = reinterpret_cast<u32x4_t *>(count);  // n_pad * sizeof(CountT) is a multiple of 64 bytes
+        for (uint32_t i = lane; i < n_pad * (uint32_t)sizeof(CountT) / 16u; i += 64u) c16[i] = v4u{0u, 0u, 0u, 0u};
+    }
 };
 
 // ---------------------------------------------------------------------------------
-// The stream: n_padded (a multiple of kRing) chunk descriptors, in read order, go through a
-// ring of kRing chunk loads in flight and are added into the wave's LDS vectors
+// The stream: n_padded (a multiple of kDepth) chunk descriptors, in read order, go through a
+// ring of kDepth chunk loads in flight and are added into the wave's LDS vectors
 // (place.cpp:349-371).  score_top / count_top: LDS byte addresses of the dummy row (cell 0)
 // in the two vectors; chunks[] has one trip of spare entries behind n_padded.
 // ---------------------------------------------------------------------------------
-template <typename Layout, typename CountT>
+template <typename Layout, typename CountT, int kDepth = kRing>
 __device__ __forceinline__ void stream_round(const PlaceParams &p, const typename WaveLds<CountT>::u64_t *chunks,
                                              uint32_t n_padded,
                                              uint32_t score_top, uint32_t count_top)
@@ -434,17 +466,17 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
     typedef __attribute__((address_space(3))) CountT lds_count;
     const int lane = lane_id();
     (void)p;
-    // (3) stream the chunks through a ring of kRing in-flight loads.  The loads are
+    // (3) stream the chunks through a ring of kDepth in-flight loads.  The loads are
     // issued from inline asm (Layout::issue): hipcc must not count them, or it would
     // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
-    // for slot i -- exactly kLoads*(kRing-1) younger ring loads exist at that
+    // for slot i -- exactly kLoads*(kDepth-1) younger ring loads exist at that
     // point and loads retire in issue order --, consumes the slot's two registers
     // inside asm statements only, and refills the slot with the next chunk.
     // (Letting hipcc read a slot register itself, even behind a "+v" wait, is not
     // safe: it is free to copy it into another register AHEAD of the wait.)
-    uint32_t ring_c[kRing], ring_s[kRing];
+    uint32_t ring_c[kDepth], ring_s[kDepth];
 #pragma unroll
-    for (int i = 0; i < kRing; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
+    for (int i = 0; i < kDepth; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
     // One stage: (1) asm: wait for the slot, turn its cell into the two LDS addresses;
     // (2) hipcc: both LDS reads, and meanwhile the next chunk's descriptor words out of
     // the lanes; (3) asm: the float add, reading the score straight from the slot
@@ -486,16 +518,16 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
         }
         refill();
     };
-    uint64_t d_next = chunks[lane & (kRing - 1)];  // descriptors of trip 0, lane i <-> stage i
-    for (uint32_t c0 = 0; c0 < n_padded; c0 += kRing) {
+    uint64_t d_next = chunks[lane & (kDepth - 1)];  // descriptors of trip 0, lane i <-> stage i
+    for (uint32_t c0 = 0; c0 < n_padded; c0 += kDepth) {
         uint32_t field[Layout::kFields];
         Layout::prepare(d_next, field);
-        d_next = chunks[c0 + kRing + (lane & (kRing - 1))];  // next trip (spare entries behind the end)
+        d_next = chunks[c0 + kDepth + (lane & (kDepth - 1))];  // next trip (spare entries behind the end)
 #pragma unroll
-        for (int i = 0; i < kRing; ++i) {
+        for (int i = 0; i < kDepth; ++i) {
             uint32_t f[Layout::kFields];
             stage(
-                ring_c[i], ring_s[i], std::integral_constant<int, Layout::kLoads *(kRing - 1)>{},
+                ring_c[i], ring_s[i], std::integral_constant<int, Layout::kLoads *(kDepth - 1)>{},
                 [&]() {
 #pragma unroll
                     for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
@@ -505,7 +537,7 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
     }
     // tail: nothing more to issue; retire the ring (the first stage waits for all of it)
 #pragma unroll
-    for (int i = 0; i < kRing; ++i)
+    for (int i = 0; i < kDepth; ++i)
         stage(ring_c[i], ring_s[i], std::integral_constant<int, 0>{}, []() {}, []() {});
 }
 
@@ -522,7 +554,7 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
 // range, the rest of the read's workgroup owning the other slices.
 struct WaveCtx {
     static constexpr bool kTeam = false;
-    static constexpr int kCandGroups = kTilesPerPass;  // top-k candidates: as many as chunk descriptors fit
+    static constexpr uint32_t kCandCap = kChunkCap;  // top-k candidates: as many as chunk descriptors fit
     __device__ __forceinline__ uint32_t rows_pad(const PlaceParams &p) const { return p.n_pad; }
     __device__ __forceinline__ uint32_t rows(const PlaceParams &p) const { return p.num_branches; }
     __device__ __forceinline__ uint32_t branch_base() const { return 0u; }
@@ -672,22 +704,28 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     float lane_best_f = -INFINITY;  // this lane's best score
     // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 64: cells behind N hold
     // no count (the dummy row of the out-of-range lanes was cleared by the caller), so there is no
-    // bounds test.  Four rows per lane and trip while they last (the four LDS reads go out
-    // together), one per trip for the remainder; the arithmetic is branch-free.
+    // bounds test.  Four consecutive rows per lane and trip while they last (one 16-byte LDS access),
+    // one per trip for the remainder; the arithmetic is branch-free.
     constexpr int kUnroll = 4;
     const uint32_t n_rows_pad = ctx.rows_pad(p);
     auto correct_rows = [&](auto unroll, uint32_t base) {
         constexpr int kRows = decltype(unroll)::value;
-        uint2 cv[kRows];
-        float pre[kRows], s[kRows];
-#pragma unroll
-        for (int u = 0; u < kRows; ++u) cv[u] = lds.load(base + (uint32_t)u * kWave + (uint32_t)lane);
+        // kRows == 4: the lane takes four consecutive rows (one wide LDS access); else one row per lane
+        float raw[kRows], pre[kRows], s[kRows];
+        uint32_t cnt[kRows];
+        if constexpr (kRows == 4) {
+            lds.load4(base + 4u * (uint32_t)lane, raw, cnt);
+        } else {
+            const uint2 cv = lds.load(base + (uint32_t)lane);
+            raw[0] = __uint_as_float(cv.x);
+            cnt[0] = cv.y;
+        }
         float smallest = INFINITY;
 #pragma unroll
         for (int u = 0; u < kRows; ++u) {
-            const uint32_t c = cv[u].y & ~lds.kSeen;
-            pre[u] = __fadd_rn(__uint_as_float(cv[u].x), __fmul_rn((float)(nk_u - c), log_thr));  // :420
-            s[u] = div_k(pre[u]);                                                                 // :421
+            const uint32_t c = cnt[u] & ~lds.kSeen;
+            pre[u] = __fadd_rn(raw[u], __fmul_rn((float)(nk_u - c), log_thr));  // :420
+            s[u] = div_k(pre[u]);                                               // :421
             smallest = fminf(smallest, c ? fabsf(pre[u]) : INFINITY);
         }
         if (!fast_div || __ballot(smallest < 0x1p-100f) != 0) {  // wave-uniform, practically never
@@ -696,12 +734,15 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         }
 #pragma unroll
         for (int u = 0; u < kRows; ++u) {
-            const uint32_t c = cv[u].y & ~lds.kSeen;
-            const float sc = c ? s[u] : -INFINITY;  // -inf = "not an edge"
+            const uint32_t c = cnt[u] & ~lds.kSeen;
+            s[u] = c ? s[u] : -INFINITY;  // -inf = "not an edge"
             touched += c ? 1u : 0u;
-            lane_best_f = fmaxf(lane_best_f, sc);
-            lds.score[base + (uint32_t)u * kWave + (uint32_t)lane] = sc;  // the count cell stays as it is
+            lane_best_f = fmaxf(lane_best_f, s[u]);
         }
+        if constexpr (kRows == 4)  // the count cells stay as they are
+            lds.store_scores4(base + 4u * (uint32_t)lane, s);
+        else
+            lds.score[base + (uint32_t)lane] = s[0];
     };
     {
         uint32_t base = 0;
@@ -724,8 +765,8 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
     const uint32_t keep = p.keep_at_most;
     auto *cand = reinterpret_cast<typename WaveLds<CountT>::u32x2_t *>(lds.desc);  // {ord(score), branch}
-    constexpr int kQ = Ctx::kCandGroups;  // candidates per lane
-    constexpr uint32_t kCandCap = (uint32_t)kQ * kWave;
+    constexpr uint32_t kCandCap = Ctx::kCandCap;  // top-k candidates the wave's descriptor list holds
+    constexpr int kQ = (int)((kCandCap + kWave - 1) / kWave);  // ... per lane
     constexpr float kLog2Of10 = 3.32192809488736f;
     uint32_t n_sel, n_cand;
     float best_score;
@@ -760,12 +801,14 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
         auto scan_rows = [&](auto unroll, uint32_t base) {
             constexpr int kRows = decltype(unroll)::value;
-            float row[kRows];
-#pragma unroll
-            for (int u = 0; u < kRows; ++u) row[u] = lds.score[base + (uint32_t)u * kWave + (uint32_t)lane];
+            float row[kRows];  // as in the correction sweep: four consecutive rows per lane, or one
+            if constexpr (kRows == 4)
+                lds.load_scores4(base + 4u * (uint32_t)lane, row);
+            else
+                row[0] = lds.score[base + (uint32_t)lane];
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
-                const uint32_t i = base + (uint32_t)u * kWave + (uint32_t)lane;
+                const uint32_t i = kRows == 4 ? base + 4u * (uint32_t)lane + (uint32_t)u : base + (uint32_t)lane;
                 const float sc = row[u];             // -inf where there is no edge (a sum of finite
                 const bool edge = sc != -INFINITY;   // log10 scores never is)
                 // exp2(-inf) = 0: rows without an edge add nothing
@@ -869,7 +912,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             ctx.partial->ref_score = ref_score;
             ctx.partial->sum = sum;
         }
-        for (uint32_t i = lane; i < n_rows_pad; i += kWave) lds.store(i, 0u, 0u);
+        lds.clear(n_rows_pad);
         (void)read;
         return;
     }
@@ -949,7 +992,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
 
     // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
-    for (uint32_t i = lane; i < n_rows_pad; i += kWave) lds.store(i, 0u, 0u);
+    lds.clear(n_rows_pad);
 }
 
 

@@ -78,7 +78,7 @@ struct TeamEntry {
 template <int W>
 struct TeamCtx {
     static constexpr bool kTeam = true;
-    static constexpr int kCandGroups = 1;  // top-k candidates of a slice: one per lane
+    static constexpr uint32_t kCandCap = kTeamCandCap;  // top-k candidates of a slice: at most one per lane
     uint32_t rows_pad_, rows_, base_, slice_, pass_;
     lds_u32x4 *cand;       // [keep_at_most] ranked rows of this slice for the merge
     lds_partial *partial;  // this slice's share of sum_scores
@@ -124,12 +124,30 @@ __device__ __attribute__((noinline)) void team_merge(const PlaceParams *__restri
     for (uint32_t s = 0; s < n_slices; ++s) touched += partials[s].touched;
     uint32_t n_sel;
     float best_score;
+    // Up to 64 slots (4 or 8 slices of the default 7 rows): one slot per lane, everything in registers.
+    const bool in_lanes = M <= (uint32_t)kWave;  // wave-uniform
+    v4u mine = v4u{0u, 0u, 0u, 0u};             // in_lanes: this lane's slot, .w = its rank
+    int best_lane = 0;
     if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
         n_sel = keep;
         best_score = thr_score;
-        for (uint32_t i = lane; i < M; i += kWave)
-            cand[(i / keep) * cand_stride + i % keep] =
-                i < keep ? v4u{ord_f32(thr_score), i, 0u, i} : v4u{0u, 0u, 0u, 0u};
+        if (in_lanes) {
+            if ((uint32_t)lane < keep) mine = v4u{ord_f32(thr_score), (uint32_t)lane, 0u, (uint32_t)lane};
+        } else {
+            for (uint32_t i = lane; i < M; i += kWave)
+                cand[(i / keep) * cand_stride + i % keep] =
+                    i < keep ? v4u{ord_f32(thr_score), i, 0u, i} : v4u{0u, 0u, 0u, 0u};
+        }
+    } else if (in_lanes) {
+        n_sel = keep < touched ? keep : touched;  // :137
+        if ((uint32_t)lane < M) mine = cand[((uint32_t)lane / keep) * cand_stride + (uint32_t)lane % keep];
+        const uint64_t key = mine.x ? (((uint64_t)mine.x << 32) | (uint64_t)(~mine.y)) : 0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < M; ++j) rank += readlane_u64(key, (int)j) > key ? 1u : 0u;
+        mine.w = rank;
+        const uint64_t first = __ballot(key != 0 && rank == 0);  // never empty: touched != 0
+        best_lane = __builtin_ctzll(first);
+        best_score = unord_f32(__builtin_amdgcn_readlane(mine.x, best_lane));
     } else {
         n_sel = keep < touched ? keep : touched;  // :137
         uint32_t best_ord = 0;
@@ -152,9 +170,17 @@ __device__ __attribute__((noinline)) void team_merge(const PlaceParams *__restri
         }
         best_score = unord_f32(best_ord);
     }
+    // 10^score of the rows that may be reported (:254): once per row, the lanes side by side
+    const bool my_row = in_lanes && mine.x != 0 && mine.w < n_sel;
+    double my_power = 0.0, best_power;
+    if (in_lanes) {
+        my_power = my_row ? pow10_f64((double)unord_f32(mine.x)) : 0.0;
+        best_power = __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(my_power), best_lane));
+    } else {
+        best_power = pow10_f64((double)best_score);
+    }
     // ---- sum_scores (:164-184) ------------------------------------------------------------------
     const float ref_score = fmaxf(best_score, thr_score);
-    const double best_power = pow10_f64((double)best_score);
     double score_sum;
     {
         double rel = 0.0, absolute = 0.0;
@@ -181,31 +207,45 @@ __device__ __attribute__((noinline)) void team_merge(const PlaceParams *__restri
     const double ratio_threshold = best_ratio * keep_factor;                                           // :192
     // ---- LWR (:241-264), filter_by_ratio (:188-199): which ranks stay --------------------------
     uint64_t kept_ranks = 0;
-    for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        if (i < M) {
-            const v4u c = cand[(i / keep) * cand_stride + i % keep];
-            if (c.x != 0 && c.w < n_sel) {
-                const double power = pow10_f64((double)unord_f32(c.x));
-                const double lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;  // :255-262
-                if (lwr >= ratio_threshold) kept_ranks |= 1ull << c.w;                              // :197
+    if (in_lanes) {
+        const double lwr = (my_row && score_sum != 0.0 && my_power != 0.0) ? my_power / score_sum : 0.0;  // :255-262
+        kept_ranks = wave_or_u64((my_row && lwr >= ratio_threshold) ? 1ull << mine.w : 0ull);            // :197
+        if (my_row && ((kept_ranks >> mine.w) & 1ull)) {
+            const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << mine.w) - 1ull));
+            epik_amd_placement out;
+            out.branch = mine.y;
+            out.score = unord_f32(mine.x);
+            out.lwr = lwr;
+            p.rows[read * keep + slot] = out;
+            if (p.kmer_counts) p.kmer_counts[read * keep + slot] = mine.z;
+        }
+    } else {
+        for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            if (i < M) {
+                const v4u c = cand[(i / keep) * cand_stride + i % keep];
+                if (c.x != 0 && c.w < n_sel) {
+                    const double power = pow10_f64((double)unord_f32(c.x));
+                    const double lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;  // :255-262
+                    if (lwr >= ratio_threshold) kept_ranks |= 1ull << c.w;                              // :197
+                }
             }
         }
-    }
-    kept_ranks = wave_or_u64(kept_ranks);
-    for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        if (i < M) {
-            const v4u c = cand[(i / keep) * cand_stride + i % keep];
-            if (c.x != 0 && c.w < n_sel && ((kept_ranks >> c.w) & 1ull)) {
-                const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << c.w) - 1ull));
-                const double power = pow10_f64((double)unord_f32(c.x));
-                epik_amd_placement out;
-                out.branch = c.y;
-                out.score = unord_f32(c.x);
-                out.lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;
-                p.rows[read * keep + slot] = out;
-                if (p.kmer_counts) p.kmer_counts[read * keep + slot] = c.z;
+        kept_ranks = wave_or_u64(kept_ranks);
+        for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            if (i < M) {
+                const v4u c = cand[(i / keep) * cand_stride + i % keep];
+                if (c.x != 0 && c.w < n_sel && ((kept_ranks >> c.w) & 1ull)) {
+                    const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << c.w) - 1ull));
+                    const double power = pow10_f64((double)unord_f32(c.x));
+                    epik_amd_placement out;
+                    out.branch = c.y;
+                    out.score = unord_f32(c.x);
+                    out.lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;
+                    p.rows[read * keep + slot] = out;
+                    if (p.kmer_counts) p.kmer_counts[read * keep + slot] = c.z;
+                }
             }
         }
     }
@@ -217,7 +257,7 @@ __device__ __attribute__((noinline)) void team_merge(const PlaceParams *__restri
 enum : int { kTeamPlace = kTeamModePlace, kTeamAccumulate = kTeamModeAccumulate, kTeamFinish = kTeamModeFinish };
 
 template <int W, typename CountT, int kMode>
-__global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
+__global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(TeamParams tp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef WaveLds<CountT> Lds;
@@ -258,6 +298,19 @@ __global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
     const uint32_t sigma = p.alphabet_size;
     const uint32_t stride = kWave - (k - 1);  // windows per 64-character tile
     const uint32_t cap = tp.desc_cap;
+#ifdef EPIK_AMD_ABLATION
+    // where the waves of a team spend their time: cycles per (wave, phase), EPIK_AMD_STAMPS=1
+    unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_last = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define TEAM_STAMP(k)                                                    \
+    if (p.dbg) {                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        dbg_t[k] += now_ - dbg_last;                                     \
+        dbg_last = now_;                                                 \
+    }
+#else
+#define TEAM_STAMP(k)
+#endif
 
     for (uint64_t read = blockIdx.x; read < p.n_reads; read += gridDim.x) {
         const uint64_t seq_begin = readlane_u64(p.seq_offsets[read], 0);
@@ -348,6 +401,7 @@ __global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
                             tile_total[s] = __builtin_amdgcn_readlane(incl, 63);
                         }
                     }
+                    TEAM_STAMP(0)  // encode, lookup, scans
                     {   // chunks per (tile, slice) across the workgroup
                         uint32_t mine = tile_total[0];
 #pragma unroll
@@ -355,6 +409,7 @@ __global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
                         if (lane < W) totals[wave * W + (uint32_t)lane] = mine;
                     }
                     __syncthreads();
+                    TEAM_STAMP(1)  // waiting for the other tiles
                     any_amb = any_amb || flags[parity] != 0u;  // set before the barrier; cleared two barriers later at the earliest
                     uint32_t base[W];       // chunks of the earlier tiles of this group, per slice
                     uint32_t my_total = 0;  // chunks of this wave's slice in the group
@@ -416,14 +471,18 @@ __global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
                                 }
                             }
                         }
+                        TEAM_STAMP(2)  // descriptors
                         __syncthreads();
+                        TEAM_STAMP(3)
                         if (my_total > w0) {
                             const uint32_t n_round = min(my_total - w0, cap);
-                            const uint32_t n_padded = (n_round + (uint32_t)kRing - 1u) & ~((uint32_t)kRing - 1u);
+                            const uint32_t n_padded = (n_round + kTeamRing - 1u) & ~(kTeamRing - 1u);
                             if ((uint32_t)lane < n_padded - n_round) lds.desc[n_round + lane] = null_chunk(p);
-                            stream_round<TeamChunks, CountT>(p, lds.desc, n_padded, score_top, count_top);
+                            stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_padded, score_top, count_top);
                         }
+                        TEAM_STAMP(4)  // stream
                         __syncthreads();
+                        TEAM_STAMP(5)  // waiting for the other slices' streams
                     }
                 }
                 // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ----------
@@ -449,15 +508,21 @@ __global__ __launch_bounds__(W * 64, 4) void team_place_kernel(TeamParams tp)
                 place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
             }
         }
+        TEAM_STAMP(6)  // slice epilogue
         if (kMode != kTeamAccumulate) {
             __syncthreads();  // every slice's rows and sums are in LDS
             if (wave == W - 1) team_merge(kp, merge_cand, merge_stride, partials, n_slices, read, n_kmers);
+            TEAM_STAMP(7)  // waiting for the other slices' epilogues (+ the merge, in the last wave)
             // placing, the barriers of the next read's front end keep the other waves' next epilogue
             // off the merge area until the merge is done; finishing, there is no front end
             if (kMode == kTeamFinish) __syncthreads();
         }
         if (kMode != kTeamFinish && wave == 0 && lane == 0) flags[parity] = 0u;  // read again two reads on
     }
+#ifdef EPIK_AMD_ABLATION
+    if (p.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg[wave * 8 + i], dbg_t[i]);
+#endif
 }
 
 // Algorithmic bytes of SURVEY.md 8(d) on the sliced database: a code's list is its sublists of all passes.

@@ -148,6 +148,7 @@ class SynthDB:
     values: np.ndarray    # PKDB_VALUE[num_entries]
     threshold: np.float32 = None
     log_threshold: np.float32 = None
+    total_entries: int = None     # postings of the whole database when this object holds one shard of it
 
     def __post_init__(self):
         sigma = alphabet.alphabet_size(self.states)
@@ -171,9 +172,12 @@ class SynthDB:
 
 def make_db(num_branches: int, states: str = "nucl", kmer_size: int = 10, omega: float = 1.5,
             p_present: float = 0.6, seed: int = 43, lognormal=(3.0, 1.5),
-            scattered: bool = False) -> SynthDB:
+            scattered: bool = False, shard=None) -> SynthDB:
     """Synthetic DB of SURVEY.md 8(d).  `scattered=True` replaces the contiguous
-    branch run by a sorted random subset (stress for the LDS scatter-add)."""
+    branch run by a sorted random subset (stress for the LDS scatter-add).
+    `shard=(g, G)`: only the lists of the codes with code % G == g are generated (every other code an
+    empty list) -- a rank of a k-mer-space-sharded job never holds the rest; which codes exist and how
+    long their lists are is the same draw as without `shard`, the postings are the shard's own."""
     sigma = alphabet.alphabet_size(states)
     num_keys = sigma ** kmer_size
     rng = np.random.default_rng(seed)
@@ -182,6 +186,16 @@ def make_db(num_branches: int, states: str = "nucl", kmer_size: int = 10, omega:
     n_present = int(present.sum())
     raw = np.floor(rng.lognormal(lognormal[0], lognormal[1], size=n_present))
     lengths = (1 + np.minimum(num_branches - 1, raw)).astype(np.int64)
+    total_all = int(lengths.sum())
+    if shard is not None:
+        g, count = shard
+        keys = np.nonzero(present)[0]
+        mine = keys % count == g
+        present = np.zeros(num_keys, dtype=bool)
+        present[keys[mine]] = True
+        lengths = lengths[mine]
+        n_present = int(mine.sum())
+        rng = np.random.default_rng([seed, 1000 + g])
     lens_all = np.zeros(num_keys, dtype=np.int64)
     lens_all[present] = lengths
     offsets = np.zeros(num_keys + 1, dtype=np.uint64)
@@ -208,8 +222,10 @@ def make_db(num_branches: int, states: str = "nucl", kmer_size: int = 10, omega:
     u = rng.random(total)
     prob = float(threshold) + u * (1.0 - float(threshold))
     values["score"] = np.log10(prob).astype(np.float32)
-    return SynthDB(states=states, kmer_size=kmer_size, omega=omega, num_branches=num_branches,
-                   offsets=offsets, values=values, threshold=threshold)
+    db = SynthDB(states=states, kmer_size=kmer_size, omega=omega, num_branches=num_branches,
+                 offsets=offsets, values=values, threshold=threshold)
+    db.total_entries = total_all  # of the whole database, whatever the shard
+    return db
 
 
 def make_reads(n_reads: int, length: int, states: str = "nucl", seed: int = 44):

@@ -30,7 +30,7 @@ struct orc_scratch {
     uint32_t *l_amb;      /* std::unordered_set l_amb of place.cpp:378, kept in insertion order */
     size_t n_lamb;
     /* query_kmers results (place.cpp:284-289): CSR ranges instead of optionals */
-    uint64_t *ex_start;
+    uint64_t *ex_start; /* the lists' postings (pointers) */
     uint64_t *ex_len;
     size_t ex_cap, n_ex;
     uint64_t *am_start;
@@ -71,6 +71,92 @@ void orc_scratch_destroy(orc_scratch *s)
     free(s->am_start);
     free(s->am_len);
     free(s);
+}
+
+/* ---- phylo_kmer_db::search (place.cpp:300,311): direct index, or the hash map of orc_db.hash ---- */
+typedef struct orc_node {
+    struct orc_node *next;
+    uint64_t key;
+    orc_pkdb_value *begin; /* its own allocation, like std::vector<pkdb_value> */
+    uint64_t len;
+} orc_node;
+struct orc_hash {
+    orc_node **buckets;
+    uint64_t n_buckets;
+};
+
+static int is_prime(uint64_t x)
+{
+    if (x < 2) return 0;
+    for (uint64_t d = 2; d * d <= x; ++d)
+        if (x % d == 0) return 0;
+    return 1;
+}
+
+struct orc_hash *orc_hash_create(const orc_db *db)
+{
+    uint64_t n_present = 0;
+    for (uint64_t k = 0; k < db->num_keys; ++k) n_present += db->offsets[k + 1] > db->offsets[k];
+    struct orc_hash *h = (struct orc_hash *)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->n_buckets = n_present + 1; /* load factor <= 1, a prime bucket count, key % buckets: libstdc++'s policy */
+    while (!is_prime(h->n_buckets)) ++h->n_buckets;
+    h->buckets = (orc_node **)calloc(h->n_buckets, sizeof(orc_node *));
+    if (!h->buckets) {
+        free(h);
+        return NULL;
+    }
+    for (uint64_t k = 0; k < db->num_keys; ++k) {
+        const uint64_t b = db->offsets[k], e = db->offsets[k + 1];
+        if (e == b) continue;
+        orc_node *node = (orc_node *)malloc(sizeof(*node));
+        orc_pkdb_value *v = (orc_pkdb_value *)malloc((size_t)(e - b) * sizeof(*v));
+        if (!node || !v) {
+            free(node);
+            free(v);
+            orc_hash_destroy(h);
+            return NULL;
+        }
+        memcpy(v, db->values + b, (size_t)(e - b) * sizeof(*v));
+        node->key = k;
+        node->begin = v;
+        node->len = e - b;
+        node->next = h->buckets[k % h->n_buckets];
+        h->buckets[k % h->n_buckets] = node;
+    }
+    return h;
+}
+
+void orc_hash_destroy(struct orc_hash *h)
+{
+    if (!h) return;
+    for (uint64_t i = 0; h->buckets && i < h->n_buckets; ++i) {
+        orc_node *node = h->buckets[i];
+        while (node) {
+            orc_node *next = node->next;
+            free(node->begin);
+            free(node);
+            node = next;
+        }
+    }
+    free(h->buckets);
+    free(h);
+}
+
+/* -> the list's postings and length (0: the key has none) */
+static inline uint64_t orc_search(const orc_db *db, uint64_t key, const orc_pkdb_value **list)
+{
+    if (db->hash) {
+        for (const orc_node *node = db->hash->buckets[key % db->hash->n_buckets]; node; node = node->next)
+            if (node->key == key) {
+                *list = node->begin;
+                return node->len;
+            }
+        *list = NULL;
+        return 0;
+    }
+    *list = db->values + db->offsets[key];
+    return db->offsets[key + 1] - db->offsets[key];
 }
 
 static int grow(uint64_t **a, uint64_t **b, size_t *cap, size_t need)
@@ -136,22 +222,22 @@ static int orc_query_kmers(const orc_db *db, orc_scratch *s, const char *seq, si
         uint64_t key = 0, wgt = 0;
         uint32_t mask = 0;
         const int kind = orc_kmer_window(db, seq + p, &key, &mask, &wgt);
+        const orc_pkdb_value *list;
         if (kind == 1) {
-            const uint64_t b = db->offsets[key], e = db->offsets[key + 1];
-            if (e > b) {
+            const uint64_t len = orc_search(db, key, &list);
+            if (len) {
                 if (grow(&s->ex_start, &s->ex_len, &s->ex_cap, s->n_ex + 1)) return -1;
-                s->ex_start[s->n_ex] = b;
-                s->ex_len[s->n_ex] = e - b;
+                s->ex_start[s->n_ex] = (uint64_t)(uintptr_t)list;
+                s->ex_len[s->n_ex] = len;
                 ++s->n_ex;
             }
         } else if (kind == 2) {
             for (uint32_t st = 0; st < db->alphabet_size; ++st) {
                 if (!((mask >> st) & 1u)) continue;
-                const uint64_t kk = key + (uint64_t)st * wgt;
-                const uint64_t b = db->offsets[kk], e = db->offsets[kk + 1];
+                const uint64_t len = orc_search(db, key + (uint64_t)st * wgt, &list);
                 if (grow(&s->am_start, &s->am_len, &s->am_cap, s->n_am + 1)) return -1;
-                s->am_start[s->n_am] = b;
-                s->am_len[s->n_am] = e - b;
+                s->am_start[s->n_am] = (uint64_t)(uintptr_t)list;
+                s->am_len[s->n_am] = len;
                 ++s->n_am;
             }
         }
@@ -181,7 +267,7 @@ static int orc_place_seq(const orc_db *db, orc_scratch *s, const char *seq, size
 
     /* exact k-mers (:349-371): k-mer order, then posting order, float32 adds */
     for (size_t i = 0; i < s->n_ex; ++i) {
-        const orc_pkdb_value *v = db->values + s->ex_start[i];
+        const orc_pkdb_value *v = (const orc_pkdb_value *)(uintptr_t)s->ex_start[i];
         const uint64_t n = s->ex_len[i];
         for (uint64_t j = 0; j < n; ++j) {
             const uint32_t b = v[j].branch;
@@ -195,7 +281,7 @@ static int orc_place_seq(const orc_db *db, orc_scratch *s, const char *seq, size
     for (size_t i = 0; i < s->n_am; ++i) {
         s->n_lamb = 0; /* l_amb is local to each ambiguous_result (:378) */
         if (s->am_len[i] == 0) continue; /* if (exact_result) (:381) */
-        const orc_pkdb_value *v = db->values + s->am_start[i];
+        const orc_pkdb_value *v = (const orc_pkdb_value *)(uintptr_t)s->am_start[i];
         const uint64_t n = s->am_len[i];
         for (uint64_t j = 0; j < n; ++j) {
             const uint32_t b = v[j].branch;
@@ -362,6 +448,88 @@ int orc_place_batch(const orc_db *db, const char *seqs, const uint64_t *seq_offs
         }
         orc_scratch_destroy(s);
     }
+    return failed ? -1 : 0;
+}
+
+/* group_by_sequence_content (place.cpp:73-81) of one batch: first[i] = index of the first read of the
+ * batch with read i's content.  Open addressing over FNV-1a of the bytes. */
+static int dedup_batch(const char *seqs, const uint64_t *offs, uint64_t n, uint64_t *first)
+{
+    uint64_t cap = 16;
+    while (cap < 2 * n) cap *= 2;
+    uint64_t *table = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    if (!table) return -1;
+    for (uint64_t i = 0; i < cap; ++i) table[i] = UINT64_MAX;
+    for (uint64_t i = 0; i < n; ++i) {
+        const char *s = seqs + offs[i];
+        const uint64_t len = offs[i + 1] - offs[i];
+        uint64_t h = 1469598103934665603ull;
+        for (uint64_t j = 0; j < len; ++j) h = (h ^ (unsigned char)s[j]) * 1099511628211ull;
+        uint64_t slot = h & (cap - 1);
+        for (;;) {
+            const uint64_t other = table[slot];
+            if (other == UINT64_MAX) {
+                table[slot] = i;
+                first[i] = i;
+                break;
+            }
+            if (offs[other + 1] - offs[other] == len && memcmp(seqs + offs[other], s, len) == 0) {
+                first[i] = other;
+                break;
+            }
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
+    free(table);
+    return 0;
+}
+
+int orc_place_batched(const orc_db *db, const char *seqs, const uint64_t *seq_offsets, uint64_t n,
+                      uint64_t batch_size, int num_threads, orc_row *rows, uint32_t *n_rows, uint32_t *counts)
+{
+    if (num_threads <= 0) num_threads = orc_max_threads();
+    if (batch_size == 0) batch_size = 2000; /* main.cpp:214 */
+    uint64_t *first = (uint64_t *)malloc((batch_size + 1) * sizeof(uint64_t));
+    uint64_t *unique = (uint64_t *)malloc((batch_size + 1) * sizeof(uint64_t));
+    orc_scratch **scratch = (orc_scratch **)calloc((size_t)num_threads, sizeof(orc_scratch *));
+    int failed = !first || !unique || !scratch;
+    for (int t = 0; !failed && t < num_threads; ++t) failed = (scratch[t] = orc_scratch_create(db)) == NULL;
+    const uint32_t keep = db->keep_at_most;
+    for (uint64_t b0 = 0; !failed && b0 < n; b0 += batch_size) {
+        const uint64_t m = n - b0 < batch_size ? n - b0 : batch_size;
+        if (dedup_batch(seqs, seq_offsets + b0, m, first)) {
+            failed = 1;
+            break;
+        }
+        uint64_t n_unique = 0;
+        for (uint64_t i = 0; i < m; ++i)
+            if (first[i] == i) unique[n_unique++] = i;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) num_threads(num_threads)
+#endif
+        for (int64_t u = 0; u < (int64_t)n_unique; ++u) {
+#ifdef _OPENMP
+            orc_scratch *s = scratch[omp_get_thread_num()];
+#else
+            orc_scratch *s = scratch[0];
+#endif
+            const uint64_t i = b0 + unique[u];
+            const int r = orc_place_read(db, s, seqs + seq_offsets[i], (size_t)(seq_offsets[i + 1] - seq_offsets[i]),
+                                         rows + i * keep, counts ? counts + i * keep : NULL);
+            n_rows[i] = r > 0 ? (uint32_t)r : 0;
+        }
+        for (uint64_t i = 0; i < m; ++i) { /* the headers of a duplicate share the placement (jplace "nm") */
+            if (first[i] == i) continue;
+            const uint64_t src = b0 + first[i], dst = b0 + i;
+            memcpy(rows + dst * keep, rows + src * keep, keep * sizeof(orc_row));
+            if (counts) memcpy(counts + dst * keep, counts + src * keep, keep * sizeof(uint32_t));
+            n_rows[dst] = n_rows[src];
+        }
+    }
+    for (int t = 0; scratch && t < num_threads; ++t) orc_scratch_destroy(scratch[t]);
+    free(scratch);
+    free(first);
+    free(unique);
     return failed ? -1 : 0;
 }
 

@@ -64,7 +64,16 @@ typedef struct {
     /* char_class[c]: bit i set <=> character c may be state i.
      * popcount 1 = unambiguous, >1 = ambiguous, 0 = invalid (gap/unknown). */
     const uint32_t *char_class; /* [256] */
+    /* NULL: phylo_kmer_db::search is a direct index into offsets[].  Non-NULL (orc_hash_create): a
+     * node-chained hash map key -> separately allocated vector of postings, the data structure shape
+     * of the reference's i2l::phylo_kmer_db -- same results, the reference's memory
+     * access pattern; used by the timed CPU baseline. */
+    const struct orc_hash *hash;
 } orc_db;
+
+/* The hash-map form of the database (see orc_db.hash); built from the CSR arrays. */
+struct orc_hash *orc_hash_create(const orc_db *db);
+void orc_hash_destroy(struct orc_hash *h);
 
 /* Scratch for one thread: the per-thread arrays of placer (place.h:126-137). */
 typedef struct orc_scratch orc_scratch;
@@ -85,6 +94,14 @@ int orc_place_read(const orc_db *db, orc_scratch *s, const char *seq, size_t len
 int orc_place_batch(const orc_db *db, const char *seqs, const uint64_t *seq_offsets,
                     uint64_t n, int num_threads, orc_row *rows, uint32_t *n_rows,
                     uint32_t *counts);
+
+/* placer::place (place.cpp:201-275) as the driver calls it (main.cpp:332-344): the reads in batches
+ * of batch_size (--batch-size, 2000), every batch de-duplicated by sequence content (:73-81, 207-212),
+ * its unique sequences placed in an OpenMP dynamic loop (:218-230), duplicates sharing the result.
+ * Same outputs as orc_place_batch. */
+int orc_place_batched(const orc_db *db, const char *seqs, const uint64_t *seq_offsets, uint64_t n,
+                      uint64_t batch_size, int num_threads, orc_row *rows, uint32_t *n_rows,
+                      uint32_t *counts);
 
 /* Algorithmic bytes of SURVEY.md 8(d): L + 8*n_kmers + 8*sum|list| + 16*rows. */
 uint64_t orc_algorithmic_bytes(const orc_db *db, const char *seq, size_t len,

@@ -30,6 +30,7 @@ class _OrcDb(ctypes.Structure):
         ("offsets", ctypes.c_void_p),
         ("values", ctypes.c_void_p),
         ("char_class", ctypes.c_void_p),
+        ("hash", ctypes.c_void_p),
     ]
 
 
@@ -61,6 +62,14 @@ def _load():
         lib.orc_algorithmic_bytes.argtypes = [ctypes.POINTER(_OrcDb), ctypes.c_void_p,
                                               ctypes.c_size_t, ctypes.c_uint32]
         lib.orc_max_threads.restype = ctypes.c_int
+        lib.orc_place_batched.restype = ctypes.c_int
+        lib.orc_place_batched.argtypes = [ctypes.POINTER(_OrcDb), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                          ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p]
+        lib.orc_hash_create.restype = ctypes.c_void_p
+        lib.orc_hash_create.argtypes = [ctypes.POINTER(_OrcDb)]
+        lib.orc_hash_destroy.restype = None
+        lib.orc_hash_destroy.argtypes = [ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -83,7 +92,8 @@ class Oracle:
             keep_factor=float(keep_factor), threshold=float(threshold),
             log_threshold=float(log_threshold), num_keys=int(self.offsets.shape[0] - 1),
             offsets=self.offsets.ctypes.data, values=self.values.ctypes.data,
-            char_class=self.char_class.ctypes.data)
+            char_class=self.char_class.ctypes.data, hash=None)
+        self._hash = None
 
     @classmethod
     def from_synth(cls, db, states=None, keep_at_most=7, keep_factor=0.01):
@@ -107,6 +117,40 @@ class Oracle:
                                        rows.ctypes.data, n_rows.ctypes.data, counts.ctypes.data)
         if rc != 0:
             raise RuntimeError(f"orc_place_batch failed: {rc}")
+        return rows, n_rows, counts
+
+    def use_hash_map(self, enabled: bool = True) -> None:
+        """phylo_kmer_db::search through a node-chained hash map (the reference's data structure shape)
+        instead of the direct index; same results."""
+        if enabled and not self._hash:
+            self._hash = self._lib.orc_hash_create(ctypes.byref(self._db))
+            if not self._hash:
+                raise MemoryError("orc_hash_create")
+        self._db.hash = self._hash if enabled else None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_hash", None):
+                self._db.hash = None
+                self._lib.orc_hash_destroy(self._hash)
+                self._hash = None
+        except Exception:
+            pass
+
+    def place_batched(self, seqs, seq_offsets, batch_size: int = 2000, num_threads: int = 1):
+        """`place` as the reference's driver runs it: batches of `batch_size` reads, each de-duplicated by
+        content and placed in an OpenMP dynamic loop (main.cpp:332-344, place.cpp:201-275)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = int(seq_offsets.shape[0] - 1)
+        rows = np.zeros((n, self.keep_at_most), dtype=ORC_ROW)
+        n_rows = np.zeros(n, dtype=np.uint32)
+        counts = np.zeros((n, self.keep_at_most), dtype=np.uint32)
+        rc = self._lib.orc_place_batched(ctypes.byref(self._db), seqs.ctypes.data, seq_offsets.ctypes.data, n,
+                                         int(batch_size), int(num_threads), rows.ctypes.data, n_rows.ctypes.data,
+                                         counts.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"orc_place_batched failed: {rc}")
         return rows, n_rows, counts
 
     def algorithmic_bytes(self, seqs, seq_offsets, n_rows) -> int:

@@ -5,7 +5,8 @@ Runs the bench workload through several variants IN ONE PROCESS, interleaved ove
 rounds (devices differ by several percent: never compare across runs).  A variant is a
 comma-separated list of key=value:
     lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
-    layout=compact|packed|paired, wide=0|1, ablate=<bitmask>, stamps=1   (env read at placer creation)
+    layout=compact|packed|paired, kernel=wave|team4|team8, wide=0|1|2, ablate=<bitmask>, stamps=1   (env read at placer creation)
+LEAVES=<n> sets the tree (N = 2n - 1), N_READS the batch.
 Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
 """
 import ctypes
@@ -25,7 +26,7 @@ def main():
 
     n = int(os.environ.get("N_READS", 1_000_000))
     rounds = int(os.environ.get("ROUNDS", 3))
-    tree = synth.make_tree(500, seed=42)
+    tree = synth.make_tree(int(os.environ.get("LEAVES", 500)), seed=42)
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
     data, offs = synth.make_reads(n, 150, seed=44)
     dev = torch.device("cuda", 0)
@@ -44,9 +45,12 @@ def main():
         os.environ["EPIK_AMD_WIDE_COUNTS"] = kv.get("wide", "0")
         os.environ["EPIK_AMD_STAMPS"] = kv.get("stamps", "0")
         os.environ["EPIK_AMD_LAYOUT"] = kv.get("layout", "paired")
+        os.environ.pop("EPIK_AMD_KERNEL", None)
+        if "kernel" in kv:
+            os.environ["EPIK_AMD_KERNEL"] = kv["kernel"]
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
         desc = capi.PlacerDesc(
-            abi_version=1, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
+            abi_version=capi.ABI_VERSION, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
             offset_bits=32, keep_factor=0.01, threshold=float(db.threshold), log_threshold=float(db.log_threshold),
             num_keys=db.num_keys, num_entries=db.num_entries, offsets=off32.ctypes.data,
             values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, reserved=0)

@@ -13,7 +13,7 @@ mkdir -p $OUT
 pass() { # name counters...
   local name=$1; shift
   timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/calib_$name -- $R/tools/scratch/calib_fetch > $OUT/calib_$name.log 2>&1
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/bench_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 $BENCH_ARGS > $OUT/bench_$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/bench_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-extras $BENCH_ARGS > $OUT/bench_$name.log 2>&1
 }
 pass fetch FETCH_SIZE
 pass rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
