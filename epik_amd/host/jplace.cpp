@@ -130,15 +130,48 @@ jplace_writer& jplace_writer::operator<<(const impl::placed_collection& placed)
 
 jplace_writer& jplace_writer::write(const impl::placed_collection& placed, size_t num_threads)
 {
-    const size_t n = placed.placed_seqs.size();
-    if (n == 0) return *this;
-    // one slice of the batch per thread, formatted side by side, written in order
-    const size_t parts = std::max<size_t>(1, std::min(num_threads, n / 2048 + 1));
+    return write(std::vector<const impl::placed_collection*>{&placed}, num_threads);
+}
+
+jplace_writer& jplace_writer::write(const std::vector<const impl::placed_collection*>& group, size_t num_threads)
+{
+    // The objects of all batches of the group, in order, cut into one run per thread (about 2048
+    // objects at least): the runs are formatted side by side and written one after the other.
+    struct run {
+        size_t batch, begin, end;  // objects [begin, end) of group[batch]
+    };
+    size_t total = 0;
+    for (const auto* placed : group) total += placed->placed_seqs.size();
+    if (total == 0) return *this;
+    const size_t parts = std::max<size_t>(1, std::min(num_threads, total / 2048 + 1));
+    const size_t per_part = (total + parts - 1) / parts;
+    std::vector<std::vector<run>> work(parts);
+    {
+        size_t part = 0, room = per_part;
+        for (size_t b = 0; b < group.size(); ++b) {
+            size_t at = 0;
+            const size_t n = group[b]->placed_seqs.size();
+            while (at < n) {
+                const size_t take = std::min(room, n - at);
+                work[part].push_back({b, at, at + take});
+                at += take;
+                room -= take;
+                if (room == 0 && part + 1 < parts) {
+                    ++part;
+                    room = per_part;
+                }
+            }
+        }
+    }
     std::vector<std::string> buffers(parts);
     auto format_part = [&](size_t part) {
-        const size_t begin = n * part / parts, end = n * (part + 1) / parts;
-        buffers[part].reserve((end - begin) * 900);
-        format_objects(placed, begin, end, buffers[part]);
+        size_t objects = 0;
+        for (const auto& r : work[part]) objects += r.end - r.begin;
+        buffers[part].reserve(objects * 900);
+        for (const auto& r : work[part]) {
+            if (!buffers[part].empty()) buffers[part] += ",";
+            format_objects(*group[r.batch], r.begin, r.end, buffers[part]);
+        }
     };
     if (parts == 1) {
         format_part(0);

@@ -9,6 +9,7 @@
 #include <fstream>
 #include <string>
 #include <string_view>
+#include <vector>
 
 #include "placer.hpp"
 
@@ -21,6 +22,8 @@ public:
     jplace_writer& operator<<(const impl::placed_collection& placed);
     /// the same, with the JSON text of the batch formatted by `num_threads` threads
     jplace_writer& write(const impl::placed_collection& placed, size_t num_threads);
+    /// several batches, in order, as one piece of work for the formatting threads
+    jplace_writer& write(const std::vector<const impl::placed_collection*>& group, size_t num_threads);
     void end();
 
 private:

@@ -31,13 +31,14 @@
 #include "phylo_kmer_db.hpp"
 #include "phylo_tree.hpp"
 #include "placer.hpp"
+#include "report.hpp"
 #include "seq_record.hpp"
 
 #ifndef EPIK_AMD_NO_MAIN
 namespace {
 
-/// Hand-over between two stages of the driver: at most `capacity` items wait; close() wakes
-/// everybody and makes push() / pop() return false.
+/// Hand-over between two stages of the driver: at most `capacity` items wait; after close() push()
+/// returns false and the pops return what is left, then false.
 template <typename T>
 class bounded_queue {
 public:
@@ -61,6 +62,21 @@ public:
         _not_full.notify_one();
         return true;
     }
+    /// Waits for at least one item, then takes what is there, `max_items` at most, in order.
+    /// False once the queue is closed and drained.
+    bool pop_up_to(std::vector<T>& items, size_t max_items)
+    {
+        items.clear();
+        std::unique_lock<std::mutex> lock(_mutex);
+        _not_empty.wait(lock, [&] { return _closed || !_items.empty(); });
+        while (!_items.empty() && items.size() < max_items) {
+            items.push_back(std::move(_items.front()));
+            _items.pop_front();
+        }
+        _not_full.notify_all();
+        return !items.empty();
+    }
+    bool pop_all(std::vector<T>& items) { return pop_up_to(items, std::numeric_limits<size_t>::max()); }
     void close()
     {
         std::lock_guard<std::mutex> lock(_mutex);
@@ -113,90 +129,8 @@ std::string make_output_filename(const std::string& input_file, const std::strin
     return dir + "placements_" + base + ".jplace";
 }
 
-/// main.cpp:66-112
-template <typename T>
-std::string to_human_readable(T num)
-{
-    std::ostringstream oss;
-    if (num < 1024) {
-        oss << std::fixed << num;
-    } else {
-        double value;
-        std::string suffix;
-        if (num < 1024 * 1024) {
-            value = num / 1024.0;
-            suffix = "K";
-        } else if (num < 1024.0 * 1024 * 1024) {
-            value = num / (1024.0 * 1024.0);
-            suffix = "M";
-        } else {
-            value = num / (1024.0 * 1024.0 * 1024.0);
-            suffix = "B";
-        }
-        double int_part;
-        if (std::modf(value, &int_part) == 0.0) {
-            oss << static_cast<long long>(int_part) << suffix;
-        } else {
-            oss.precision(1);
-            oss << std::fixed << value << suffix;
-        }
-    }
-    return oss.str();
-}
-
-/// main.cpp:115-151
-std::string humanize_time(size_t milliseconds)
-{
-    const size_t ms_per_sec = 1000, ms_per_min = 60 * ms_per_sec, ms_per_hour = 60 * ms_per_min;
-    const size_t ms_per_day = 24 * ms_per_hour;
-    const size_t days = milliseconds / ms_per_day;
-    milliseconds %= ms_per_day;
-    const size_t hours = milliseconds / ms_per_hour;
-    milliseconds %= ms_per_hour;
-    const size_t minutes = milliseconds / ms_per_min;
-    milliseconds %= ms_per_min;
-    const size_t seconds = milliseconds / ms_per_sec;
-    std::ostringstream oss;
-    if (days > 0) oss << days << " day" << (days > 1 ? "s" : "") << ", ";
-    if (hours > 0 || days > 0) oss << std::setw(2) << std::setfill('0') << hours << ":";
-    oss << std::setw(2) << std::setfill('0') << minutes << ":" << std::setw(2) << std::setfill('0') << seconds;
-    return oss.str();
-}
-
 }  // namespace
 #endif  // EPIK_AMD_NO_MAIN
-
-namespace epik_amd {
-
-/// main.cpp:154-194: "128K", "50M", "4.2Gb", bare number = bytes; 1024-based, first letter only
-size_t parse_human_readable(const std::string& max_ram)
-{
-    double value;
-    char unit = 0;
-    std::stringstream ss(max_ram);
-    ss >> value;
-    if (ss.fail()) throw std::runtime_error("Could not parse --max-ram parameter: wrong numerical part");
-    if (!ss.eof()) {
-        ss >> unit;
-        if (ss.fail()) throw std::runtime_error("Could not parse --max-ram parameter: wrong unit");
-    }
-    switch (std::toupper(unit)) {
-        case 0:
-        case 'B': return static_cast<size_t>(value);
-        case 'K': return static_cast<size_t>(value * 1024);
-        case 'M': return static_cast<size_t>(value * 1024 * 1024);
-        case 'G': return static_cast<size_t>(value * 1024 * 1024 * 1024);
-        default: throw std::runtime_error("Unknown memory unit.");
-    }
-}
-
-/// main.cpp:196-202
-void check_mu(float mu)
-{
-    if ((mu < 0.0) || (mu > 1.0)) throw std::runtime_error("Mu has to a value in [0, 1]");
-}
-
-}  // namespace epik_amd
 
 #ifndef EPIK_AMD_NO_MAIN
 
@@ -299,10 +233,10 @@ int main(int argc, char** argv)
 
         size_t max_entries = std::numeric_limits<size_t>::max();
         if (parsed.has("max-ram")) {
-            const auto max_ram = epik_amd::parse_human_readable(parsed.require("max-ram"));
+            const auto max_ram = epik_amd::parse_memory_size(parsed.require("max-ram"));
             max_entries = static_cast<size_t>(max_ram / sizeof(epik_amd::pkdb_value));
             if (max_entries == 0) throw std::runtime_error("Memory limit is too low");
-            std::cout << "Max-RAM provided: will be loaded not more than " << to_human_readable(max_entries)
+            std::cout << "Max-RAM provided: will be loaded not more than " << epik_amd::human_count(max_entries)
                       << " phylo-k-mers." << std::endl;
         }
 
@@ -336,8 +270,8 @@ int main(int argc, char** argv)
                   << "\tomega: " << db.omega() << std::endl
                   << "\tPositions loaded: " << (db.positions_loaded() ? "true" : "false") << std::endl
                   << std::endl;
-        std::cout << "Loaded " << to_human_readable(db.get_num_entries_loaded()) << " of "
-                  << to_human_readable(db.get_num_entries_total()) << " phylo-k-mers. " << std::endl
+        std::cout << "Loaded " << epik_amd::human_count(db.get_num_entries_loaded()) << " of "
+                  << epik_amd::human_count(db.get_num_entries_total()) << " phylo-k-mers. " << std::endl
                   << std::endl;
 
         const auto tree = epik_amd::io::parse_newick(db.tree());
@@ -356,84 +290,127 @@ int main(int argc, char** argv)
         double average_speed = 0.0;
         size_t num_iterations = 0;
 
-        // Three stages on three threads, batches handed on through short queues: the FASTA
-        // reader, the placer (this thread: dedup, GPU, length join) and the jplace writer
-        // (formatting on `--jobs` threads).  The reference runs them one after the other
-        // (main.cpp:336-361); batch boundaries, dedup per batch and output order are the same.
+        // Stages on their own threads, batches handed on through queues: the FASTA reader; one placer
+        // thread per device; the jplace writer (formatting on `--jobs` threads).  The reference runs
+        // read, place and write one after the other per batch (main.cpp:336-361); batch boundaries,
+        // dedup per batch (place.cpp:207) and output order are the same here.  A placer thread takes
+        // every batch that is waiting (up to kGroupBatches) as ONE launch -- a 2000-read batch is far too
+        // small to fill a device -- so with several devices whole groups of batches go to them in turn,
+        // and the writer puts the batches back in input order.
+        constexpr size_t kGroupBatches = 64;
         struct work_item {
+            size_t sequence = 0;                          // position of the batch in the input
             std::vector<epik_amd::seq_record> batch;     // owns the bytes the views below point into
             epik_amd::placer::placed_collection placed;
         };
-        bounded_queue<std::vector<epik_amd::seq_record>> to_place(4);
-        bounded_queue<work_item> to_write(4);
+        const size_t n_devices = placer.device_count();
+        bounded_queue<work_item> to_place(2 * kGroupBatches * n_devices);
+        bounded_queue<work_item> to_write(2 * kGroupBatches * n_devices);
         std::exception_ptr reader_error, writer_error;
-        stage_clock read_clock, place_clock, write_clock;
+        std::vector<std::exception_ptr> placer_errors(n_devices);
+        stage_clock read_clock, write_clock;
+        std::vector<stage_clock> place_clocks(n_devices);
+        std::mutex stats_mutex;
         std::thread reader_thread([&] {
             try {
                 epik_amd::io::batch_fasta reader(query_file, batch_size);
-                while (true) {
+                for (size_t sequence = 0;; ++sequence) {
                     read_clock.start();
                     auto batch = reader.next_batch();
                     read_clock.stop();
-                    const bool last = batch.empty();
-                    if (!to_place.push(std::move(batch)) || last) break;  // an empty batch ends the stream
+                    if (batch.empty() || !to_place.push(work_item{sequence, std::move(batch), {}})) break;
                 }
             } catch (...) {
                 reader_error = std::current_exception();
-                to_place.push({});
             }
+            to_place.close();  // the placer threads drain what is queued, then stop
         });
         std::thread writer_thread([&] {
             try {
-                work_item item;
-                while (to_write.pop(item)) {
+                std::map<size_t, work_item> waiting;  // batches that arrived ahead of their turn
+                size_t next = 0;
+                std::vector<work_item> arrived;
+                while (to_write.pop_all(arrived)) {
+                    for (auto& item : arrived) waiting.emplace(item.sequence, std::move(item));
+                    std::vector<const epik_amd::placer::placed_collection*> group;
+                    std::vector<work_item> ready;  // keeps the batches alive while they are written
+                    for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+                        ready.push_back(std::move(it->second));
+                        waiting.erase(it);
+                        ++next;
+                    }
+                    for (const auto& item : ready) group.push_back(&item.placed);
+                    if (group.empty()) continue;
                     write_clock.start();
-                    jplace.write(item.placed, num_threads);
+                    jplace.write(group, num_threads);
                     write_clock.stop();
                 }
             } catch (...) {
                 writer_error = std::current_exception();
                 to_write.close();
+                to_place.close();
             }
         });
-        std::exception_ptr placer_error;
-        try {
-            std::vector<epik_amd::seq_record> batch;
-            while (to_place.pop(batch) && !batch.empty()) {
-                const auto begin_batch = std::chrono::steady_clock::now();
-                place_clock.start();
-                auto placed_batch = placer.place(batch, num_threads);
-                place_clock.stop();
-                const auto end_batch = std::chrono::steady_clock::now();
-                auto ms_diff =
-                    (float)std::chrono::duration_cast<std::chrono::milliseconds>(end_batch - begin_batch).count();
-                if (ms_diff == 0) ms_diff = 1;
-                average_speed += 1000.0 * (double)batch_size / ms_diff;  // main.cpp:351-352 (nominal batch size)
-                num_seq_placed += batch.size();
-                ++num_iterations;
-                if (!to_write.push(work_item{std::move(batch), std::move(placed_batch)})) break;
-            }
-        } catch (...) {
-            placer_error = std::current_exception();
+        std::vector<std::thread> placer_threads;
+        for (size_t device = 0; device < n_devices; ++device) {
+            placer_threads.emplace_back([&, device] {
+                try {
+                    std::vector<work_item> group;
+                    while (to_place.pop_up_to(group, kGroupBatches)) {
+                        const auto begin_group = std::chrono::steady_clock::now();
+                        place_clocks[device].start();
+                        std::vector<const std::vector<epik_amd::seq_record>*> batches;
+                        for (const auto& item : group) batches.push_back(&item.batch);
+                        auto placed = placer.place_batches(batches, device);
+                        place_clocks[device].stop();
+                        auto ms_diff = (float)std::chrono::duration_cast<std::chrono::microseconds>(
+                                           std::chrono::steady_clock::now() - begin_group).count() / 1000.0f;
+                        if (ms_diff <= 0) ms_diff = 0.001f;
+                        {
+                            std::lock_guard<std::mutex> lock(stats_mutex);
+                            for (const auto& item : group) num_seq_placed += item.batch.size();
+                            // main.cpp:351-352: nominal batch size over the batch's time; a batch of a group
+                            // takes its share of the group's time
+                            average_speed += (double)group.size() * 1000.0 * (double)batch_size /
+                                             ((double)ms_diff / (double)group.size());
+                            num_iterations += group.size();
+                        }
+                        bool open = true;
+                        for (size_t i = 0; i < group.size() && open; ++i) {
+                            group[i].placed = std::move(placed[i]);
+                            open = to_write.push(std::move(group[i]));
+                        }
+                        if (!open) break;
+                    }
+                } catch (...) {
+                    placer_errors[device] = std::current_exception();
+                    to_place.close();
+                }
+            });
         }
+        for (auto& t : placer_threads) t.join();
         to_place.close();
         to_write.close();
         reader_thread.join();
         writer_thread.join();
-        for (const auto& error : {placer_error, reader_error, writer_error})
+        for (const auto& error : placer_errors)
             if (error) std::rethrow_exception(error);
+        for (const auto& error : {reader_error, writer_error})
+            if (error) std::rethrow_exception(error);
+        double place_ms = 0;
+        for (const auto& clock : place_clocks) place_ms += clock.ms();
         if (std::getenv("EPIK_AMD_STAGE_TIMES"))
-            std::cout << "stage read " << read_clock.ms() << " ms\nstage place " << place_clock.ms()
+            std::cout << "stage read " << read_clock.ms() << " ms\nstage place " << place_ms
                       << " ms\nstage write " << write_clock.ms() << " ms" << std::endl;
         jplace.end();
         if (num_iterations) average_speed /= (double)num_iterations;
         std::cout << std::endl
-                  << "Placed " << num_seq_placed << " sequences.\nAverage speed: " << to_human_readable(average_speed)
+                  << "Placed " << num_seq_placed << " sequences.\nAverage speed: " << epik_amd::human_count(average_speed, false)
                   << " seq/s.\n";
         std::cout << "Output: " << jplace_filename << std::endl;
         const auto placement_time =
             (size_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - begin).count();
-        std::cout << "Placement time: " << humanize_time(placement_time) << " (" << placement_time << " ms)"
+        std::cout << "Placement time: " << epik_amd::human_duration(placement_time) << " (" << placement_time << " ms)"
                   << std::endl;
         std::cout << "Done." << '\n' << std::flush;
     } catch (const std::runtime_error& error) {

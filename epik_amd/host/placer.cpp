@@ -3,7 +3,6 @@
 #include <cmath>
 #include <stdexcept>
 #include <string>
-#include <thread>
 
 namespace epik_amd {
 
@@ -70,42 +69,46 @@ placer::~placer() noexcept
 
 placed_collection placer::place(const std::vector<seq_record>& seq_records, size_t /*num_threads*/)
 {
-    // identical sequences are placed once (place.cpp:73-81, 207-212)
-    sequence_map_t sequence_map;
-    std::vector<std::string_view> unique_sequences;
-    for (const auto& rec : seq_records) {
-        auto [it, inserted] = sequence_map.try_emplace(rec.sequence());
-        if (inserted) unique_sequences.push_back(rec.sequence());
-        it->second.push_back(rec.header());
-    }
-    const size_t n = unique_sequences.size();
-    std::vector<placed_sequence> placed_seqs(n);
-    if (n == 0) return {std::move(sequence_map), std::move(placed_seqs)};
+    auto placed = place_batches({&seq_records}, 0);
+    return std::move(placed[0]);
+}
 
-    // one contiguous shard of the unique reads per device
-    const size_t n_dev = _handles.size();
-    std::vector<std::string> errors(n_dev);
-    auto run_shard = [&](size_t d) {
-        const size_t begin = n * d / n_dev, end = n * (d + 1) / n_dev;
-        if (begin == end) return;
-        std::string bytes;
-        std::vector<uint64_t> offsets{0};
-        for (size_t i = begin; i < end; ++i) {
-            bytes.append(unique_sequences[i]);
-            offsets.push_back(bytes.size());
+std::vector<placed_collection> placer::place_batches(const std::vector<const std::vector<seq_record>*>& batches,
+                                                     size_t device_index)
+{
+    if (device_index >= _handles.size()) throw std::runtime_error("GPU placer: no such device index");
+    std::vector<placed_collection> out(batches.size());
+    // identical sequences of a batch are placed once (place.cpp:73-81, 207-212); the unique reads of
+    // all batches go through the boundary in one call
+    std::string bytes;
+    std::vector<uint64_t> offsets{0};
+    std::vector<size_t> first_unique(batches.size() + 1, 0);
+    for (size_t b = 0; b < batches.size(); ++b) {
+        auto& sequence_map = out[b].sequence_map;
+        auto& placed_seqs = out[b].placed_seqs;
+        for (const auto& rec : *batches[b]) {
+            auto [it, inserted] = sequence_map.try_emplace(rec.sequence());
+            if (inserted) {
+                placed_seqs.push_back({rec.sequence(), {}});
+                bytes.append(rec.sequence());
+                offsets.push_back(bytes.size());
+            }
+            it->second.push_back(rec.header());
         }
-        const size_t m = end - begin;
-        std::vector<epik_amd_placement> rows(m * _keep_at_most);
-        std::vector<uint32_t> n_rows(m), counts(m * _keep_at_most);
-        if (epik_amd_placer_place(_handles[d], bytes.data(), offsets.data(), m, rows.data(), n_rows.data(),
-                                  counts.data()) != EPIK_AMD_OK) {
-            errors[d] = epik_amd_last_error();
-            return;
-        }
-        for (size_t i = 0; i < m; ++i) {
-            auto& out = placed_seqs[begin + i];
-            out.sequence = unique_sequences[begin + i];
-            out.placements.reserve(n_rows[i]);
+        first_unique[b + 1] = first_unique[b] + placed_seqs.size();
+    }
+    const size_t n = offsets.size() - 1;
+    if (n == 0) return out;
+    std::vector<epik_amd_placement> rows(n * _keep_at_most);
+    std::vector<uint32_t> n_rows(n), counts(n * _keep_at_most);
+    if (epik_amd_placer_place(_handles[device_index], bytes.data(), offsets.data(), n, rows.data(), n_rows.data(),
+                              counts.data()) != EPIK_AMD_OK)
+        throw std::runtime_error(std::string("GPU placer: ") + epik_amd_last_error());
+    for (size_t b = 0; b < batches.size(); ++b) {
+        for (size_t u = 0; u < out[b].placed_seqs.size(); ++u) {
+            const size_t i = first_unique[b] + u;
+            auto& placements = out[b].placed_seqs[u].placements;
+            placements.reserve(n_rows[i]);
             for (uint32_t r = 0; r < n_rows[i]; ++r) {
                 const auto& row = rows[i * _keep_at_most + r];
                 const size_t count = counts[i * _keep_at_most + r];
@@ -113,27 +116,16 @@ placed_collection placer::place(const std::vector<seq_record>& seq_records, size
                 double distal = 0.0, pendant = 0.0;
                 if (count != 0) {
                     const auto node = _original_tree.get_by_postorder_id(row.branch);
-                    if (!node) {
-                        errors[d] = "Could not find node by post-order id: " + std::to_string(row.branch);
-                        return;
-                    }
+                    if (!node)
+                        throw std::runtime_error("Could not find node by post-order id: " + std::to_string(row.branch));
                     distal = (*node)->get_branch_length() / 2;  // place.cpp:435
                     pendant = _pendant_lengths[row.branch];
                 }
-                out.placements.push_back({row.branch, row.score, row.lwr, count, distal, pendant});
+                placements.push_back({row.branch, row.score, row.lwr, count, distal, pendant});
             }
         }
-    };
-    if (n_dev == 1) {
-        run_shard(0);
-    } else {
-        std::vector<std::thread> threads;
-        for (size_t d = 0; d < n_dev; ++d) threads.emplace_back(run_shard, d);
-        for (auto& t : threads) t.join();
     }
-    for (const auto& e : errors)
-        if (!e.empty()) throw std::runtime_error("GPU placer: " + e);
-    return {std::move(sequence_map), std::move(placed_seqs)};
+    return out;
 }
 
 }  // namespace epik_amd

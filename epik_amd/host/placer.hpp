@@ -4,8 +4,9 @@
 // (epik/include/epik/place.h:39-140): construct with (db, tree, keep_at_most, keep_factor,
 // max_threads), call place(seq_records, num_threads) per FASTA batch, get a
 // placed_collection whose string_views point into the caller's batch.
-// Extra, MI355X-specific: a list of HIP devices; the unique reads of a batch are split
-// across them (database replicated, no collective).
+// Extra, MI355X-specific: a list of HIP devices (database replicated on each, no collective) and
+// place_batches(): several FASTA batches in one launch on one of them -- the driver hands whole
+// groups of batches to the devices in turn.
 #ifndef EPIK_AMD_HOST_PLACER_HPP
 #define EPIK_AMD_HOST_PLACER_HPP
 
@@ -62,7 +63,15 @@ public:
     placer& operator=(const placer&) = delete;
     ~placer() noexcept;
 
+    /// The reference's call: one batch, on the first device.
     placed_collection place(const std::vector<seq_record>& seq_records, size_t num_threads);
+
+    /// Several batches in ONE launch on device `device_index` (of the list given to the constructor).
+    /// Every batch is de-duplicated on its own, exactly as `place` does it (place.cpp:207-212: dedup is
+    /// per batch), the unique reads of all of them cross the boundary together, and every batch gets
+    /// its own placed_collection back.  Thread-safe across different devices.
+    std::vector<placed_collection> place_batches(const std::vector<const std::vector<seq_record>*>& batches,
+                                                 size_t device_index);
 
     size_t device_count() const noexcept { return _handles.size(); }
 
