@@ -43,7 +43,7 @@ def test_driver_help_and_errors(host_bins, tmp_path):
     assert bad.returncode == 255 and "Error:" in bad.stderr   # return -1
     mu = subprocess.run([os.path.join(host_bins, "epik-dna"), "-d", "x", "-q", "x", "-o", ".", "--mu", "2"],
                         capture_output=True, text=True)
-    assert mu.returncode == 255 and "Mu has to" in mu.stderr
+    assert mu.returncode == 255 and "--mu must lie in [0, 1]" in mu.stderr
 
 
 def test_launcher_builds_reference_argv():
