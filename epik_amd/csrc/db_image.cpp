@@ -72,7 +72,7 @@ TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t for
             if (forced_waves && waves != forced_waves) continue;
             const uint32_t slices = (uint32_t)waves * passes;
             const uint32_t rows = (n + slices - 1) / slices;
-            const uint32_t rows_pad = (rows + 1u + 63u) & ~63u;
+            const uint32_t rows_pad = team_rows_pad(rows);
             const uint32_t desc = team_desc_bytes(keep);
             if (team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts32), desc, keep) > kLdsPerCu) continue;
             const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts16), desc, keep);

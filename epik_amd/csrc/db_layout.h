@@ -67,6 +67,8 @@ constexpr uint32_t kTeamDescCap = 56;  // chunk descriptors per slice and round 
 constexpr uint32_t kTeamCandCap = 60;  // top-k candidates of a slice (+ 4 spare entries = the list's 64)
 // bytes of one table entry {u32 line, u16 len[W]}
 constexpr int team_entry_bytes(int waves) { return waves <= 6 ? 16 : waves <= 14 ? 32 : 64; }
+// LDS rows of a slice: its branches + the dummy row, to a multiple of 16 (the epilogue's sweeps mask their last trip)
+constexpr uint32_t team_rows_pad(uint32_t slice_rows) { return (slice_rows + 1u + 15u) & ~15u; }
 constexpr uint32_t team_slice_bytes(uint32_t rows_pad, int counts) { return (rows_pad * (4u + (1u << counts)) + 15u) & ~15u; }
 // a slice's descriptor list (one round + one trip of spare entries) also holds its top-k candidates
 // and, with one pass, its ranked rows for the merge (keep_at_most entries of 16 bytes)

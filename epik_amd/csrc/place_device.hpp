@@ -702,24 +702,22 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const bool fast_div = p.kmer_size <= 32u;
     uint32_t touched = 0;
     float lane_best_f = -INFINITY;  // this lane's best score
-    // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 64: cells behind N hold
-    // no count (the dummy row of the out-of-range lanes was cleared by the caller), so there is no
-    // bounds test.  Four consecutive rows per lane and trip while they last (one 16-byte LDS access),
-    // one per trip for the remainder; the arithmetic is branch-free.
+    // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 16: cells behind N hold
+    // no count (the dummy row of the out-of-range lanes was cleared by the caller), so rows need no
+    // bounds test.  Four consecutive rows per lane (one 16-byte LDS access), 256 rows per trip; the
+    // arithmetic is branch-free.
     constexpr int kUnroll = 4;
     const uint32_t n_rows_pad = ctx.rows_pad(p);
-    auto correct_rows = [&](auto unroll, uint32_t base) {
-        constexpr int kRows = decltype(unroll)::value;
-        // kRows == 4: the lane takes four consecutive rows (one wide LDS access); else one row per lane
-        float raw[kRows], pre[kRows], s[kRows];
-        uint32_t cnt[kRows];
-        if constexpr (kRows == 4) {
-            lds.load4(base + 4u * (uint32_t)lane, raw, cnt);
-        } else {
-            const uint2 cv = lds.load(base + (uint32_t)lane);
-            raw[0] = __uint_as_float(cv.x);
-            cnt[0] = cv.y;
-        }
+    auto correct_rows = [&](auto whole, uint32_t base) {
+        // the lane takes four consecutive rows (one wide LDS access); the last, partial trip of 256
+        // rows (kWhole == false) leaves the lanes behind the end without rows
+        constexpr bool kWhole = decltype(whole)::value;
+        constexpr int kRows = kUnroll;
+        const uint32_t i0 = base + 4u * (uint32_t)lane;
+        const bool mine = kWhole || i0 < n_rows_pad;
+        float raw[kRows] = {0.0f, 0.0f, 0.0f, 0.0f}, pre[kRows], s[kRows];
+        uint32_t cnt[kRows] = {0u, 0u, 0u, 0u};
+        if (mine) lds.load4(i0, raw, cnt);
         float smallest = INFINITY;
 #pragma unroll
         for (int u = 0; u < kRows; ++u) {
@@ -739,16 +737,12 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             touched += c ? 1u : 0u;
             lane_best_f = fmaxf(lane_best_f, s[u]);
         }
-        if constexpr (kRows == 4)  // the count cells stay as they are
-            lds.store_scores4(base + 4u * (uint32_t)lane, s);
-        else
-            lds.score[base + (uint32_t)lane] = s[0];
+        if (mine) lds.store_scores4(i0, s);  // the count cells stay as they are
     };
     {
         uint32_t base = 0;
-        for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave)
-            correct_rows(std::integral_constant<int, kUnroll>{}, base);
-        for (; base < n_rows_pad; base += kWave) correct_rows(std::integral_constant<int, 1>{}, base);
+        for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave) correct_rows(std::true_type{}, base);
+        if (base < n_rows_pad) correct_rows(std::false_type{}, base);
     }
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
     touched = wave_sum_u32(touched);
@@ -799,16 +793,15 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     if (touched != 0) {
         n_cand = 0;
         const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
-        auto scan_rows = [&](auto unroll, uint32_t base) {
-            constexpr int kRows = decltype(unroll)::value;
-            float row[kRows];  // as in the correction sweep: four consecutive rows per lane, or one
-            if constexpr (kRows == 4)
-                lds.load_scores4(base + 4u * (uint32_t)lane, row);
-            else
-                row[0] = lds.score[base + (uint32_t)lane];
+        auto scan_rows = [&](auto whole, uint32_t base) {
+            constexpr bool kWhole = decltype(whole)::value;  // as in the correction sweep
+            constexpr int kRows = kUnroll;
+            const uint32_t i0 = base + 4u * (uint32_t)lane;
+            float row[kRows] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kWhole || i0 < n_rows_pad) lds.load_scores4(i0, row);
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
-                const uint32_t i = kRows == 4 ? base + 4u * (uint32_t)lane + (uint32_t)u : base + (uint32_t)lane;
+                const uint32_t i = i0 + (uint32_t)u;
                 const float sc = row[u];             // -inf where there is no edge (a sum of finite
                 const bool edge = sc != -INFINITY;   // log10 scores never is)
                 // exp2(-inf) = 0: rows without an edge add nothing
@@ -824,9 +817,8 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         };
         {
             uint32_t base = 0;
-            for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave)
-                scan_rows(std::integral_constant<int, kUnroll>{}, base);
-            for (; base < n_rows_pad; base += kWave) scan_rows(std::integral_constant<int, 1>{}, base);
+            for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave) scan_rows(std::true_type{}, base);
+            if (base < n_rows_pad) scan_rows(std::false_type{}, base);
         }
         if (n_cand > kCandCap) {
             // Too many ties at tau for the candidate buffer: repeated selection over all

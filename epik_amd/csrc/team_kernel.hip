@@ -274,7 +274,7 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
     lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave * tp.slice_bytes + (size_t)rows_pad * 4);
     lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave * tp.desc_bytes);
     lds_u32 *totals = (lds_u32 *)reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes);  // [W tiles][W slices]
-    lds_u32 *flags = totals + W * W;                                                                      // [2]: any ambiguous k-mer, by read parity
+    lds_u32 *flags = totals + W * W;                                                                      // [2]: any ambiguous k-mer, alternating over the workgroup's reads
     lds_partial *partials = (lds_partial *)reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4);
     const uint32_t n_slices = W * tp.passes;
     lds_u32x4 *merge_cand;
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
             continue;
         }
         const uint64_t n_kmers = len - k + 1;  // :322
-        const uint32_t parity = (uint32_t)read & 1u;
+        // which of the two flags this read uses: the workgroup's reads alternate (NOT read & 1: with an even
+        // grid every read of a workgroup has the same parity, and the clear below would race with the next read)
+        const uint32_t parity = (uint32_t)((read - blockIdx.x) / gridDim.x) & 1u;
         bool any_amb = false;  // the same in every wave of the workgroup
 
         for (uint32_t pass = 0; pass < tp.passes; ++pass) {

@@ -121,7 +121,7 @@ def test_team_layout(db, kernel, waves, monkeypatch):
     assert plan.kernel == 1 and plan.layout == 5 and plan.team_waves == waves and plan.team_passes == 1
     rows = plan.slice_rows
     assert rows * waves >= db.num_branches > rows * (waves - 1)
-    rows_pad = (rows + 1 + 63) // 64 * 64
+    rows_pad = (rows + 1 + 15) // 16 * 16
     entry_bytes = 16 if waves == 4 else 32
     post, line = bytearray(), 0
     for key, (b, e) in enumerate(_lists(db)):
