@@ -62,24 +62,36 @@ struct TeamChoice {
     uint32_t passes = 0, slice_rows = 0, rows_pad = 0, resident = 0;
 };
 
-// (W, P) of the team kernel for a tree of `n` branches: as few passes as fit a CU's LDS (with the 32-bit
-// counts, the widest), and 4 waves rather than 8 when both do (measured at N = 9 999 and 19 999, r02:
-// a workgroup of 4 is 1.5 x faster -- fewer slices to merge, fewer idle waves in the front end).
+// (W, P) of the team kernel for a tree of `n` branches.  Measured (r02, N = 10 000 .. 30 000, 150 bp
+// reads): a read takes about (0.15 + P) x 20 us in a workgroup whatever the slice size, so the
+// geometry that places most reads per second is the one with most resident workgroups per unit
+// of that time -- e.g. two passes of half-size slices at N = 20 000 (3 workgroups per CU) beat one
+// pass (1 workgroup) 1.8 x.  4 waves always beat 8 (fewer slices to merge, fewer idle waves in the
+// front end): 8 only when forced.  The 32-bit-count kernel must fit a CU.
 TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
 {
+    TeamChoice best;
+    double best_score = 0.0;
+    const int waves = forced_waves ? forced_waves : 4;
     for (uint32_t passes = forced_passes ? forced_passes : 1; passes <= 4096; ++passes) {
-        for (int waves : {4, 8}) {
-            if (forced_waves && waves != forced_waves) continue;
-            const uint32_t slices = (uint32_t)waves * passes;
-            const uint32_t rows = (n + slices - 1) / slices;
-            const uint32_t rows_pad = team_rows_pad(rows);
-            const uint32_t desc = team_desc_bytes(keep);
-            if (team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts32), desc, keep) > kLdsPerCu) continue;
-            const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts16), desc, keep);
-            return TeamChoice{waves, passes, rows, rows_pad, team_resident_blocks(waves, normal) * (uint32_t)waves};
+        const uint32_t slices = (uint32_t)waves * passes;
+        const uint32_t rows = (n + slices - 1) / slices;
+        const uint32_t rows_pad = team_rows_pad(rows);
+        const uint32_t desc = team_desc_bytes(keep);
+        if (team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, kCounts32), desc, keep) > kLdsPerCu) continue;
+        // judged with the counts short reads get: 8 bits where that kernel exists (its "seen" bits of the
+        // ambiguous path must fit the slice's descriptor list), else 16
+        const int usual = (rows_pad + 7u) / 8u <= desc ? kCounts8 : kCounts16;
+        const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, usual), desc, keep);
+        const uint32_t blocks = team_resident_blocks(waves, normal);
+        const double score = (double)blocks / (0.15 + (double)passes);
+        if (score > best_score) {
+            best_score = score;
+            best = TeamChoice{waves, passes, rows, rows_pad, blocks * (uint32_t)waves};
         }
+        if (forced_passes || blocks >= team_kernel_waves_per_cu(waves) / (uint32_t)waves) break;  // more passes only cost
     }
-    return TeamChoice{};
+    return best;
 }
 
 }  // namespace
@@ -165,8 +177,8 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     for (int c = 0; c < 3; ++c) plan.wave_resident[c] = wave_fits ? wave_kernel_resident_waves(plan.n_pad, c) : 0;
 
     // ---- kernel: one wavefront per read while enough of them fit a CU, else a workgroup per read ----
-    // (measured, r02: the team kernel wins where fewer than 6 waves of the other fit a CU, N >~ 4 500)
-    bool team = !wave_fits || plan.wave_resident[kCounts16] < 6;
+    // (measured, r02: the team kernel wins where fewer than 5 waves of the other fit a CU, N >~ 5 500)
+    bool team = !wave_fits || plan.wave_resident[kCounts16] < 5;
     int forced_waves = 0;
     uint32_t forced_passes = 0;
     if (forced_kernel && forced_kernel[0]) {
