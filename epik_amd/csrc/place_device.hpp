@@ -555,8 +555,10 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
 struct WaveCtx {
     static constexpr bool kTeam = false;
     static constexpr uint32_t kCandCap = kChunkCap;  // top-k candidates: as many as chunk descriptors fit
-    __device__ __forceinline__ uint32_t rows_pad(const PlaceParams &p) const { return p.n_pad; }
-    __device__ __forceinline__ uint32_t rows(const PlaceParams &p) const { return p.num_branches; }
+    template <typename Params>
+    __device__ __forceinline__ uint32_t rows_pad(const Params &p) const { return p.n_pad; }
+    template <typename Params>
+    __device__ __forceinline__ uint32_t rows(const Params &p) const { return p.num_branches; }
     __device__ __forceinline__ uint32_t branch_base() const { return 0u; }
     template <typename Layout>
     __device__ __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr, uint32_t &len) const
@@ -679,6 +681,7 @@ template <typename Layout, typename CountT, typename Ctx>
 __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
                                                          uint64_t read, uint64_t n_kmers, Ctx ctx)
 {
+    // (__builtin_amdgcn_kernarg_segment_ptr() is null inside an out-of-line function: the block comes as kp)
     const PlaceParams &p = *kp;
     const int lane = lane_id();
     const uint32_t N = ctx.rows(p);

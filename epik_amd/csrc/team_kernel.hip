@@ -82,8 +82,10 @@ struct TeamCtx {
     uint32_t rows_pad_, rows_, base_, slice_, pass_;
     lds_u32x4 *cand;       // [keep_at_most] ranked rows of this slice for the merge
     lds_partial *partial;  // this slice's share of sum_scores
-    __device__ __forceinline__ uint32_t rows_pad(const PlaceParams &) const { return rows_pad_; }
-    __device__ __forceinline__ uint32_t rows(const PlaceParams &) const { return rows_; }
+    template <typename Params>
+    __device__ __forceinline__ uint32_t rows_pad(const Params &) const { return rows_pad_; }
+    template <typename Params>
+    __device__ __forceinline__ uint32_t rows(const Params &) const { return rows_; }
     __device__ __forceinline__ uint32_t branch_base() const { return base_; }
     template <typename Layout>
     __device__ __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr, uint32_t &len) const

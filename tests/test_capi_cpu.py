@@ -58,6 +58,9 @@ def _desc(db, **over):
     (dict(num_keys=17), capi.ERR_INVALID),
     (dict(num_entries=3), capi.ERR_INVALID),
     (dict(offsets=None), capi.ERR_INVALID),
+    # k-mer codes are 32-bit on the device: nucl k <= 15 (4^16 = 2^32 codes is one too many), amino k <= 7
+    (dict(kmer_size=16, num_keys=4 ** 16), capi.ERR_UNSUPPORTED),
+    (dict(alphabet_size=20, kmer_size=8, num_keys=20 ** 8), capi.ERR_UNSUPPORTED),
 ])
 def test_create_rejects_bad_descriptors(small_case, over, code):
     _, db = small_case
@@ -135,4 +138,4 @@ def test_generated_isa_keeps_its_hands_off_the_load_ring():
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     run = subprocess.run(["make", "-C", os.path.join(root, "epik_amd", "csrc"), "asm"], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
-    assert "ring-asm lint: 0 problem(s)" in run.stdout
+    assert run.stdout.count("ring-asm lint: 0 problem(s)") == 2   # place_kernel.hip and team_kernel.hip

@@ -199,3 +199,21 @@ def test_golden_fixture_regression(oracle_lib):
             assert int(rows[i, j]["score"].view(np.uint32)) == score_bits
             assert float(rows[i, j]["lwr"]) == pytest.approx(lwr, rel=1e-14, abs=1e-300)
             assert int(counts[i, j]) == c
+
+
+def test_hash_map_lookup_and_batched_dedup_change_nothing(oracle_lib, small_case):
+    """The two CPU-baseline variants of bench.py (BASELINE.md 3): phylo_kmer_db::search through a
+    node-chained hash map, and placer::place as the driver runs it -- batches of `batch_size` reads,
+    each de-duplicated by content (place.cpp:73-81, 207-212) -- give the rows of the plain loop."""
+    _, db = small_case
+    rng = np.random.default_rng(3)
+    reads = mixed_reads(rng, 3000, db.kmer_size, max_len=120)
+    reads += reads[:500] + ["", "AC", reads[7]]          # duplicates inside and across batches
+    data, offs = synth.pack_reads(reads)
+    orc = oracle_lib.Oracle.from_synth(db)
+    plain = orc.place(data, offs, num_threads=2)
+    for use_hash in (False, True):
+        orc.use_hash_map(use_hash)
+        for got in (orc.place(data, offs, num_threads=2), orc.place_batched(data, offs, batch_size=700, num_threads=3)):
+            for a, b in zip(plain, got):
+                assert a.tobytes() == b.tobytes()

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Everything the round's measurements under profiles/ come from, in one GPU call:
+#   bash tools/profile_round.sh r02_a        (on the GPU box; results under gpurun_out/<tag>/)
+# bench lines, rocprofv3 --kernel-trace --stats summaries of the same commands, and the PMC passes
+# (separate rocprofv3 --pmc runs, tools/pmc_passes.sh) for the headline workload, the HBM-resident
+# database (k = 11) and the large tree (N = 9 999, team kernel).
+R=${GRAFT_REPO_ROOT:-$PWD}
+TAG=${1:-r02}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+log() { echo "[profile_round] $*"; }
+
+log "full default bench line"
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || log "bench failed"
+
+trace() { # name args...
+  local name=$1; shift
+  log "kernel trace: $name"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$name -- \
+      python3 $R/bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0 --no-extras "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err \
+      || log "trace $name failed"
+  cp $(ls $OUT/kt_$name/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_$name.csv 2>/dev/null
+}
+trace headline
+trace k11 --kmer-size 11
+trace n9999 --leaves 5000
+trace amino_k7 --states amino --kmer-size 7 --read-length 300 --p-present 0.0026
+log "k-mer-space shard, N = 9999, one GPU"
+python3 $R/bench.py --mode kmer-shard --leaves 5000 --reads-per-step 65536 --steps 10 --warmup 2 --cpu-baseline-seconds 0 \
+    > $OUT/bench_kmer_shard_n9999.json 2> $OUT/bench_kmer_shard_n9999.err
+
+for cfg in "headline:" "k11:--kmer-size 11" "n9999:--leaves 5000"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  log "PMC passes: $name"
+  (cd $R && BENCH_ARGS="$args" bash tools/pmc_passes.sh ${TAG}_$name > $OUT/pmc_$name.log 2>&1)
+  cp $R/gpurun_out/pmc_${TAG}_$name/summary.txt $OUT/pmc_summary_$name.txt 2>/dev/null
+done
+log done
+ls $OUT
