@@ -560,6 +560,10 @@ struct WaveCtx {
     template <typename Params>
     __device__ __forceinline__ uint32_t rows(const Params &p) const { return p.num_branches; }
     __device__ __forceinline__ uint32_t branch_base() const { return 0u; }
+    // the placer constants the epilogue needs (a team context carries them in registers instead)
+    __device__ __forceinline__ uint32_t kmer_size(const PlaceParams &p) const { return p.kmer_size; }
+    __device__ __forceinline__ float log_threshold(const PlaceParams &p) const { return p.log_threshold; }
+    __device__ __forceinline__ uint32_t keep_at_most(const PlaceParams &p) const { return p.keep_at_most; }
     template <typename Layout>
     __device__ __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr, uint32_t &len) const
     {
@@ -685,8 +689,8 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const PlaceParams &p = *kp;
     const int lane = lane_id();
     const uint32_t N = ctx.rows(p);
-    const float k_f = (float)p.kmer_size;
-    const float log_thr = p.log_threshold;
+    const float k_f = (float)ctx.kmer_size(p);
+    const float log_thr = ctx.log_threshold(p);
     // ---- score correction (:418-422), dense over N --------------------------------------
     // score[i] becomes the corrected score (-inf = "not an edge"); count[i] keeps the count
     // (and the ambiguous path's flag bit).
@@ -702,7 +706,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         const float r = __fmaf_rn(-q, k_f, x);
         return __fmaf_rn(r, inv_k, q);
     };
-    const bool fast_div = p.kmer_size <= 32u;
+    const bool fast_div = ctx.kmer_size(p) <= 32u;
     uint32_t touched = 0;
     float lane_best_f = -INFINITY;  // this lane's best score
     // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 16: cells behind N hold
@@ -760,7 +764,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     // with the relative terms in float32 (v_exp_f32): ~1e-7 relative on score_sum, i.e. on
     // every like_weight_ratio (bar: 1e-5).  Row scores and 10^ref_score stay in double, and
     // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
-    const uint32_t keep = p.keep_at_most;
+    const uint32_t keep = ctx.keep_at_most(p);
     auto *cand = reinterpret_cast<typename WaveLds<CountT>::u32x2_t *>(lds.desc);  // {ord(score), branch}
     constexpr uint32_t kCandCap = Ctx::kCandCap;  // top-k candidates the wave's descriptor list holds
     constexpr int kQ = (int)((kCandCap + kWave - 1) / kWave);  // ... per lane

@@ -80,6 +80,11 @@ struct TeamCtx {
     static constexpr bool kTeam = true;
     static constexpr uint32_t kCandCap = kTeamCandCap;  // top-k candidates of a slice: at most one per lane
     uint32_t rows_pad_, rows_, base_, slice_, pass_;
+    uint32_t kmer_size_, keep_;  // placer constants, in registers: the slice epilogue loads nothing from the argument block
+    float log_threshold_;
+    __device__ __forceinline__ uint32_t kmer_size(const PlaceParams &) const { return kmer_size_; }
+    __device__ __forceinline__ float log_threshold(const PlaceParams &) const { return log_threshold_; }
+    __device__ __forceinline__ uint32_t keep_at_most(const PlaceParams &) const { return keep_; }
     lds_u32x4 *cand;       // [keep_at_most] ranked rows of this slice for the merge
     lds_partial *partial;  // this slice's share of sum_scores
     template <typename Params>
@@ -111,11 +116,19 @@ typedef PackedLayout<kPlainTable> TeamChunks;  // the chunk format (and its load
 // place_epilogue: sum_scores (:164-184) from the slices' partial sums, like-weight-ratios
 // (:241-264), filter_by_ratio (:188-199), rows out.
 // ---------------------------------------------------------------------------------
-__device__ __attribute__((noinline)) void team_merge(const PlaceParams *__restrict__ kp, lds_u32x4 *cand,
-                                                     uint32_t cand_stride, lds_partial *partials, uint32_t n_slices,
-                                                     uint64_t read, uint64_t n_kmers)
+// the placer constants and output arrays of a launch, handed to team_merge in registers
+struct MergeParams {
+    uint32_t keep_at_most, kmer_size, num_branches;
+    float log_threshold;
+    double keep_factor;
+    epik_amd_placement *rows;
+    uint32_t *n_rows, *kmer_counts;
+};
+
+__device__ __attribute__((noinline)) void team_merge(MergeParams p, lds_u32x4 *cand, uint32_t cand_stride,
+                                                     lds_partial *partials, uint32_t n_slices, uint64_t read,
+                                                     uint64_t n_kmers)
 {
-    const PlaceParams &p = *kp;
     const int lane = lane_id();
     const uint32_t keep = p.keep_at_most;
     const uint32_t M = n_slices * keep;
@@ -314,10 +327,14 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
 #define TEAM_STAMP(k)
 #endif
 
+    // the bounds of a read are loaded one read ahead: they arrive under the read in front of them
+    uint64_t bounds[2] = {0, 0};
+    if (blockIdx.x < p.n_reads) bounds[0] = p.seq_offsets[blockIdx.x], bounds[1] = p.seq_offsets[blockIdx.x + 1];
     for (uint64_t read = blockIdx.x; read < p.n_reads; read += gridDim.x) {
-        const uint64_t seq_begin = readlane_u64(p.seq_offsets[read], 0);
-        const uint64_t len = readlane_u64(p.seq_offsets[read + 1], 0) - seq_begin;
+        const uint64_t seq_begin = readlane_u64(bounds[0], 0);
+        const uint64_t len = readlane_u64(bounds[1], 0) - seq_begin;
         const uint8_t *__restrict__ seq = p.seqs + seq_begin;
+        if (read + gridDim.x < p.n_reads) bounds[0] = p.seq_offsets[read + gridDim.x], bounds[1] = p.seq_offsets[read + gridDim.x + 1];
         // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than
         // this launch's counts hold is marked (the caller chose the count width).  Uniform over the
         // workgroup: nobody is left waiting at a barrier.
@@ -341,6 +358,9 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
         for (uint32_t pass = 0; pass < tp.passes; ++pass) {
             TeamCtx<W> ctx;
             ctx.rows_pad_ = rows_pad;
+            ctx.kmer_size_ = k;
+            ctx.keep_ = p.keep_at_most;
+            ctx.log_threshold_ = p.log_threshold;
             ctx.slice_ = wave;
             ctx.pass_ = pass;
             ctx.base_ = (pass * W + wave) * tp.slice_rows;
@@ -515,7 +535,18 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
         TEAM_STAMP(6)  // slice epilogue
         if (kMode != kTeamAccumulate) {
             __syncthreads();  // every slice's rows and sums are in LDS
-            if (wave == W - 1) team_merge(kp, merge_cand, merge_stride, partials, n_slices, read, n_kmers);
+            if (wave == W - 1) {
+                MergeParams mp;
+                mp.keep_at_most = p.keep_at_most;
+                mp.kmer_size = k;
+                mp.num_branches = p.num_branches;
+                mp.log_threshold = p.log_threshold;
+                mp.keep_factor = p.keep_factor;
+                mp.rows = p.rows;
+                mp.n_rows = p.n_rows;
+                mp.kmer_counts = p.kmer_counts;
+                team_merge(mp, merge_cand, merge_stride, partials, n_slices, read, n_kmers);
+            }
             TEAM_STAMP(7)  // waiting for the other slices' epilogues (+ the merge, in the last wave)
             // placing, the barriers of the next read's front end keep the other waves' next epilogue
             // off the merge area until the merge is done; finishing, there is no front end
