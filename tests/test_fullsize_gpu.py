@@ -1,6 +1,7 @@
-"""BASELINE configs[1] at its full size (N=999, k=10, 1 M x 150 bp reads, the bench.py workload):
-too many reads for the oracle, so the whole batch goes through size-independent properties and a
-random sample of it through the oracle, bit for bit."""
+"""BASELINE configs[1] at its full size (N=999, k=10, 1 M x 150 bp reads, the bench.py workload) and
+the configs[4] tree (N=9 999, the team kernel) on 300 k reads: too many reads for the oracle, so the
+whole batch goes through size-independent properties and a random sample of it through the oracle,
+bit for bit."""
 import numpy as np
 import pytest
 
@@ -8,14 +9,14 @@ from conftest import assert_rows_match
 from epik_amd import synth
 
 pytestmark = pytest.mark.gpu
-N_READS = 1_000_000
 
 
-@pytest.fixture(scope="module")
-def full_case(gpu_available):
+@pytest.fixture(scope="module", params=[(500, 1_000_000), (5000, 300_000)], ids=["n999", "n9999"])
+def full_case(gpu_available, request):
     assert gpu_available, "pytest -m gpu needs a HIP device (no CPU fallback exists)"
     from epik_amd.placer import Placer
-    tree = synth.make_tree(500, seed=42)
+    leaves, N_READS = request.param
+    tree = synth.make_tree(leaves, seed=42)
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
     data, offs = synth.make_reads(N_READS, 150, seed=44)
     with Placer.from_synth(db) as pl:
@@ -56,7 +57,7 @@ def test_idempotent_and_order_independent(full_case):
 
 def test_random_sample_matches_the_oracle(full_case, oracle_lib):
     db, data, offs, (rows, n_rows, counts), *_ = full_case
-    pick = np.sort(np.random.default_rng(9).choice(N_READS, size=4000, replace=False))
+    pick = np.sort(np.random.default_rng(9).choice(len(n_rows), size=4000, replace=False))
     sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
     ref = oracle_lib.Oracle.from_synth(db).place(sample, sample_offs, num_threads=0)
     assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
