@@ -7,6 +7,7 @@
 #ifndef EPIK_AMD_PLACE_DEVICE_HPP
 #define EPIK_AMD_PLACE_DEVICE_HPP
 #include <hip/hip_runtime.h>
+#include <float.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -731,7 +732,9 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             const uint32_t c = cnt[u] & ~lds.kSeen;
             pre[u] = __fadd_rn(raw[u], __fmul_rn((float)(nk_u - c), log_thr));  // :420
             s[u] = div_k(pre[u]);                                               // :421
-            smallest = fminf(smallest, c ? fabsf(pre[u]) : INFINITY);
+            // (rows without a k-mer take part too: theirs is nk * log_thr, tiny only if log_thr is 0 --
+            // then the exact division below runs, which is as right and only slower)
+            smallest = fminf(smallest, fabsf(pre[u]));
         }
         if (!fast_div || __ballot(smallest < 0x1p-100f) != 0) {  // wave-uniform, practically never
 #pragma unroll
@@ -799,7 +802,8 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     const bool relative_sum = ref_score > -280.0f;  // wave-uniform
     if (touched != 0) {
         n_cand = 0;
-        const float tau_f = tau <= 1u ? -INFINITY : unord_f32(tau);
+        // every edge's score is finite, every other row holds -inf: one comparison tells a candidate
+        const float tau_f = tau <= 1u ? -FLT_MAX : unord_f32(tau);
         auto scan_rows = [&](auto whole, uint32_t base) {
             constexpr bool kWhole = decltype(whole)::value;  // as in the correction sweep
             constexpr int kRows = kUnroll;
@@ -809,11 +813,10 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;
-                const float sc = row[u];             // -inf where there is no edge (a sum of finite
-                const bool edge = sc != -INFINITY;   // log10 scores never is)
+                const float sc = row[u];  // -inf where there is no edge (a sum of finite log10 scores never is)
                 // exp2(-inf) = 0: rows without an edge add nothing
                 rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
-                const bool is_cand = edge && sc >= tau_f;
+                const bool is_cand = sc >= tau_f;
                 const uint64_t m = __ballot(is_cand);
                 if (m) {
                     const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
