@@ -118,14 +118,14 @@ def cpu_baseline(db, data, offs, target_seconds: float):
     """Times the oracle (kind "port") on a bounded prefix of the same read batch, the way the
     reference's driver runs placer::place (BASELINE.md 3): batches of 2000 reads, per-batch dedup,
     OpenMP dynamic loop; lookup through a node-chained hash map (the reference's data structure
-    shape) and, beside it, through the direct index.  Median of three runs each."""
+    shape) and, beside it, through the direct index.  Median of five runs each."""
     from oracle import oracle
     oracle.build()
     orc = oracle.Oracle.from_synth(db)
     threads = min(host_cores(), oracle.Oracle.max_threads())
     n_total = len(offs) - 1
 
-    def timed(n, n_threads, runs=3):
+    def timed(n, n_threads, runs=5):
         times = []
         for _ in range(runs):
             t0 = time.perf_counter()
@@ -135,7 +135,7 @@ def cpu_baseline(db, data, offs, target_seconds: float):
 
     out = {}
     for label, n_threads, share in (("all", threads, 0.65), ("one", 1, 0.35)):
-        per_variant = target_seconds * share / 2 / 3  # two variants, three runs each
+        per_variant = target_seconds * share / 2 / 5  # two variants, five runs each
         variants = {}
         for name, use_hash in (("hash_map", True), ("direct_index", False)):
             orc.use_hash_map(use_hash)
@@ -146,7 +146,7 @@ def cpu_baseline(db, data, offs, target_seconds: float):
         out[label] = {
             "value": variants["hash_map"]["reads_per_s"], "unit": "reads/s", "cores": n_threads, "kind": "port",
             "variants": {k: v["reads_per_s"] for k, v in variants.items()},
-            "sample": f"{variants['hash_map']['reads']} reads of the step batch, median of 3 runs, "
+            "sample": f"{variants['hash_map']['reads']} reads of the step batch, median of 5 runs, "
                       "oracle/epik_oracle.c run as the reference's driver runs placer::place: batches of 2000 reads, "
                       "per-batch dedup, OpenMP dynamic loop (place.cpp:201-275); `value` = the hash-map lookup variant "
                       "(node-chained map key -> vector of postings), `variants.direct_index` = CSR lookup"}

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r02_* and
+rewrites profiles/traffic.json from the PMC summaries, stamped with the hash of the kernel sources in
+the tree (run it on the same sources the GPU run used).
+
+    python tools/collect_profiles.py r02_c
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from epik_amd import provenance  # noqa: E402
+
+FILES = {
+    "bench.json": "r02_bench.json",
+    "bench_headline.json": "r02_bench_headline_trace_run.json",
+    "bench_k11.json": "r02_bench_k11.json",
+    "bench_n9999.json": "r02_bench_n9999_team.json",
+    "bench_amino_k7.json": "r02_bench_amino_k7.json",
+    "bench_kmer_shard_n9999.json": "r02_bench_kmer_shard_n9999_1gpu.json",
+    "kernel_stats_headline.csv": "r02_kernel_stats.csv",
+    "kernel_stats_k11.csv": "r02_kernel_stats_k11.csv",
+    "kernel_stats_n9999.csv": "r02_kernel_stats_n9999_team.csv",
+    "kernel_stats_amino_k7.csv": "r02_kernel_stats_amino_k7.csv",
+    "pmc_summary_headline.txt": "r02_pmc_summary.txt",
+    "pmc_summary_k11.txt": "r02_pmc_summary_k11.txt",
+    "pmc_summary_n9999.txt": "r02_pmc_summary_n9999_team.txt",
+    "sq_counters_headline.txt": "r02_sq_counters.txt",
+    "sq_counters_n9999_team.txt": "r02_sq_counters_n9999_team.txt",
+}
+
+
+def counters(path, kernel):
+    out = {}
+    for line in open(path):
+        parts = line.split()
+        if len(parts) >= 4 and parts[0] == "bench" and parts[1] == kernel:
+            out[parts[2]] = float(parts[3].split("=")[1])
+    return out
+
+
+def main():
+    tag = sys.argv[1]
+    src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+    for a, b in FILES.items():
+        path = os.path.join(src, a)
+        if not os.path.exists(path):
+            print("missing", a)
+            continue
+        text = open(path).read()
+        if a.endswith(".json"):
+            text = text.strip().splitlines()[-1] + "\n"
+        open(os.path.join(dst, b), "w").write(text)
+    head = json.loads(open(os.path.join(dst, "r02_bench.json")).read())
+    old = json.load(open(os.path.join(dst, "traffic.json")))
+    c = counters(os.path.join(src, "pmc_summary_headline.txt"), "place_reads_kernel")
+    doc = {
+        "workload": head["config"]["workload"],
+        "kernel": "place_reads_kernel<PackedLayout<1>, uint16_t> (paired lookup table, range-checked buffer loads, "
+                  "16-bit counts: the default for DNA)",
+        "hbm_bytes_per_launch": c["TCC_EA0_RDREQ_128B_sum"] * 128.0,
+        "kernel_source_sha": provenance.kernel_source_hash(),
+        "commit": subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip(),
+        "method": (f"rocprofv3 --pmc in separate passes (tools/pmc_passes.sh via tools/profile_round.sh {tag}): "
+                   f"TCC_EA0_RDREQ_128B_sum = {c['TCC_EA0_RDREQ_128B_sum']:.6g} requests x 128 B per launch (every request is "
+                   f"a 128-B line: 32B = {c['TCC_EA0_RDREQ_32B_sum']:.0f}, 64B = {c['TCC_EA0_RDREQ_64B_sum']:.0f}); cross-check "
+                   f"FETCH_SIZE = {c['FETCH_SIZE']:.6g} KiB, which on gfx950 counts 128-B requests as 64 B "
+                   f"(MI355X_MICROARCH.md, HBM section) -> x2 x 1024 = {c['FETCH_SIZE'] * 2048:.4g} B; calibration streams of "
+                   "tools/calib_fetch.hip in the same summary file"),
+        "l2_hit_rate": c["TCC_HIT_sum"] / c["TCC_REQ_sum"],
+        "source": "profiles/r02_pmc_summary.txt",
+        "note": "bench.py reports this number only while kernel_source_sha equals the hash of the kernel sources it "
+                "runs (epik_amd/provenance.py)",
+        "other_workloads_same_sources": {},
+        "previous": old.get("previous", {}),
+    }
+    for name, kern, f, out in (("k=11 database (1.13 GB on the device)", "place_reads_kernel", "pmc_summary_k11.txt",
+                                "r02_pmc_summary_k11.txt"),
+                               ("N=9999 tree, team kernel", "team_place_kernel", "pmc_summary_n9999.txt",
+                                "r02_pmc_summary_n9999_team.txt")):
+        cc = counters(os.path.join(src, f), kern)
+        doc["other_workloads_same_sources"][name] = {"hbm_bytes_per_launch": cc["TCC_EA0_RDREQ_128B_sum"] * 128.0,
+                                                      "l2_hit_rate": cc["TCC_HIT_sum"] / cc["TCC_REQ_sum"],
+                                                      "source": "profiles/" + out}
+    json.dump(doc, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print("traffic:", doc["hbm_bytes_per_launch"], "sha", doc["kernel_source_sha"])
+
+
+if __name__ == "__main__":
+    main()
