@@ -71,18 +71,16 @@ constexpr int team_entry_bytes(int waves) { return waves <= 6 ? 16 : waves <= 14
 constexpr uint32_t team_rows_pad(uint32_t slice_rows) { return (slice_rows + 1u + 15u) & ~15u; }
 constexpr uint32_t team_slice_bytes(uint32_t rows_pad, int counts) { return (rows_pad * (4u + (1u << counts)) + 15u) & ~15u; }
 // a slice's descriptor list (one round + one trip of spare entries) also holds its top-k candidates
-// and, with one pass, its ranked rows for the merge (keep_at_most entries of 16 bytes)
-constexpr uint32_t team_desc_bytes(uint32_t keep)
+constexpr uint32_t team_desc_bytes(uint32_t /*keep*/)
 {
-    const uint32_t list = (kTeamDescCap + kTeamRing) * 8u, rows = keep * 16u;
     static_assert((kTeamCandCap + 4u) * 8u <= (kTeamDescCap + kTeamRing) * 8u, "the candidates live in the descriptor list");
-    return ((list > rows ? list : rows) + 15u) & ~15u;
+    return ((kTeamDescCap + kTeamRing) * 8u + 15u) & ~15u;
 }
-// LDS bytes of a workgroup: slices, descriptor lists, tile totals + flags, partial sums, (P > 1) ranked rows
+// LDS bytes of a workgroup: slices, descriptor lists, tile totals + flags, partial sums, the slices' ranked rows
 constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes, uint32_t desc_bytes, uint32_t keep)
 {
     return (size_t)waves * slice_bytes + (size_t)waves * desc_bytes + ((size_t)waves * waves + 4) * 4 +
-           (size_t)waves * passes * 24 + (passes > 1 ? (size_t)waves * passes * keep * 16 : 0);
+           (size_t)waves * passes * 24 + (size_t)waves * passes * keep * 16;
 }
 constexpr uint32_t team_resident_blocks(int waves, size_t lds_bytes)
 {

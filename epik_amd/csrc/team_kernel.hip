@@ -7,7 +7,7 @@
 // N ~ 10 000 branches three waves fit a CU, and beyond ~20 000 none does.  Here the W waves of a
 // workgroup place ONE read together: wave w owns the rows of slice w of the branch range, and the
 // database is stored pre-split the same way -- every posting list as W sublists, one per slice,
-// in the list's original order (create(), capi.hip).  A branch still receives its float32 adds in
+// in the list's original order (db_image.cpp).  A branch still receives its float32 adds in
 // exactly the k-mer order of place.cpp:349-371, because every wave walks the read's k-mers in
 // order and the postings of one list are distinct branches: bit-identical sums, as before.
 // Trees too large even for that are placed in P passes over S = W * P slices (pass p = slices
@@ -23,7 +23,9 @@
 //               together, sum_scores, like-weight-ratios, filter, rows out -- while the other
 //               waves already encode the next read.
 //
-// HBM-bandwidth bound gather / scatter-add; no MFMA.
+// Gather / scatter-add, no MFMA.  Unlike the one-wavefront kernel this one is not bound by bandwidth but by
+// the time a workgroup takes per read (LDS leaves room for three reads per CU at N = 9 999) and by vector
+// instruction issue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -135,8 +137,23 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, lds_u32x4 *c
     const float k_f = (float)p.kmer_size;
     const float thr_score = __fdiv_rn(__fmul_rn((float)n_kmers, p.log_threshold), k_f);  // :175 / :146-147
     constexpr float kLog2Of10 = 3.32192809488736f;
+    // the slices' partial sums, one slice per lane (their LDS reads go out together; read one after the
+    // other they were a chain of round trips on the path of the next read's first barrier)
+    uint32_t my_touched = 0, my_relative = 0;
+    float my_ref = 0.0f;
+    double my_sum = 0.0;
+    const bool sums_in_lanes = n_slices <= (uint32_t)kWave;  // wave-uniform; else looped over below
+    if (sums_in_lanes && (uint32_t)lane < n_slices) {
+        my_touched = partials[lane].touched;
+        my_relative = partials[lane].relative;
+        my_ref = partials[lane].ref_score;
+        my_sum = partials[lane].sum;
+    }
     uint32_t touched = 0;
-    for (uint32_t s = 0; s < n_slices; ++s) touched += partials[s].touched;
+    if (sums_in_lanes)
+        touched = wave_sum_u32(my_touched);
+    else
+        for (uint32_t s = 0; s < n_slices; ++s) touched += partials[s].touched;
     uint32_t n_sel;
     float best_score;
     // Up to 64 slots (4 or 8 slices of the default 7 rows): one slot per lane, everything in registers.
@@ -199,13 +216,20 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, lds_u32x4 *c
     double score_sum;
     {
         double rel = 0.0, absolute = 0.0;
-        for (uint32_t s = 0; s < n_slices; ++s) {
-            if (partials[s].touched == 0) continue;
-            const double sum = partials[s].sum;
-            if (partials[s].relative)
-                rel += sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(partials[s].ref_score, ref_score), kLog2Of10));
-            else
-                absolute += sum;
+        if (sums_in_lanes) {
+            const bool counts = my_touched != 0;
+            const double scaled = my_sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(my_ref, ref_score), kLog2Of10));
+            rel = wave_sum_f64(counts && my_relative ? scaled : 0.0);
+            absolute = wave_sum_f64(counts && !my_relative ? my_sum : 0.0);
+        } else {
+            for (uint32_t s = 0; s < n_slices; ++s) {
+                if (partials[s].touched == 0) continue;
+                const double sum = partials[s].sum;
+                if (partials[s].relative)
+                    rel += sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(partials[s].ref_score, ref_score), kLog2Of10));
+                else
+                    absolute += sum;
+            }
         }
         const float not_placed = (float)p.num_branches - (float)touched;  // :174
         if (ref_score > -280.0f) {
@@ -292,21 +316,21 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
     lds_u32 *flags = totals + W * W;                                                                      // [2]: any ambiguous k-mer, alternating over the workgroup's reads
     lds_partial *partials = (lds_partial *)reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4);
     const uint32_t n_slices = W * tp.passes;
-    lds_u32x4 *merge_cand;
-    uint32_t merge_stride;  // in entries of 16 bytes, from one slice's rows to the next
-    if (tp.passes == 1) {
-        merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(desc_base);
-        merge_stride = tp.desc_bytes / 16u;
-    } else {
-        merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4) + n_slices);
-        merge_stride = p.keep_at_most;
-    }
+    // the slices' ranked rows for the merge: an area of their own (not the idle descriptor lists: the tile
+    // waves fill those for the next read while the last wave still merges this one)
+    lds_u32x4 *merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4) + n_slices);
+    const uint32_t merge_stride = p.keep_at_most;  // in entries of 16 bytes, from one slice's rows to the next
+    lds_u32 *tiles_done = flags + 2;  // how many tiles of this workgroup have published their totals so far
+    uint32_t tiles_expected = 0;      // ... and how many must have before this group's descriptors can be laid out
     const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
     const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
                                                               (rows_pad - 1u) * (uint32_t)sizeof(CountT));
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // = &tp.base
     for (uint32_t i = lane; i < rows_pad; i += kWave) lds.store(i, 0u, 0u);
-    if (threadIdx.x < 2) flags[threadIdx.x] = 0u;
+    // (no list entry is ever read before it was written; should that ever break, an entry is at least a chunk
+    // of zero bytes at a valid address and not what the LDS happened to hold)
+    for (uint32_t i = lane; i < tp.desc_bytes / 8u; i += kWave) lds.desc[i] = null_chunk(p);
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;  // the two flags, the tile counter, a spare
     __syncthreads();
 
     const uint32_t k = p.kmer_size;
@@ -430,11 +454,26 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                         uint32_t mine = tile_total[0];
 #pragma unroll
                         for (int s = 1; s < W; ++s) mine = (lane == s) ? tile_total[s] : mine;
-                        if (lane < W) totals[wave * W + (uint32_t)lane] = mine;
+                        if (has_tile && lane < W) totals[wave * W + (uint32_t)lane] = mine;
                     }
-                    __syncthreads();
+                    uint32_t n_tiles;  // tiles of this group: the rows of the table that were published for it
+                    // Not a barrier: only the waves that HAVE a tile publish, and nobody waits for one that has
+                    // none -- the last wave, still merging the previous read while the others encode this one,
+                    // finds the counter already there when it arrives.  (Every wave counts the same tiles: the
+                    // counter only grows, and the two real barriers of the round keep a fast wave from
+                    // publishing the next group before everybody has read this one's totals.)
+                    {
+                        const uint64_t tiles_left = (n_kmers - group_pos + stride - 1) / stride;
+                        n_tiles = tiles_left < (uint64_t)W ? (uint32_t)tiles_left : (uint32_t)W;
+                        tiles_expected += n_tiles;
+                        if (has_tile && lane == 0)
+                            __hip_atomic_fetch_add((uint32_t *)tiles_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while ((int32_t)(__hip_atomic_load((uint32_t *)tiles_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                                         tiles_expected) < 0)
+                            __builtin_amdgcn_s_sleep(1);
+                    }
                     TEAM_STAMP(1)  // waiting for the other tiles
-                    any_amb = any_amb || flags[parity] != 0u;  // set before the barrier; cleared two barriers later at the earliest
+                    any_amb = any_amb || flags[parity] != 0u;  // set before the publication; cleared two barriers later at the earliest
                     uint32_t base[W];       // chunks of the earlier tiles of this group, per slice
                     uint32_t my_total = 0;  // chunks of this wave's slice in the group
                     uint32_t max_total = 0;
@@ -450,7 +489,8 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                             base[s] = 0;
 #pragma unroll
                             for (int t = 0; t < W; ++t) {
-                                const uint32_t v = __builtin_amdgcn_readlane(held[(t * W + s) / kWave], (t * W + s) % kWave);
+                                // (a wave without a tile published nothing: its row is whatever an earlier group left)
+                                const uint32_t v = (uint32_t)t < n_tiles ? __builtin_amdgcn_readlane(held[(t * W + s) / kWave], (t * W + s) % kWave) : 0u;
                                 base[s] += (uint32_t)t < wave ? v : 0u;
                                 sum += v;
                             }
@@ -531,6 +571,11 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                 if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
                 place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
             }
+            // A wave's descriptor list is its scratch in the ambiguous sweep and the epilogue (seen bits,
+            // top-k candidates), and the tile waves of the next pass / read write into every list as soon as
+            // THEY have met: nobody may start that before everybody is through here.  Placing, the barrier
+            // in front of the merge below does it after the last pass.
+            if (kMode == kTeamAccumulate || pass + 1 < tp.passes) __syncthreads();
         }
         TEAM_STAMP(6)  // slice epilogue
         if (kMode != kTeamAccumulate) {
