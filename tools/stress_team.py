@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Race hunt for the team kernel (developer tool): a million reads -- a third of them with ambiguous or
+invalid characters, lengths from below k to several tile groups -- placed by the team kernel and by the
+one-wavefront kernel on the same device; every row must agree bit for bit (like-weight-ratios to 2e-6: the
+slices add up sum_scores in another order),
+run after run.  Also the accumulate + finish halves against the one-pass placement.
+
+    python tools/stress_team.py [leaves] [reads] [repeats]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    torch.cuda.is_available()
+    from epik_amd import alphabet, dist as edist, synth
+    from epik_amd.placer import Placer
+    leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+    repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    tree = synth.make_tree(leaves, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=9, seed=43, lognormal=(3.3, 1.6))
+    rng = np.random.default_rng(7)
+    lengths = rng.integers(5, 420, size=n)
+    offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    data = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(offs[-1]), dtype=np.uint8)]
+    dirty = rng.choice(int(offs[-1]), size=int(offs[-1]) // 400, replace=False)
+    data[dirty] = np.frombuffer(b"NRYKM-*", dtype=np.uint8)[rng.integers(0, 7, size=len(dirty))]
+
+    def place(kernel):
+        os.environ["EPIK_AMD_KERNEL"] = kernel
+        with Placer.from_synth(db) as pl:
+            return [pl.place_packed(data, offs) for _ in range(repeats)], pl.launch_info()
+
+    ref, info = place("wave")
+    print("wave  :", info, flush=True)
+    for kernel in ("team4", "team8", "team4x2"):
+        got, info = place(kernel)
+        print(f"{kernel:6s}:", info, flush=True)
+        for run, (rows, n_rows, counts) in enumerate(got):
+            assert np.array_equal(n_rows, ref[0][1]), (kernel, run, "row counts")
+            valid = np.arange(rows.shape[1])[None, :] < n_rows[:, None]
+            for field in ("branch", "score"):
+                a, b = rows[field][valid], ref[0][0][field][valid]
+                assert a.tobytes() == b.tobytes(), (kernel, run, field, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+            assert np.array_equal(counts[valid], ref[0][2][valid]), (kernel, run, "counts")
+            assert np.abs(rows["lwr"][valid] - ref[0][0]["lwr"][valid]).max() <= 2e-6, (kernel, run, "lwr")
+    print(f"one-pass: {n} reads x {repeats} runs x 3 team geometries agree with the one-wavefront kernel", flush=True)
+
+    m = min(n, 200_000)
+    sub_offs = offs[:m + 1]
+    sub = data[:int(sub_offs[-1])]
+    dev = torch.device("cuda", 0)
+    os.environ["EPIK_AMD_KERNEL"] = "team4"
+    with Placer.from_synth(db) as pl:
+        one_pass = pl.place_packed(sub, sub_offs)
+        slot, per = edist.amb_slots(sub, sub_offs, alphabet.char_class_table(db.states), 1)
+        for run in range(repeats):
+            accumulate, finish = edist.kmer_sharded_gpu_fns(pl, sub, sub_offs, dev)
+            got = edist.place_kmer_sharded(accumulate, finish, m, None, amb_slot=slot, amb_per_owner=per)
+            for a, b in zip(got, one_pass):
+                assert a.tobytes() == b.tobytes(), ("accumulate+finish", run)
+    print(f"accumulate + finish: {m} reads x {repeats} runs agree with the one-pass placement", flush=True)
+
+
+if __name__ == "__main__":
+    main()
