@@ -198,3 +198,14 @@ def test_legacy_differ_agrees_with_the_reference_script(tmp_path, capsys):
         matched = int(out.strip().splitlines()[-1].split("/")[0])
         ours = jplace_diff.diff_legacy(jplace.read_jplace(a), jplace.read_jplace(b), only_best)
         assert matched == len(names) - len(ours), (only_best, matched, ours)
+
+
+def test_legacy_differ_matches_the_reference_verdicts_on_record():
+    """The same comparison against verdicts the reference's function gave in the build container
+    (tests/golden/make_jplace_diff_golden.py): this one runs wherever the reference is absent too."""
+    with open(os.path.join(ROOT, "tests", "golden", "jplace_diff_reference.json")) as fh:
+        golden = json.load(fh)
+    assert len(golden["cases"]) == 8
+    for case in golden["cases"]:
+        ours = jplace_diff.diff_legacy(case["first"], case["second"], case["only_best"])
+        assert case["names"] - len(ours) == case["reference_matched"], (case["seed"], case["only_best"], ours)
