@@ -376,10 +376,10 @@ def main():
         big_plan = eplacer.plan(big)
         with Placer.from_synth(big, device=local_rank) as big_placer:
             big_placer.choose_counts(args.read_length)
-            _, big_ms = timed_steps(make_step(big_placer), 3, 1)
+            _, big_ms = timed_steps(make_step(big_placer), 6, 2)
             roof = roofline_of(big_placer, big_plan, big_ms, "")
         roof["workload"] = (f"nucl k=11, N={tree.num_nodes}, {big.num_entries} postings, the same "
-                            f"{n} x {args.read_length} bp reads; 3 steps after 1 warm-up")
+                            f"{n} x {args.read_length} bp reads; 6 steps after 2 warm-ups")
         roof["reads_per_s"] = n / (big_ms * 1e-3)
         result["roofline_hbm_resident"] = roof
         del big
