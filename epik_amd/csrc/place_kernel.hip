@@ -336,11 +336,14 @@ hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts,
     });
 }
 
-hipError_t set_place_reads_lds_limit(DbLayout layout, int counts, size_t lds_bytes)
+// The attribute is a cap per kernel and process, not a reservation (what a launch occupies is what it
+// asks for): it is always raised to the whole LDS of a CU, so that placers of different trees alive in
+// one process can never lower it under each other's launches.
+hipError_t set_place_reads_lds_limit(DbLayout layout, int counts, size_t /*lds_bytes*/)
 {
     return dispatch(layout, counts, [&]<typename L, typename C>() {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<L, C>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     });
 }
 
@@ -362,11 +365,11 @@ hipError_t launch_finish_reads(const PlaceParams &p, int counts, dim3 grid, dim3
     });
 }
 
-hipError_t set_finish_reads_lds_limit(int counts, size_t lds_bytes)
+hipError_t set_finish_reads_lds_limit(int counts, size_t /*lds_bytes*/)
 {
     return dispatch_counts<PackedLayout<kPlainTable>>(counts, [&]<typename L, typename C>() {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&finish_reads_kernel<C>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     });
 }
 

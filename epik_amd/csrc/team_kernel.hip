@@ -650,13 +650,13 @@ hipError_t launch_team(const TeamParams &tp, int waves, int counts, int mode, di
     });
 }
 
-hipError_t set_team_lds_limit(int waves, int counts, size_t lds_bytes)
+hipError_t set_team_lds_limit(int waves, int counts, size_t /*lds_bytes*/)  // (always the whole CU: see place_kernel.hip)
 {
     hipError_t err = hipSuccess;
     for (int mode = 0; mode < 3 && err == hipSuccess; ++mode)
         err = team_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_place_kernel<W, C, M>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
         });
     return err;
 }

@@ -84,3 +84,27 @@ def test_n9999_long_reads_leave_the_8_bit_counts(large_tree, oracle_lib, kernel,
     with Placer.from_synth(db) as pl:
         got = pl.place_packed(data, offs)
     assert_rows_match(*got, *ref)
+
+
+@pytest.mark.parametrize("kernel", ["wave", "team4"])
+def test_placers_of_different_trees_share_a_process(large_tree, small_case, oracle_lib, kernel, monkeypatch):
+    """The dynamic-LDS cap of a kernel is per process: creating a placer for a small tree must not
+    lower it under the launches of a live placer for a large one (more than 64 KB per workgroup here)."""
+    from epik_amd.placer import Placer
+    monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+    monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", "1")   # 32-bit counts: 82 KB of LDS per workgroup
+    _, big = large_tree
+    _, small = small_case
+    rng = np.random.default_rng(51)
+    data, offs = synth.pack_reads(mixed_reads(rng, 400, big.kmer_size, max_len=151))
+    sdata, soffs = synth.pack_reads(mixed_reads(rng, 400, small.kmer_size, max_len=100))
+    with Placer.from_synth(big) as first:
+        before = first.place_packed(data, offs)
+        assert first.launch_info()["lds_bytes_per_block"] > 64 << 10
+        with Placer.from_synth(small) as second:
+            assert_rows_match(*second.place_packed(sdata, soffs),
+                              *oracle_lib.Oracle.from_synth(small).place(sdata, soffs, num_threads=0))
+            after = first.place_packed(data, offs)
+    for a, b in zip(before, after):
+        assert a.tobytes() == b.tobytes()
+    assert_rows_match(*after, *oracle_lib.Oracle.from_synth(big).place(data, offs, num_threads=0))
