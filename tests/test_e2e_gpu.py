@@ -75,3 +75,38 @@ def test_epik_py_place_matches_oracle(tmp_path, oracle_lib, devices):
             assert x["distal_length"] == pytest.approx(y["distal_length"], rel=1e-9)
             assert x["pendant_length"] == pytest.approx(y["pendant_length"], rel=1e-9)
     assert got["short"] == []
+
+
+def test_epik_aa_places_proteins(tmp_path, oracle_lib):
+    """The protein driver (`epik.py place -s amino` -> epik-aa, epik/CMakeLists.txt:124): 20-state
+    encoder, ambiguous residues B / Z / X, against the oracle's jplace."""
+    from epik_amd import alphabet
+    subprocess.run(["make", "-C", os.path.join(ROOT, "epik_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    tree = synth.make_tree(40, seed=13)
+    db = synth.make_db(tree.num_nodes, states="amino", kmer_size=4, seed=14, p_present=0.3, lognormal=(1.5, 1.0))
+    db_path = str(tmp_path / "db.ekdb")
+    dbfile.write_db(db_path, db, tree.newick())
+    rng = np.random.default_rng(6)
+    records = []
+    for i in range(3000):
+        alpha = alphabet.AMINO_STATES if i % 4 else alphabet.AMINO_STATES + "BZX*"
+        records.append((f"prot_{i}", "".join(rng.choice(list(alpha), size=int(rng.integers(3, 320))))))
+    fasta = str(tmp_path / "p.fasta")
+    with open(fasta, "w") as fh:
+        for h, s in records:
+            fh.write(f">{h}\n{s}\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "epik.py"), "place", "-i", db_path, "-s", "amino",
+                          "-o", str(out_dir), fasta], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "Placed 3000 sequences." in run.stdout and "Sequence type: Proteins" in run.stdout
+    ref_path = str(tmp_path / "ref.jplace")
+    _oracle_jplace(ref_path, oracle_lib, db, tree, records)
+    got, ref = jplace.read_jplace(str(out_dir / "placements_p.fasta.jplace")), jplace.read_jplace(ref_path)
+    assert set(got) == set(ref) == {h for h, _ in records}
+    assert jplace_diff.diff_strict(got, ref) == []
+    # the DNA driver refuses a protein database (the two binaries differ as the reference's do)
+    wrong = subprocess.run([os.path.join(ROOT, "epik_amd", "bin", "epik-dna"), "-d", db_path, "-q", fasta, "-o",
+                            str(out_dir)], capture_output=True, text=True, timeout=600)
+    assert wrong.returncode == 255 and "Proteins" in wrong.stderr
