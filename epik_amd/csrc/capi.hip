@@ -175,7 +175,16 @@ namespace {
 // builder -- after an error it keeps handing out staging memory and finish() reports the error.
 class DeviceSink final : public epik_amd::image::Sink {
 public:
-    static constexpr size_t kStage = 16u << 20;
+    // staging buffer size; EPIK_AMD_STAGE_BYTES (>= 4096) shrinks it so that tests reach the
+    // buffer switches and the larger-than-a-buffer path with small databases
+    static constexpr size_t kStageMax = 16u << 20;
+    DeviceSink()
+    {
+        if (const char *e = std::getenv("EPIK_AMD_STAGE_BYTES")) {
+            const unsigned long long v = std::strtoull(e, nullptr, 10);
+            if (v >= 4096 && v <= kStageMax) _stage_bytes = static_cast<size_t>(v);
+        }
+    }
     ~DeviceSink() override
     {
         for (int i = 0; i < 2; ++i) {
@@ -189,7 +198,7 @@ public:
         _total = total;
         _stream = stream;
         for (int i = 0; i < 2; ++i) {
-            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&_stage[i]), kStage, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&_stage[i]), _stage_bytes, hipHostMallocDefault);
             if (e != hipSuccess) return e;
             e = hipEventCreateWithFlags(&_event[i], hipEventDisableTiming);
             if (e != hipSuccess) return e;
@@ -198,11 +207,13 @@ public:
     }
     uint8_t *reserve(size_t n) override
     {
-        if (n > kStage) {  // no part of the image is written in pieces this large
-            _overflow = true;
-            n = kStage;
+        flush_large();
+        if (n > _stage_bytes) {  // a single posting list of millions of branches: through a buffer of its own,
+            flush();       // copied synchronously when the next piece is asked for
+            _large.assign(n, 0);  // (may throw std::bad_alloc: create() catches at the boundary)
+            return _large.data();
         }
-        if (_fill + n > kStage) flush();
+        if (_fill + n > _stage_bytes) flush();
         uint8_t *p = _stage[_cur] + _fill;
         std::memset(p, 0, n);
         _fill += n;
@@ -211,6 +222,7 @@ public:
     // everything reserved so far is on its way; returns the first error, checks the size
     hipError_t finish(bool *size_ok)
     {
+        flush_large();
         flush();
         const hipError_t e = hipStreamSynchronize(_stream);
         if (_error == hipSuccess) _error = e;
@@ -219,6 +231,19 @@ public:
     }
 
 private:
+    void flush_large()
+    {
+        if (_large.empty()) return;
+        if (_done + _large.size() > _total) {
+            _overflow = true;
+        } else if (_error == hipSuccess) {
+            _error = hipStreamSynchronize(_stream);  // keep the order of the bytes: everything before it has left
+            if (_error == hipSuccess)
+                _error = hipMemcpy(_base + _done, _large.data(), _large.size(), hipMemcpyHostToDevice);
+        }
+        _done += _large.size();
+        std::vector<uint8_t>().swap(_large);
+    }
     void flush()
     {
         if (_fill == 0) return;
@@ -234,6 +259,8 @@ private:
         _cur ^= 1;
         if (_used[_cur] && _error == hipSuccess) _error = hipEventSynchronize(_event[_cur]);  // its last copy has left
     }
+    size_t _stage_bytes = kStageMax;
+    std::vector<uint8_t> _large;  // a piece larger than a staging buffer, waiting to be copied
     uint8_t *_base = nullptr, *_stage[2] = {nullptr, nullptr};
     hipEvent_t _event[2] = {nullptr, nullptr};
     bool _used[2] = {false, false};

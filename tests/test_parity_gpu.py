@@ -69,6 +69,19 @@ def test_host_buffer_pipeline_chunks(placer_cls, oracle_lib, small_case, chunks,
     _compare(placer_cls, oracle_lib, db, data, offs)
 
 
+def test_create_through_small_staging_buffers(placer_cls, oracle_lib, monkeypatch):
+    """`create()` streams the image through two pinned staging buffers (16 MB each); with 4 KB ones a
+    small database crosses hundreds of buffer switches, and every list longer than a buffer (here:
+    of more than ~680 postings) takes the path of a single posting list of millions of branches."""
+    monkeypatch.setenv("EPIK_AMD_STAGE_BYTES", "4096")
+    tree = synth.make_tree(600, seed=3)
+    db = synth.make_db(tree.num_nodes, kmer_size=5, p_present=0.8, seed=8, lognormal=(5.5, 1.5))
+    assert int(np.diff(db.offsets).max()) > 800
+    rng = np.random.default_rng(12)
+    data, offs = synth.pack_reads(mixed_reads(rng, 1500, db.kmer_size, max_len=200))
+    _compare(placer_cls, oracle_lib, db, data, offs)
+
+
 def test_golden_fixture(placer_cls):
     """Committed vectors (tests/golden/make_golden.py)."""
     with open(os.path.join(GOLDEN, "synth_k6.json")) as fh:
