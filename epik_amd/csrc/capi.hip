@@ -44,6 +44,7 @@ int fail_hip(hipError_t e, const char *what)
     } while (0)
 
 constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // gfx950: 160 KiB per CU
+[[maybe_unused]] constexpr size_t kDbgWords = 64 + 4096 * 64;        // diagnostic builds: phase sums + a row of 8 per wave of 4096 workgroups
 
 }  // namespace
 
@@ -64,6 +65,20 @@ struct epik_amd_placer {
     int team_waves = 0;
     const uint8_t *team_table = nullptr;
     uint32_t team_passes = 0, team_slice_rows = 0, team_rows_pad = 0;
+    // the team placement as front kernel + streaming kernel (team_stream.hip); the scratch of a launch,
+    // grown on demand: a header per read, the reads left to team_place_kernel, the descriptor pool
+    bool team_front = false;
+    uint8_t *d_front_hdr = nullptr;
+    size_t front_hdr_bytes = 0;
+    uint64_t *d_slow_list = nullptr;
+    size_t slow_list_reads = 0;
+    uint64_t *d_front_pool = nullptr;
+    uint64_t front_pool_cap = 0;                  // descriptors
+    uint64_t front_pool_forced = 0;               // EPIK_AMD_TEAM_POOL: that many, whatever the batch (tests)
+    unsigned long long *d_front_cursor = nullptr; // [0] descriptors asked for, [1] reads on the slow list, [2] reads of the launch
+    unsigned long long *h_front_cursor = nullptr; // pinned: the same of the last launch that has finished
+    uint64_t longest_read_hint = 0;               // epik_amd_placer_choose_counts
+    uint32_t front_blocks = 0;                    // grid of the front kernel: the workgroups a device holds
     uint64_t num_keys = 0;
     uint64_t num_entries = 0;
     // launch geometry per count width (epik_amd::CountBits)
@@ -113,8 +128,10 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(t, p->params.dbg, sizeof t, hipMemcpyDeviceToHost);
         if (p->team) {
-            const char *names[8] = {"encode+lookup", "wait-tiles", "descriptors", "wait-desc", "stream", "wait-streams",
-                                    "epilogue", "wait-epilogues(+merge)"};
+            const char *classic[8] = {"encode+lookup", "wait-tiles", "descriptors", "wait-desc", "stream", "wait-streams",
+                                      "epilogue", "wait-epilogues(+merge)"};
+            const char *streaming[8] = {"descriptors", "stream", "ambiguous", "epilogue", "wait-slices", "merge", "-", "-"};
+            const char **names = p->team_front ? streaming : classic;
             double all = 0;
             for (int w = 0; w < p->team_waves; ++w)
                 for (int i = 0; i < 8; ++i) all += (double)t[w * 8 + i];
@@ -124,6 +141,16 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
                     std::fprintf(stderr, "  %s %.1f%%", names[i], 100.0 * t[w * 8 + i] * p->team_waves / all);
                 std::fprintf(stderr, "\n");
             }
+            const char *epi[8] = {"correction", "tau", "scan", "rank", "partial-sum", "wait-merge", "publish", "clear"};
+            std::vector<unsigned long long> rows(kDbgWords - 64);
+            (void)hipMemcpy(rows.data(), p->params.dbg + 64, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "slice epilogue, share of all waves' time:");
+            for (int i = 0; i < 8; ++i) {
+                double sum = 0;
+                for (size_t r = 0; r < rows.size() / 8; ++r) sum += (double)rows[r * 8 + i];
+                std::fprintf(stderr, "  %s %.1f%%", epi[i], 100.0 * sum / all);
+            }
+            std::fprintf(stderr, "\n");
             (void)hipFree(p->params.dbg);
             p->params.dbg = nullptr;
         }
@@ -151,6 +178,11 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_n_rows);
     (void)hipFree(p->d_counts);
     (void)hipFree(p->d_total);
+    (void)hipFree(p->d_front_hdr);
+    (void)hipFree(p->d_slow_list);
+    (void)hipFree(p->d_front_pool);
+    (void)hipFree(p->d_front_cursor);
+    if (p->h_front_cursor) (void)hipHostFree(p->h_front_cursor);
     if (p->ev_start) (void)hipEventDestroy(p->ev_start);
     if (p->ev_stop) (void)hipEventDestroy(p->ev_stop);
     for (hipEvent_t e : p->ev_in) (void)hipEventDestroy(e);
@@ -365,8 +397,8 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
 #ifdef EPIK_AMD_ABLATION
     if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
     if (const char *st = std::getenv("EPIK_AMD_STAMPS"); st && st[0] == '1') {
-        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), 64 * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemset(pp.dbg, 0, 64 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), kDbgWords * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(pp.dbg, 0, kDbgWords * sizeof(unsigned long long)));
     }
 #endif
     hipDeviceProp_t prop;
@@ -379,6 +411,11 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
         p->team_slice_rows = plan.team_slice_rows;
         p->team_rows_pad = plan.team_rows_pad;
         const uint32_t desc_bytes = epik_amd::team_desc_bytes(d->keep_at_most);
+        // Placing, the front end runs as a kernel of its own (team_stream.hip) unless the tree has more
+        // slices than header words fit a wave, or EPIK_AMD_TEAM_FRONT=0 asks for the one-kernel placement.
+        const char *front_env = std::getenv("EPIK_AMD_TEAM_FRONT");
+        p->team_front = (uint32_t)plan.team_waves * plan.team_passes <= epik_amd::kFrontMaxSlices &&
+                        !(front_env && front_env[0] == '0');
         for (int counts = 0; counts < 3; ++counts) {
             auto &g = p->geo[counts];
             g.waves_per_block = (uint32_t)plan.team_waves;
@@ -391,11 +428,27 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
             uint32_t per_cu = epik_amd::team_resident_blocks(plan.team_waves, g.lds_block_bytes);
             if (per_cu == 0) continue;  // (make_plan made sure the 32-bit counts fit; narrower ones then do too)
             CREATE_TRY(epik_amd::set_team_lds_limit(plan.team_waves, counts, g.lds_block_bytes));
+            // the grid is the workgroups resident at once: of the streaming kernel where it places (a grid
+            // larger than team_place_kernel holds at once only queues -- that kernel then gets the few reads
+            // the front kernel left it, or the launches of a k-mer-space shard, which size their own)
             int by_query = 0;
-            CREATE_TRY(epik_amd::team_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
+            if (p->team_front) {
+                CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts));
+                CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
+            } else {
+                CREATE_TRY(epik_amd::team_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
+            }
             per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(per_cu, (uint32_t)std::max(by_query, 1)));
             g.max_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
             g.resident_waves = per_cu * (uint32_t)plan.team_waves;
+        }
+        if (p->team_front) {
+            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_front_cursor), 3 * sizeof(unsigned long long)));
+            CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_front_cursor), 3 * sizeof(unsigned long long),
+                                     hipHostMallocDefault));
+            p->h_front_cursor[0] = p->h_front_cursor[1] = p->h_front_cursor[2] = 0;
+            if (const char *e = std::getenv("EPIK_AMD_TEAM_POOL")) p->front_pool_forced = std::strtoull(e, nullptr, 10);
+            p->front_blocks = (uint32_t)prop.multiProcessorCount * 8u;  // 32 waves per CU: all it holds
         }
     } else {
         for (int counts = 0; counts < 3; ++counts) {
@@ -571,8 +624,63 @@ struct shard_buffers {
 enum launch_mode { kPlace = epik_amd::kTeamModePlace, kAccumulate = epik_amd::kTeamModeAccumulate,
                    kFinish = epik_amd::kTeamModeFinish };
 
+// Scratch of the front kernel for a launch of n reads (`total_chars`: their characters when the caller knows,
+// else 0).  The pool is sized from what the image says a k-mer's descriptors take and from what earlier
+// launches asked for; a read that finds it full is placed by team_place_kernel, so the estimate only
+// decides speed.  Grown, never shrunk; growing frees the old buffer (which waits for the device).
+static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars)
+{
+    const uint32_t slices = (uint32_t)p->team_waves * p->team_passes;
+    const size_t hdr_bytes = (size_t)n * epik_amd::front_hdr_stride(slices);
+    if (hdr_bytes > p->front_hdr_bytes) {
+        (void)hipFree(p->d_front_hdr);
+        p->d_front_hdr = nullptr, p->front_hdr_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_front_hdr), hdr_bytes));
+        p->front_hdr_bytes = hdr_bytes;
+    }
+    if (n > p->slow_list_reads) {
+        (void)hipFree(p->d_slow_list);
+        p->d_slow_list = nullptr, p->slow_list_reads = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_slow_list), (size_t)n * sizeof(uint64_t)));
+        p->slow_list_reads = n;
+    }
+    uint64_t want;
+    if (p->front_pool_forced) {
+        want = p->front_pool_forced;
+    } else {
+        // chunks per k-mer that has a list (all slices and passes together), 10 % on top, and the padding
+        // of every slice's list to the ring
+        const double per_kmer = (double)p->plan.team_chunks / (double)std::max<uint64_t>(p->plan.present_codes, 1);
+        const uint64_t chars = total_chars ? total_chars : n * (p->longest_read_hint ? p->longest_read_hint : 160u);
+        // ... and what the waves of the front kernel leave unused of the pieces they take the pool in
+        const uint64_t front_waves = std::min<uint64_t>(n, (uint64_t)p->front_blocks * 4u);
+        double est = (double)chars * per_kmer * 1.1 + (double)n * slices * epik_amd::kTeamRing +
+                     (double)front_waves * epik_amd::kFrontPoolChunk;
+        // what the last finished launch asked for per read, if that is more
+        if (p->h_front_cursor[2]) {
+            const double asked = (double)p->h_front_cursor[0] / (double)p->h_front_cursor[2] * (double)n * 1.15;
+            if (asked > est) est = asked;
+        }
+        want = (uint64_t)est + 1024u;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t room = ((uint64_t)free_b + p->front_pool_cap * 8u) / 2u / 8u;  // at most half of what is free
+            want = std::min<uint64_t>(want, std::max<uint64_t>(room, 1024u));
+        }
+    }
+    want = (want + 7u) & ~7ull;
+    if (want > p->front_pool_cap || (p->front_pool_forced && want != p->front_pool_cap)) {
+        (void)hipFree(p->d_front_pool);
+        p->d_front_pool = nullptr, p->front_pool_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_front_pool), (size_t)want * sizeof(uint64_t)));
+        p->front_pool_cap = want;
+    }
+    return EPIK_AMD_OK;
+}
+
 static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, const void *d_seq_offsets, uint64_t n,
-                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream, const shard_buffers &shard = {})
+                  void *d_rows, void *d_n_rows, void *d_counts, hipStream_t stream, const shard_buffers &shard = {},
+                  uint64_t total_chars = 0)
 {
     if (n == 0) return EPIK_AMD_OK;
     epik_amd::PlaceParams pp = p->params;
@@ -608,8 +716,32 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         tp.desc_cap = epik_amd::kTeamDescCap;
         tp.slice_bytes = g.lds_wave_bytes;
         tp.desc_bytes = epik_amd::team_desc_bytes(pp.keep_at_most);
-        HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,
-                                      stream));
+        if (mode == kPlace && p->team_front) {
+            // front kernel (a wave per read), streaming kernel (a workgroup per read), and team_place_kernel
+            // for the reads whose descriptors found the pool full
+            if (const int rc = reserve_front(p, n, total_chars); rc != EPIK_AMD_OK) return rc;
+            tp.front_hdr = p->d_front_hdr;
+            tp.front_hdr_stride = epik_amd::front_hdr_stride((uint32_t)p->team_waves * p->team_passes);
+            tp.front_pool = p->d_front_pool;
+            tp.front_pool_cap = p->front_pool_cap;
+            tp.front_cursor = p->d_front_cursor;
+            tp.slow_list = p->d_slow_list;
+            HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
+            const uint64_t front_blocks = std::min<uint64_t>((n + 3) / 4, (uint64_t)p->front_blocks);
+            HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
+            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, dim3((unsigned)blocks), g.lds_block_bytes,
+                                                 stream));
+            tp.read_list = p->d_slow_list;
+            tp.read_list_count = p->d_front_cursor + 1;
+            HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,
+                                          stream));
+            // what this launch asked of the pool, for the size of the next one's (read whenever it has arrived)
+            HIP_TRY(hipMemcpyAsync(p->h_front_cursor, p->d_front_cursor, 3 * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, stream));
+        } else {
+            HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,
+                                          stream));
+        }
     } else if (mode == kFinish) {
         HIP_TRY(epik_amd::launch_finish_reads(pp, p->counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
                                               g.lds_block_bytes, stream));
@@ -823,7 +955,7 @@ static int place_impl(epik_amd_placer *p, const char *seqs, const uint64_t *seq_
             break;
         }
         rc = launch(p, kPlace, p->d_seqs, p->d_seq_offsets + r0, cnt, p->d_rows + r0 * keep, p->d_n_rows + r0,
-                    p->d_counts + r0 * keep, p->stream);
+                    p->d_counts + r0 * keep, p->stream, {}, b1 - b0);
         if (rc != EPIK_AMD_OK) break;
         e = hipEventRecord(p->ev_kernel[c], p->stream);
         if (e != hipSuccess) {
@@ -905,6 +1037,7 @@ int epik_amd_placer_choose_counts(epik_amd_placer *p, uint64_t longest_read)
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
     p->counts = counts_for(p, longest_read);
     p->counts_forced = true;
+    p->longest_read_hint = longest_read;
     return EPIK_AMD_OK;
 }
 

@@ -228,7 +228,10 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
             for (uint64_t i = 0; i < len; ++i) ++cnt[v[i].branch / c.slice_rows];
             for (uint32_t p = 0; p < c.passes; ++p) {
                 uint32_t bytes = 0;
-                for (int w = 0; w < c.waves; ++w) bytes += pad4(cnt[p * c.waves + w] * 6u);
+                for (int w = 0; w < c.waves; ++w) {
+                    bytes += pad4(cnt[p * c.waves + w] * 6u);
+                    plan.team_chunks += (cnt[p * c.waves + w] + 63u) / 64u;
+                }
                 lines += (bytes + 127u) / 128u;
             }
         }

@@ -43,6 +43,7 @@ struct Plan {
     // team kernel (layout == kTeam)
     int team_waves = 0;
     uint32_t team_passes = 0, team_slice_rows = 0, team_rows_pad = 0;
+    uint64_t team_chunks = 0;  // chunks of <= 64 postings over all sublists (what a read's descriptors take: capi.hip)
     // device image
     uint64_t table_bytes = 0, filter_bytes = 0, posting_bytes = 0;
     uint64_t kept_entries = 0, present_codes = 0;

@@ -38,7 +38,11 @@ constexpr uint32_t kLdsGranule = 1280u;       // LDS is handed out in 128ths of 
 constexpr uint32_t kWaveKernelWavesPerCu = 20u;  // place_reads_kernel: __launch_bounds__(256, 5)
 // team_place_kernel: __launch_bounds__(256, 3) with 4 waves (no spills; LDS leaves 3 workgroups at most where
 // this kernel is chosen), (512, 4) with 8
-constexpr uint32_t team_kernel_waves_per_cu(int waves) { return waves == 4 ? 12u : 16u; }
+#ifndef EPIK_AMD_STREAM_OCC
+#define EPIK_AMD_STREAM_OCC 0  // experiments: waves per SIMD the team kernels are compiled for (0: 3 with 4-wave teams, 4 with 8)
+#endif
+constexpr uint32_t team_waves_per_simd(int waves) { return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : waves == 4 ? 3u : 4u; }
+constexpr uint32_t team_kernel_waves_per_cu(int waves) { return 4u * team_waves_per_simd(waves); }
 
 constexpr uint32_t kWaveDescBytes = (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
 // LDS bytes of one wave of the one-wavefront-per-read kernels: scores + counts + chunk descriptors

@@ -689,6 +689,18 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     // (__builtin_amdgcn_kernarg_segment_ptr() is null inside an out-of-line function: the block comes as kp)
     const PlaceParams &p = *kp;
     const int lane = lane_id();
+#ifdef EPIK_AMD_ABLATION
+    // where the epilogue spends its time: cycles per section, a row of dbg[64 ..] per wave, EPIK_AMD_STAMPS=1
+    unsigned long long epi_last = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define EPI_STAMP(k)                                                                   \
+    if (p.dbg) {                                                                       \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        if (lane == 0) p.dbg[64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] += now_ - epi_last; \
+        epi_last = __builtin_amdgcn_s_memtime();                                       \
+    }
+#else
+#define EPI_STAMP(k)
+#endif
     const uint32_t N = ctx.rows(p);
     const float k_f = (float)ctx.kmer_size(p);
     const float log_thr = ctx.log_threshold(p);
@@ -754,6 +766,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave) correct_rows(std::true_type{}, base);
         if (base < n_rows_pad) correct_rows(std::false_type{}, base);
     }
+    EPI_STAMP(0)  // correction sweep
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
     touched = wave_sum_u32(touched);
     const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
@@ -798,6 +811,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         }
         best_score = unord_f32(top);
     }
+    EPI_STAMP(1)  // tau
     const float ref_score = fmaxf(best_score, thr_score);
     const bool relative_sum = ref_score > -280.0f;  // wave-uniform
     if (touched != 0) {
@@ -853,6 +867,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             ranked_in_place = true;
         }
     }
+    EPI_STAMP(2)  // scan sweep
     // ---- rank: <= 3 candidates per lane, rank = number of candidates with a larger key --------
     const uint32_t n_q = (n_cand + kWave - 1) / kWave;
     uint64_t my_key[kQ];
@@ -886,6 +901,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             }
         }
     }
+    EPI_STAMP(3)  // rank
     if constexpr (Ctx::kTeam) {
         // ---- one slice of a team placement: ranked rows and partial sum to the merge area ----------
         double sum;
@@ -899,6 +915,9 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             }
             sum = wave_sum_f64(sum);
         }
+        EPI_STAMP(4)  // partial sum
+        ctx.before_publish();
+        EPI_STAMP(5)  // waiting for the previous merge
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             if ((uint32_t)q < n_q && my_key[q] != 0 && my_rank[q] < n_sel) {
@@ -914,7 +933,9 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
             ctx.partial->ref_score = ref_score;
             ctx.partial->sum = sum;
         }
+        EPI_STAMP(6)  // publish
         lds.clear(n_rows_pad);
+        EPI_STAMP(7)  // clear
         (void)read;
         return;
     }

@@ -68,12 +68,47 @@ struct TeamParams {
     uint32_t desc_cap;           // chunk descriptors per slice and round (a multiple of the ring, >= 64)
     uint32_t slice_bytes;        // LDS bytes of one slice's rows (scores then counts), a multiple of 16
     uint32_t desc_bytes;         // LDS bytes of one slice's descriptor list, a multiple of 16
+    // team_place_kernel over a list of reads (null: reads 0 .. base.n_reads - 1): the reads the front
+    // kernel below could not prepare
+    const uint64_t *read_list;
+    const unsigned long long *read_list_count;
+    // The front end as a kernel of its own (team_stream.hip).  team_front_kernel leaves, per read, a
+    // header {u32 off8, u32 flags, u32 length, u32 cnt[S]} (S = W * passes slices; front_hdr_stride bytes
+    // apart) and the chunk descriptors of every slice, in read order, in the pool: slice s of the read owns
+    // the descriptors from off8 * 8 + sum of the earlier slices' counts (each rounded up to the ring, the
+    // padding being null chunks) on.  front_cursor[0] = descriptors handed out so far (it runs past
+    // front_pool_cap when the pool is too small: those reads go on slow_list, front_cursor[1] counts them),
+    // front_cursor[2] = reads of the launch.
+    uint8_t *front_hdr;
+    uint32_t front_hdr_stride;
+    uint64_t *front_pool;
+    uint64_t front_pool_cap;
+    unsigned long long *front_cursor;
+    uint64_t *slow_list;
 };
+// header flags
+constexpr uint32_t kFrontAmbiguous = 1u;  // the read has an ambiguous k-mer (place.cpp:306-313)
+constexpr uint32_t kFrontSlow = 2u;       // its descriptors are not in the pool: team_place_kernel places it
+constexpr uint32_t kFrontNoRows = 4u;     // shorter than k: no placement
+constexpr uint32_t kFrontTooNarrow = 8u;  // more k-mers than the launch's counts hold
+// the header's words sit one per lane in the consumer
+constexpr uint32_t kFrontHdrWords = 3;
+constexpr uint32_t kFrontMaxSlices = 64 - kFrontHdrWords;
+constexpr uint32_t front_hdr_stride(uint32_t slices) { return ((kFrontHdrWords + slices) * 4u + 15u) & ~15u; }
+// a wave of the front kernel takes the pool this many descriptors at a time (one atomic add each) and hands
+// them to its reads itself; a read that needs more takes exactly what it needs
+constexpr uint32_t kFrontPoolChunk = 4096;
 enum : int { kTeamModePlace = 0, kTeamModeAccumulate = 1, kTeamModeFinish = 2 };
 hipError_t launch_team(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
                        hipStream_t stream);
 hipError_t set_team_lds_limit(int waves, int counts, size_t lds_bytes);
 hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
+// team_stream.hip: the front kernel (any grid of 256-thread workgroups, one read per wave) and the
+// streaming kernel (one workgroup per read, grid = resident workgroups, LDS as the team kernel's)
+hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream);
+hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 grid, size_t lds_bytes, hipStream_t stream);
+hipError_t set_team_stream_lds_limit(int waves, int counts);
+hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream);
 
 hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts, dim3 grid, dim3 block,

@@ -1,0 +1,281 @@
+// team_device.hpp -- device-side pieces shared by the team kernels (team_kernel.hip: the whole
+// placement of a read in one workgroup; team_stream.hip: the same with the front end taken out into
+// a kernel of its own): the table entry of the sliced database, the slice context of a wave, and
+// the merge of the slices' results.  Anonymous namespace: each translation unit gets its own copy.
+#ifndef EPIK_AMD_TEAM_DEVICE_HPP
+#define EPIK_AMD_TEAM_DEVICE_HPP
+#include "place_device.hpp"
+
+namespace epik_amd {
+
+namespace {
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) v4u lds_u32x4;
+typedef __attribute__((address_space(3))) TeamPartial lds_partial;
+
+// Table entry of the team layout: {u32 line, u16 len[W]}, padded to 16 / 32 / 64 bytes.  The W
+// sublists lie back to back from byte line * 128 on, each in chunks of <= 64 postings (f32 score[cnt]
+// then u16 cell[cnt], cell local to the slice, 0 = the slice's dummy row) and padded to 4 bytes.
+template <int W>
+struct TeamEntry {
+    static constexpr int kWords = team_entry_bytes(W) / 4;
+    uint32_t line;
+    uint32_t len[W];
+    __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key)
+    {
+        const uint4 *e = reinterpret_cast<const uint4 *>(tp.team_table + ((uint64_t)pass * tp.num_keys + key) * (kWords * 4u));
+        uint32_t w[kWords];
+#pragma unroll
+        for (int i = 0; i < kWords / 4; ++i) {
+            const uint4 v = e[i];
+            w[4 * i] = v.x;
+            w[4 * i + 1] = v.y;
+            w[4 * i + 2] = v.z;
+            w[4 * i + 3] = v.w;
+        }
+        line = w[0];
+#pragma unroll
+        for (int s = 0; s < W; ++s) len[s] = (w[1 + s / 2] >> (16 * (s & 1))) & 0xffffu;
+    }
+    // byte offset of sublist s in the posting region
+    __device__ __forceinline__ uint64_t start(int s) const
+    {
+        uint32_t off = 0;
+#pragma unroll
+        for (int q = 0; q < W; ++q)
+            if (q < s) off += (len[q] * 6u + 3u) & ~3u;
+        return (uint64_t)line * 128u + off;
+    }
+};
+
+// The slice of the branch range one wave of a team accumulates (see WaveCtx in place_device.hpp).
+template <int W>
+struct TeamCtx {
+    static constexpr bool kTeam = true;
+    static constexpr uint32_t kCandCap = kTeamCandCap;  // top-k candidates of a slice: at most one per lane
+    uint32_t rows_pad_, rows_, base_, slice_, pass_;
+    uint32_t kmer_size_, keep_;  // placer constants, in registers: the slice epilogue loads nothing from the argument block
+    float log_threshold_;
+    __device__ __forceinline__ uint32_t kmer_size(const PlaceParams &) const { return kmer_size_; }
+    __device__ __forceinline__ float log_threshold(const PlaceParams &) const { return log_threshold_; }
+    __device__ __forceinline__ uint32_t keep_at_most(const PlaceParams &) const { return keep_; }
+    lds_u32x4 *cand;       // [keep_at_most] ranked rows of this slice for the merge
+    lds_partial *partial;  // this slice's share of sum_scores
+    // team_stream_kernel: the merge area may still be read by the merge of the workgroup's previous read;
+    // merged_ counts the finished merges and must have reached need_ before the slice publishes (null: the
+    // caller's barriers see to it)
+    lds_u32 *merged_ = nullptr;
+    uint32_t need_ = 0;
+    __device__ __forceinline__ void before_publish() const
+    {
+        if (merged_)
+            while ((int32_t)(__hip_atomic_load((uint32_t *)merged_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - need_) < 0)
+                __builtin_amdgcn_s_sleep(1);
+    }
+    template <typename Params>
+    __device__ __forceinline__ uint32_t rows_pad(const Params &) const { return rows_pad_; }
+    template <typename Params>
+    __device__ __forceinline__ uint32_t rows(const Params &) const { return rows_; }
+    __device__ __forceinline__ uint32_t branch_base() const { return base_; }
+    template <typename Layout>
+    __device__ __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint64_t &addr, uint32_t &len) const
+    {
+        const TeamParams &tp = reinterpret_cast<const TeamParams &>(p);  // PlaceParams is its first member
+        TeamEntry<W> e;
+        e.load(tp, pass_, key);
+        addr = e.line * 128ull;
+        len = 0;
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            if ((uint32_t)s < slice_) addr += (e.len[s] * 6u + 3u) & ~3u;
+            if ((uint32_t)s == slice_) len = e.len[s];
+        }
+    }
+};
+
+typedef PackedLayout<kPlainTable> TeamChunks;  // the chunk format (and its loads) of the packed layout
+
+// ---------------------------------------------------------------------------------
+// The merge of a team placement, by one wave: the slices' ranked rows (S * keep_at_most slots of
+// {ord(score), branch, count, -}, empty slots 0) ranked together, then exactly the tail of
+// place_epilogue: sum_scores (:164-184) from the slices' partial sums, like-weight-ratios
+// (:241-264), filter_by_ratio (:188-199), rows out.
+// ---------------------------------------------------------------------------------
+// the placer constants and output arrays of a launch, handed to team_merge in registers
+struct MergeParams {
+    uint32_t keep_at_most, kmer_size, num_branches;
+    float log_threshold;
+    double keep_factor;
+    epik_amd_placement *rows;
+    uint32_t *n_rows, *kmer_counts;
+};
+
+__device__ __attribute__((noinline)) void team_merge(MergeParams p, lds_u32x4 *cand, uint32_t cand_stride,
+                                                     lds_partial *partials, uint32_t n_slices, uint64_t read,
+                                                     uint64_t n_kmers)
+{
+    const int lane = lane_id();
+    const uint32_t keep = p.keep_at_most;
+    const uint32_t M = n_slices * keep;
+    const float k_f = (float)p.kmer_size;
+    const float thr_score = __fdiv_rn(__fmul_rn((float)n_kmers, p.log_threshold), k_f);  // :175 / :146-147
+    constexpr float kLog2Of10 = 3.32192809488736f;
+    // the slices' partial sums, one slice per lane (their LDS reads go out together; read one after the
+    // other they were a chain of round trips on the path of the next read's first barrier)
+    uint32_t my_touched = 0, my_relative = 0;
+    float my_ref = 0.0f;
+    double my_sum = 0.0;
+    const bool sums_in_lanes = n_slices <= (uint32_t)kWave;  // wave-uniform; else looped over below
+    if (sums_in_lanes && (uint32_t)lane < n_slices) {
+        my_touched = partials[lane].touched;
+        my_relative = partials[lane].relative;
+        my_ref = partials[lane].ref_score;
+        my_sum = partials[lane].sum;
+    }
+    uint32_t touched = 0;
+    if (sums_in_lanes)
+        touched = wave_sum_u32(my_touched);
+    else
+        for (uint32_t s = 0; s < n_slices; ++s) touched += partials[s].touched;
+    uint32_t n_sel;
+    float best_score;
+    // Up to 64 slots (4 or 8 slices of the default 7 rows): one slot per lane, everything in registers.
+    const bool in_lanes = M <= (uint32_t)kWave;  // wave-uniform
+    v4u mine = v4u{0u, 0u, 0u, 0u};             // in_lanes: this lane's slot, .w = its rank
+    int best_lane = 0;
+    if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
+        n_sel = keep;
+        best_score = thr_score;
+        if (in_lanes) {
+            if ((uint32_t)lane < keep) mine = v4u{ord_f32(thr_score), (uint32_t)lane, 0u, (uint32_t)lane};
+        } else {
+            for (uint32_t i = lane; i < M; i += kWave)
+                cand[(i / keep) * cand_stride + i % keep] =
+                    i < keep ? v4u{ord_f32(thr_score), i, 0u, i} : v4u{0u, 0u, 0u, 0u};
+        }
+    } else if (in_lanes) {
+        n_sel = keep < touched ? keep : touched;  // :137
+        if ((uint32_t)lane < M) mine = cand[((uint32_t)lane / keep) * cand_stride + (uint32_t)lane % keep];
+        const uint64_t key = mine.x ? (((uint64_t)mine.x << 32) | (uint64_t)(~mine.y)) : 0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < M; ++j) rank += readlane_u64(key, (int)j) > key ? 1u : 0u;
+        mine.w = rank;
+        const uint64_t first = __ballot(key != 0 && rank == 0);  // never empty: touched != 0
+        best_lane = __builtin_ctzll(first);
+        best_score = unord_f32(__builtin_amdgcn_readlane(mine.x, best_lane));
+    } else {
+        n_sel = keep < touched ? keep : touched;  // :137
+        uint32_t best_ord = 0;
+        for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint64_t key = 0;
+            if (i < M) {
+                const v4u c = cand[(i / keep) * cand_stride + i % keep];
+                key = c.x ? (((uint64_t)c.x << 32) | (uint64_t)(~c.y)) : 0ull;
+            }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < M; ++j) {  // the same address in every lane: an LDS broadcast
+                const v4u c = cand[(j / keep) * cand_stride + j % keep];
+                const uint64_t kj = c.x ? (((uint64_t)c.x << 32) | (uint64_t)(~c.y)) : 0ull;
+                rank += kj > key ? 1u : 0u;
+            }
+            if (i < M) cand[(i / keep) * cand_stride + i % keep].w = rank;
+            const uint64_t first = __ballot(key != 0 && rank == 0);
+            if (first) best_ord = __builtin_amdgcn_readlane((uint32_t)(key >> 32), __builtin_ctzll(first));
+        }
+        best_score = unord_f32(best_ord);
+    }
+    // 10^score of the rows that may be reported (:254): once per row, the lanes side by side
+    const bool my_row = in_lanes && mine.x != 0 && mine.w < n_sel;
+    double my_power = 0.0, best_power;
+    if (in_lanes) {
+        my_power = my_row ? pow10_f64((double)unord_f32(mine.x)) : 0.0;
+        best_power = __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(my_power), best_lane));
+    } else {
+        best_power = pow10_f64((double)best_score);
+    }
+    // ---- sum_scores (:164-184) ------------------------------------------------------------------
+    const float ref_score = fmaxf(best_score, thr_score);
+    double score_sum;
+    {
+        double rel = 0.0, absolute = 0.0;
+        if (sums_in_lanes) {
+            const bool counts = my_touched != 0;
+            const double scaled = my_sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(my_ref, ref_score), kLog2Of10));
+            rel = wave_sum_f64(counts && my_relative ? scaled : 0.0);
+            absolute = wave_sum_f64(counts && !my_relative ? my_sum : 0.0);
+        } else {
+            for (uint32_t s = 0; s < n_slices; ++s) {
+                if (partials[s].touched == 0) continue;
+                const double sum = partials[s].sum;
+                if (partials[s].relative)
+                    rel += sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(partials[s].ref_score, ref_score), kLog2Of10));
+                else
+                    absolute += sum;
+            }
+        }
+        const float not_placed = (float)p.num_branches - (float)touched;  // :174
+        if (ref_score > -280.0f) {
+            if (not_placed != 0.0f)
+                rel += (double)(not_placed * __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
+            const double ref_power = (ref_score == best_score) ? best_power : pow10_f64((double)ref_score);
+            score_sum = ref_power * rel + absolute;
+        } else {
+            score_sum = (double)not_placed * pow10_f64((double)thr_score) + absolute;  // :174-183, all double
+        }
+    }
+    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
+    const double best_ratio = (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191
+    const double ratio_threshold = best_ratio * keep_factor;                                           // :192
+    // ---- LWR (:241-264), filter_by_ratio (:188-199): which ranks stay --------------------------
+    uint64_t kept_ranks = 0;
+    if (in_lanes) {
+        const double lwr = (my_row && score_sum != 0.0 && my_power != 0.0) ? my_power / score_sum : 0.0;  // :255-262
+        kept_ranks = wave_or_u64((my_row && lwr >= ratio_threshold) ? 1ull << mine.w : 0ull);            // :197
+        if (my_row && ((kept_ranks >> mine.w) & 1ull)) {
+            const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << mine.w) - 1ull));
+            epik_amd_placement out;
+            out.branch = mine.y;
+            out.score = unord_f32(mine.x);
+            out.lwr = lwr;
+            p.rows[read * keep + slot] = out;
+            if (p.kmer_counts) p.kmer_counts[read * keep + slot] = mine.z;
+        }
+    } else {
+        for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            if (i < M) {
+                const v4u c = cand[(i / keep) * cand_stride + i % keep];
+                if (c.x != 0 && c.w < n_sel) {
+                    const double power = pow10_f64((double)unord_f32(c.x));
+                    const double lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;  // :255-262
+                    if (lwr >= ratio_threshold) kept_ranks |= 1ull << c.w;                              // :197
+                }
+            }
+        }
+        kept_ranks = wave_or_u64(kept_ranks);
+        for (uint32_t i0 = 0; i0 < M; i0 += kWave) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            if (i < M) {
+                const v4u c = cand[(i / keep) * cand_stride + i % keep];
+                if (c.x != 0 && c.w < n_sel && ((kept_ranks >> c.w) & 1ull)) {
+                    const uint32_t slot = (uint32_t)__popcll(kept_ranks & ((1ull << c.w) - 1ull));
+                    const double power = pow10_f64((double)unord_f32(c.x));
+                    epik_amd_placement out;
+                    out.branch = c.y;
+                    out.score = unord_f32(c.x);
+                    out.lwr = (score_sum != 0.0 && power != 0.0) ? power / score_sum : 0.0;
+                    p.rows[read * keep + slot] = out;
+                    if (p.kmer_counts) p.kmer_counts[read * keep + slot] = c.z;
+                }
+            }
+        }
+    }
+    if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
+}
+
+
+}  // namespace
+}  // namespace epik_amd
+#endif

@@ -1,0 +1,468 @@
+// team_stream.hip -- large trees, the front end as a kernel of its own.
+//
+// Reference path: as team_kernel.hip (epik/src/epik/place.cpp:278-440, 134-199, 241-267).
+//
+// team_place_kernel keeps three workgroups on a CU (a read's per-branch vectors fill the LDS), and each
+// of them walks through the phases of a read one after the other: characters -> classes -> table entries ->
+// chunk descriptors (four dependent trips to memory and two meetings of the waves) before the first posting
+// is fetched.  With twelve waves on a CU nothing hides that latency.  Here the placement is two kernels:
+//
+//   team_front_kernel   one WAVE per read, no per-branch vectors, so the CU is full of waves: encode
+//                       (i2l::to_kmers, place.cpp:294), lookup (phylo_kmer_db::search, :300) and the chunk
+//                       descriptors of every slice of the branch range, in read order, into a pool in HBM
+//                       (8 bytes per chunk of <= 64 postings: ~3 % on top of the postings themselves) plus
+//                       a header per read;
+//   team_stream_kernel  one workgroup per read as before, but a wave now only loads ITS slice's descriptor
+//                       list (coalesced, the header a read ahead), streams it into its rows (:349-371) and
+//                       runs the slice epilogue (:418-422, its share of :134-184).  The waves of a workgroup
+//                       never meet at a barrier: a slice that is done says so with an LDS counter, the wave
+//                       whose turn it is (read by read, in turn) merges the slices' results once all have,
+//                       and the others are already on the next read.
+//
+// A read whose descriptors did not fit the pool is put on a list and placed by team_place_kernel afterwards.
+// The arithmetic and its order are those of the other kernels: every branch receives its float32 adds from
+// one wave, in the k-mer order of the read -- bit-identical scores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "team_device.hpp"
+
+namespace epik_amd {
+
+// ---------------------------------------------------------------------------------
+// Front end.  A read of up to kTilesPerPass tiles (150 bp: three) on a one-pass tree keeps its table
+// entries in registers: its characters, then their classes, then the entries each go out together, the
+// chunks of every slice are counted, the read takes its descriptors' place in the pool, and the descriptors
+// are written.  Any other read is swept twice per pass: once to count, once to write (the table entries
+// come out of the L2 the second time).  The pool is handed out to the waves kFrontPoolChunk descriptors at
+// a time: one atomic add per read on a single counter costs more than everything else here (measured: 8 ns
+// each, device-wide).
+// ---------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t max_kmers)
+{
+    const PlaceParams &p = tp.base;
+    const int lane = lane_id();
+    const uint32_t k = p.kmer_size;
+    const uint32_t sigma = p.alphabet_size;
+    const uint32_t stride = kWave - (k - 1);  // windows per 64-character tile
+    const uint32_t n_slices = (uint32_t)W * tp.passes;
+    const uint64_t waves_per_block = blockDim.x >> 6;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    const uint64_t null_desc = null_chunk(p);
+    constexpr int T = kTilesPerPass;
+    unsigned long long chunk_at = 0;  // this wave's piece of the pool: next free descriptor, how many are left
+    uint32_t chunk_left = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) tp.front_cursor[2] = p.n_reads;  // (the host sizes the next launch's pool by it)
+    for (uint64_t read = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); read < p.n_reads; read += n_waves) {
+        const uint64_t seq_begin = p.seq_offsets[read];
+        const uint64_t len = p.seq_offsets[read + 1] - seq_begin;
+        const uint8_t *__restrict__ seq = p.seqs + seq_begin;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
+        // header words, one per lane: 0 = first descriptor / 8, 1 = flags, 2 = length, 3 + s = chunks of slice s
+        uint32_t word = 0;
+        if (len < k || len - k + 1 > max_kmers) {  // no placement / counts too narrow: the consumer reports it
+            word = lane == 1 ? (len < k ? kFrontNoRows : kFrontTooNarrow) : lane == 2 ? (uint32_t)len : 0u;
+            if ((uint32_t)lane < kFrontHdrWords + n_slices) hdr[lane] = word;
+            continue;
+        }
+        const uint64_t n_kmers = len - k + 1;  // :322
+        bool any_amb = false;
+        // one tile: which windows are exact k-mers, and (cold) whether any is ambiguous (:306-313)
+        auto exact_windows = [&](const Tile &tl) {
+            bool exact = tl.in_range;
+            if ((tl.inv_mask | tl.amb_mask) != 0) {  // wave-uniform, cold
+                const uint64_t wmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+                const uint64_t inv_w = (tl.inv_mask >> lane) & wmask;
+                const uint64_t amb_w = (tl.amb_mask >> lane) & wmask;
+                const bool is_amb = tl.in_range && inv_w == 0 && __popcll(amb_w) == 1;
+                exact = tl.in_range && inv_w == 0 && amb_w == 0;
+                any_amb = any_amb || __ballot(is_amb) != 0;
+            }
+            return exact;
+        };
+        const bool one_group = tp.passes == 1 && n_kmers <= (uint64_t)T * stride;  // wave-uniform
+        TeamEntry<W> held[T];  // one_group: the entries of the read's tiles
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            held[t].line = 0;
+#pragma unroll
+            for (int s = 0; s < W; ++s) held[t].len[s] = 0;
+        }
+        // ---- chunks per slice -------------------------------------------------------------------------
+        if (one_group) {
+            uint32_t ch[T], cls[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) ch[t] = tile_char(seq, len, (uint64_t)t * stride);
+#pragma unroll
+            for (int t = 0; t < T; ++t) cls[t] = tile_class(ch[t], len, (uint64_t)t * stride, p.char_class);
+            uint32_t acc[W];
+#pragma unroll
+            for (int s = 0; s < W; ++s) acc[s] = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const Tile tl = tile_from_class(cls[t], len, (uint64_t)t * stride, n_kmers, k, sigma, stride);
+                if (exact_windows(tl)) held[t].load(tp, 0u, tl.key);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int s = 0; s < W; ++s) acc[s] += (held[t].len[s] + (uint32_t)kWave - 1u) >> 6;
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                const uint32_t total = wave_sum_u32(acc[s]);
+                word = ((uint32_t)lane == kFrontHdrWords + (uint32_t)s) ? total : word;
+            }
+        } else {
+            for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+                uint32_t acc[W];
+#pragma unroll
+                for (int s = 0; s < W; ++s) acc[s] = 0;
+                for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
+                    const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
+                    if (exact_windows(tl)) {
+                        TeamEntry<W> e;
+                        e.load(tp, pass, tl.key);
+#pragma unroll
+                        for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < W; ++s) {
+                    const uint32_t total = wave_sum_u32(acc[s]);
+                    word = ((uint32_t)lane == kFrontHdrWords + pass * W + (uint32_t)s) ? total : word;
+                }
+            }
+        }
+        // ---- the read's place in the pool: every slice's list rounded up to the ring ---------------
+        const bool is_count = (uint32_t)lane >= kFrontHdrWords && (uint32_t)lane < kFrontHdrWords + n_slices;
+        const uint32_t padded = is_count ? (word + kTeamRing - 1u) & ~(kTeamRing - 1u) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(padded);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t first_of_slice = incl - padded;  // lane 3 + s: where slice s starts, in descriptors from the read's first
+        unsigned long long off = 0;
+        if (total > kFrontPoolChunk) {  // a long read: exactly what it needs
+            if (lane == 0) off = atomicAdd(tp.front_cursor, (unsigned long long)total);
+            off = readlane_u64(off, 0);
+        } else if (total != 0) {
+            if (total > chunk_left) {  // the rest of the old piece is lost (on average half a read's worth)
+                if (lane == 0) off = atomicAdd(tp.front_cursor, (unsigned long long)kFrontPoolChunk);
+                chunk_at = readlane_u64(off, 0);
+                chunk_left = kFrontPoolChunk;
+            }
+            off = chunk_at;
+            chunk_at += total;
+            chunk_left -= total;
+        }
+        const bool fits = off + total <= tp.front_pool_cap;
+        uint32_t flags = any_amb ? kFrontAmbiguous : 0u;
+        if (!fits) {
+            flags |= kFrontSlow;
+            if (lane == 0) tp.slow_list[atomicAdd(tp.front_cursor + 1, 1ull)] = read;
+        }
+        word = lane == 0 ? (uint32_t)(off >> 3) : lane == 1 ? flags : lane == 2 ? (uint32_t)len : word;
+        if ((uint32_t)lane < kFrontHdrWords + n_slices) hdr[lane] = word;
+        if (!fits || total == 0) continue;
+        // ---- the descriptors ---------------------------------------------------------------------------
+        uint64_t *__restrict__ out = tp.front_pool + off;
+        // the chunks of one tile's sublists of slice s, from descriptor `run` of the read on; returns their number
+        auto write_sublists = [&](uint32_t llen, uint64_t start, uint32_t run) {
+            const uint32_t nch = (llen + (uint32_t)kWave - 1u) >> 6;
+            const uint32_t scan = wave_incl_scan_u32(nch);
+            const uint32_t at = run + scan - nch;
+            // every lane writes the first kOwnChunks chunks of its own sublist; the rest of a longer one is
+            // written by the whole wave, lane j writing chunk kOwnChunks + j
+            constexpr uint32_t kOwnChunks = 3;
+#pragma unroll
+            for (uint32_t c = 0; c < kOwnChunks; ++c) {
+                if (nch > c) {
+                    const uint32_t rest = llen - (c << 6);
+                    const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                    out[at + c] = chunk_address<TeamChunks>(p, start, c) | (cnt << 48);
+                }
+            }
+            uint64_t long_lists = __ballot(nch > kOwnChunks);
+            while (long_lists) {
+                const int m = __builtin_ctzll(long_lists);
+                long_lists &= long_lists - 1;
+                const uint32_t l_first = __builtin_amdgcn_readlane(at, m);
+                const uint32_t l_len = __builtin_amdgcn_readlane(llen, m);
+                const uint64_t l_start = readlane_u64(start, m);
+                for (uint32_t c = (uint32_t)lane + kOwnChunks; (c << 6) < l_len; c += kWave) {
+                    const uint32_t rest = l_len - (c << 6);
+                    const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
+                    out[l_first + c] = chunk_address<TeamChunks>(p, l_start, c) | (cnt << 48);
+                }
+            }
+            return __builtin_amdgcn_readlane(scan, 63);
+        };
+        for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+            uint32_t run[W];  // where the next tile's chunks of slice s go (scalar)
+#pragma unroll
+            for (int s = 0; s < W; ++s)
+                run[s] = __builtin_amdgcn_readlane(first_of_slice, (int)kFrontHdrWords + (int)(pass * W) + s);
+            if (one_group) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int s = 0; s < W; ++s) run[s] += write_sublists(held[t].len[s], held[t].start(s), run[s]);
+            } else {
+                for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
+                    const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
+                    TeamEntry<W> e;
+                    e.line = 0;
+#pragma unroll
+                    for (int s = 0; s < W; ++s) e.len[s] = 0;
+                    if (exact_windows(tl)) e.load(tp, pass, tl.key);
+#pragma unroll
+                    for (int s = 0; s < W; ++s) run[s] += write_sublists(e.len[s], e.start(s), run[s]);
+                }
+            }
+            // the padding behind every list: chunks of zero bytes
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                const int slot = (int)kFrontHdrWords + (int)(pass * W) + s;
+                const uint32_t end = __builtin_amdgcn_readlane(first_of_slice, slot) + __builtin_amdgcn_readlane(padded, slot);
+                if (run[s] + (uint32_t)lane < end) out[run[s] + (uint32_t)lane] = null_desc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Stream + epilogue + merge.  LDS as team_place_kernel's: the W slices' rows | the W descriptor lists |
+// four counters (where the other kernel keeps its tile totals) | partial sums | the slices' ranked rows.
+// ---------------------------------------------------------------------------------
+template <int W, typename CountT>
+__global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_kernel(TeamParams tp)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    typedef WaveLds<CountT> Lds;
+    const PlaceParams &p = tp.base;
+    const int lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rows_pad = tp.rows_pad;
+    Lds lds;
+    unsigned char *desc_base = lds_raw + (size_t)W * tp.slice_bytes;
+    lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave * tp.slice_bytes);
+    lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave * tp.slice_bytes + (size_t)rows_pad * 4);
+    lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave * tp.desc_bytes);
+    lds_u32 *sync = (lds_u32 *)reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes);
+    lds_u32 *done = sync;        // slice epilogues finished so far, over all the workgroup's reads
+    lds_u32 *merged = sync + 1;  // merges finished so far
+    lds_partial *partials = (lds_partial *)reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4);
+    const uint32_t n_slices = W * tp.passes;
+    lds_u32x4 *merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4) + n_slices);
+    const uint32_t merge_stride = p.keep_at_most;
+    const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
+    const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
+                                                              (rows_pad - 1u) * (uint32_t)sizeof(CountT));
+    const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // = &tp.base
+    for (uint32_t i = lane; i < rows_pad; i += kWave) lds.store(i, 0u, 0u);
+    if (threadIdx.x < 4) sync[threadIdx.x] = 0u;
+    __syncthreads();  // the only one
+
+    const uint32_t k = p.kmer_size;
+    const uint32_t cap = tp.desc_cap;  // descriptors per round (a multiple of the ring; + one trip of spare entries <= 64)
+    const uint64_t null_desc = null_chunk(p);
+    uint32_t gen = 0;  // reads this workgroup has merged or is about to: the same in all its waves
+#ifdef EPIK_AMD_ABLATION
+    // where the waves spend their time: cycles per (wave, phase), EPIK_AMD_STAMPS=1
+    unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_last = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define STREAM_STAMP(k)                                                  \
+    if (p.dbg) {                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        dbg_t[k] += now_ - dbg_last;                                     \
+        dbg_last = now_;                                                 \
+    }
+#else
+#define STREAM_STAMP(k)
+#endif
+
+    // A read's header (one word per lane: 0 first descriptor / 8, 1 flags, 2 length, 3 + s chunks of slice s)
+    // is loaded two reads ahead, and this wave's first descriptors of a read one read ahead -- just before the
+    // read in front of it streams, so that they arrive under its postings (loads return in order: the ring's
+    // first wait covers them) and nothing is in flight when the out-of-line functions are entered.
+    auto load_header = [&](uint64_t r) {
+        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(tp.front_hdr + r * tp.front_hdr_stride);
+        return (uint32_t)lane < kFrontHdrWords + n_slices ? hdr[lane] : 0u;
+    };
+    // where the descriptors of slice `slot - kFrontHdrWords` of the read with header `word` lie, and how many
+    auto slice_list = [&](uint32_t word, int slot, uint32_t &my_padded) {
+        const bool is_count = (uint32_t)lane >= kFrontHdrWords && (uint32_t)lane < kFrontHdrWords + n_slices;
+        const uint32_t padded = is_count ? (word + kTeamRing - 1u) & ~(kTeamRing - 1u) : 0u;
+        const uint32_t first_of_slice = wave_incl_scan_u32(padded) - padded;
+        my_padded = __builtin_amdgcn_readlane(padded, slot);
+        const uint64_t first_desc = (uint64_t)__builtin_amdgcn_readlane(word, 0) << 3;
+        return (const uint64_t *)(tp.front_pool + first_desc + __builtin_amdgcn_readlane(first_of_slice, slot));
+    };
+    auto first_round = [&](uint32_t word) {
+        const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
+        uint64_t d = null_desc;
+        if (!(flags & (kFrontSlow | kFrontNoRows | kFrontTooNarrow))) {
+            uint32_t my_padded;
+            const uint64_t *list = slice_list(word, (int)(kFrontHdrWords + wave), my_padded);
+            const uint32_t n_first = my_padded < cap ? my_padded : cap;
+            if ((uint32_t)lane < n_first) d = list[lane];
+        }
+        return d;
+    };
+    uint32_t word_cur = 0, word_next = 0;
+    uint64_t desc_cur = null_desc;
+    if (blockIdx.x < p.n_reads) {
+        word_cur = load_header(blockIdx.x);
+        if ((uint64_t)blockIdx.x + gridDim.x < p.n_reads) word_next = load_header((uint64_t)blockIdx.x + gridDim.x);
+        desc_cur = first_round(word_cur);
+    }
+    for (uint64_t read = blockIdx.x; read < p.n_reads; read += gridDim.x) {
+        const uint32_t word = word_cur;
+        const uint64_t my_desc = desc_cur;
+        word_cur = word_next;
+        desc_cur = read + gridDim.x < p.n_reads ? first_round(word_cur) : null_desc;
+        if (read + 2ull * gridDim.x < p.n_reads) word_next = load_header(read + 2ull * gridDim.x);
+        const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
+        // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than this
+        // launch's counts hold is marked (the caller chose the count width).  Uniform over the workgroup.
+        if (flags & (kFrontNoRows | kFrontTooNarrow)) {
+            if (threadIdx.x == 0) p.n_rows[read] = (flags & kFrontNoRows) ? 0u : kCountsTooNarrow;
+            continue;
+        }
+        if (flags & kFrontSlow) continue;  // team_place_kernel places it after this launch
+        const uint64_t len = __builtin_amdgcn_readlane(word, 2);
+        const uint64_t n_kmers = len - k + 1;  // :322
+
+        for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+            TeamCtx<W> ctx;
+            ctx.rows_pad_ = rows_pad;
+            ctx.kmer_size_ = k;
+            ctx.keep_ = p.keep_at_most;
+            ctx.log_threshold_ = p.log_threshold;
+            ctx.slice_ = wave;
+            ctx.pass_ = pass;
+            ctx.base_ = (pass * W + wave) * tp.slice_rows;
+            ctx.rows_ = ctx.base_ >= p.num_branches ? 0u : min(tp.slice_rows, p.num_branches - ctx.base_);
+            ctx.cand = merge_cand + (size_t)(pass * W + wave) * merge_stride;
+            ctx.partial = partials + (pass * W + wave);
+            ctx.merged_ = merged;  // the previous read's merge must be over before this slice publishes
+            ctx.need_ = gen;
+            // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
+            uint32_t my_padded;
+            const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded);
+            for (uint32_t r0 = 0; r0 < my_padded; r0 += cap) {
+                const uint32_t n_round = min(my_padded - r0, cap);  // a multiple of the ring
+                // all 64 entries: the round's descriptors, then null chunks (the ring reads one trip ahead)
+                uint64_t d = my_desc;
+                if (pass != 0 || r0 != 0) d = (uint32_t)lane < n_round ? my_list[r0 + (uint32_t)lane] : null_desc;
+                lds.desc[lane] = d;
+                STREAM_STAMP(0)  // descriptors
+#ifdef EPIK_AMD_ABLATION
+                if (p.ablate & 8u) continue;  // (timing experiments: nothing streamed)
+#endif
+                stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_round, score_top, count_top);
+                STREAM_STAMP(1)  // stream
+            }
+            // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ----------------------
+            if (flags & kFrontAmbiguous) {
+                const uint8_t *seq = p.seqs + p.seq_offsets[read];
+                place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, (int64_t)-1, ctx);
+            }
+            STREAM_STAMP(2)  // ambiguous k-mers
+            // ---- correction, the slice's best rows and share of sum_scores, reset of the rows -------------
+            if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
+#ifdef EPIK_AMD_ABLATION
+            if (p.ablate & 2u) {  // (timing experiments: no slice epilogue)
+                lds.clear(rows_pad);
+                continue;
+            }
+#endif
+            place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
+            STREAM_STAMP(3)  // slice epilogue (with the wait for the previous merge)
+        }
+        // ---- this wave's slices are in the merge area ------------------------------------------------------
+        if (lane == 0) __hip_atomic_fetch_add((uint32_t *)done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wave == gen % (uint32_t)W) {  // its turn: merge once every wave is through
+            const uint32_t need = (gen + 1u) * (uint32_t)W;
+            while ((int32_t)(__hip_atomic_load((uint32_t *)done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - need) < 0)
+                __builtin_amdgcn_s_sleep(1);
+            STREAM_STAMP(4)  // waiting for the other slices
+            MergeParams mp;
+            mp.keep_at_most = p.keep_at_most;
+            mp.kmer_size = k;
+            mp.num_branches = p.num_branches;
+            mp.log_threshold = p.log_threshold;
+            mp.keep_factor = p.keep_factor;
+            mp.rows = p.rows;
+            mp.n_rows = p.n_rows;
+            mp.kmer_counts = p.kmer_counts;
+#ifdef EPIK_AMD_ABLATION
+            if (!(p.ablate & 4u))  // (timing experiments: no merge)
+#endif
+            team_merge(mp, merge_cand, merge_stride, partials, n_slices, read, n_kmers);
+            if (lane == 0) __hip_atomic_fetch_add((uint32_t *)merged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            STREAM_STAMP(5)  // merge
+        }
+        ++gen;
+    }
+#ifdef EPIK_AMD_ABLATION
+    if (p.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg[wave * 8 + i], dbg_t[i]);
+#endif
+}
+
+namespace {
+
+template <typename F>
+hipError_t stream_dispatch(int waves, int counts, F &&f)
+{
+#define EPIK_STREAM_CASE(W, C) \
+    if (waves == W && counts == C) \
+        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>>();
+    EPIK_STREAM_CASE(4, kCounts8) EPIK_STREAM_CASE(4, kCounts16) EPIK_STREAM_CASE(4, kCounts32)
+    EPIK_STREAM_CASE(8, kCounts8) EPIK_STREAM_CASE(8, kCounts16) EPIK_STREAM_CASE(8, kCounts32)
+#undef EPIK_STREAM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream)
+{
+    // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them)
+    const uint64_t max_kmers = counts == kCounts8 ? WaveLds<uint8_t>::kMaxKmers
+                               : counts == kCounts16 ? WaveLds<uint16_t>::kMaxKmers : WaveLds<uint32_t>::kMaxKmers;
+    if (waves == 4)
+        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(256), 0, stream, tp, max_kmers);
+    else if (waves == 8)
+        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(256), 0, stream, tp, max_kmers);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    return stream_dispatch(waves, counts, [&]<int W, typename C>() {
+        hipLaunchKernelGGL((team_stream_kernel<W, C>), grid, dim3(W * 64), lds_bytes, stream, tp);
+        return hipGetLastError();
+    });
+}
+
+hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whole CU: see place_kernel.hip)
+{
+    return stream_dispatch(waves, counts, [&]<int W, typename C>() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+    });
+}
+
+hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
+{
+    return stream_dispatch(waves, counts, [&]<int W, typename C>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C>, W * 64, lds_bytes);
+    });
+}
+
+}  // namespace epik_amd

@@ -30,6 +30,28 @@ def small_case():
     return tree, db
 
 
+def select_kernel(monkeypatch, name):
+    """Environment of a placer for the GPU tests.  `name`: a layout of the one-wavefront kernel
+    (paired, filtered, packed, compact), or teamW[xP] -- the team placement as front kernel +
+    streaming kernel (team_stream.hip) --, teamW[xP]-classic -- team_place_kernel alone --, or
+    teamW[xP]-smallpool -- a descriptor pool so small that some reads of a batch fall to
+    team_place_kernel behind the streaming kernel."""
+    for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT"):
+        monkeypatch.delenv(var, raising=False)
+    if name.startswith("team"):
+        kernel, _, variant = name.partition("-")
+        monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+        if variant == "classic":
+            monkeypatch.setenv("EPIK_AMD_TEAM_FRONT", "0")
+        elif variant == "smallpool":
+            monkeypatch.setenv("EPIK_AMD_TEAM_POOL", "2048")
+        else:
+            assert variant == "", name
+    else:
+        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+        monkeypatch.setenv("EPIK_AMD_LAYOUT", name)
+
+
 def mixed_reads(rng, n, k, alphabet_plain="ACGT", alphabet_amb="ACGTNRY-", max_len=60):
     reads = []
     for i in range(n):

@@ -9,7 +9,7 @@ CPU oracle bit for bit through the C ABI:
 import numpy as np
 import pytest
 
-from conftest import assert_rows_match, mixed_reads
+from conftest import assert_rows_match, mixed_reads, select_kernel
 from epik_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -46,17 +46,14 @@ def large_tree(gpu_available):
 
 
 @pytest.mark.parametrize("counts", ["auto", "0", "1", "2"])
-@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team8"])
+@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team8", "team4-classic", "team4-smallpool"])
 def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     """150 bp reads (141 k-mers: the 8-bit counts apply), with ambiguous and invalid characters in a
     third of them; `auto` lets place() choose, 0 / 1 / 2 force 16- / 32- / 8-bit counts."""
     from epik_amd.placer import Placer
     _, db = large_tree
-    if layout.startswith("team"):
-        monkeypatch.setenv("EPIK_AMD_KERNEL", layout)
-    elif layout != "default":  # default: what create() chooses for this tree (the team kernel)
-        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
-        monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
+    if layout != "default":  # default: what create() chooses for this tree (the team kernels)
+        select_kernel(monkeypatch, layout)
     if counts != "auto":
         monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", counts)
     rng = np.random.default_rng(48)
@@ -69,13 +66,16 @@ def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     assert_rows_match(*got, *ref)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "team4", "team8"])
+@pytest.mark.parametrize("kernel", ["wave", "team4", "team8", "team4-classic", "team4-smallpool"])
 def test_n9999_long_reads_leave_the_8_bit_counts(large_tree, oracle_lib, kernel, monkeypatch):
     """One read of more than 255 k-mers in the batch: place() must not pick the 8-bit counts; and
     reads long enough for several passes over the tiles."""
     from epik_amd.placer import Placer
     _, db = large_tree
-    monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+    if kernel == "wave":
+        monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+    else:
+        select_kernel(monkeypatch, kernel)
     rng = np.random.default_rng(49)
     reads = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(8, 150, size=400)]
     reads += ["".join(rng.choice(list("ACGTN"), size=int(n))) for n in (263, 700, 3000, 40000)]

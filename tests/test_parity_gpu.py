@@ -8,25 +8,24 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_rows_match, mixed_reads
+from conftest import assert_rows_match, mixed_reads, select_kernel
 from epik_amd import alphabet, synth
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact", "team4", "team8", "team4x3"])
+@pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact", "team4", "team8", "team4x3",
+                                      "team4-classic", "team4x3-classic", "team4-smallpool", "team8x2-smallpool"])
 def db_layout(request, monkeypatch):
     """Every parity test runs on every HBM layout of the database (line-aligned lists behind a
     direct-index table -- keyed by k-mer, or by the overlap of consecutive k-mers for DNA, or behind
     a presence filter keyed that way -- and the CSR used when that table would not fit) with one
     wavefront per read, and with the team kernels (a workgroup of 4 / 8 waves per read over the sliced
-    database; team4x3: the branch range in three passes of four slices), whatever the size of the tree."""
-    if request.param.startswith("team"):
-        monkeypatch.setenv("EPIK_AMD_KERNEL", request.param)
-    else:
-        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
-        monkeypatch.setenv("EPIK_AMD_LAYOUT", request.param)
+    database; team4x3: the branch range in three passes of four slices), whatever the size of the tree:
+    as front kernel + streaming kernel, as the one-kernel placement (-classic), and with a descriptor
+    pool too small for the batch (-smallpool: both, mixed)."""
+    select_kernel(monkeypatch, request.param)
     return request.param
 
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_rows_match
+from conftest import assert_rows_match, select_kernel
 from epik_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -48,16 +48,12 @@ def _random_case(seed):
     return db, synth.pack_reads(reads)
 
 
-@pytest.mark.parametrize("layout", ["paired", "packed", "compact", "team4", "team8x2"])
+@pytest.mark.parametrize("layout", ["paired", "packed", "compact", "team4", "team8x2", "team4x2-classic", "team4-smallpool"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EPIK_AMD_RANDOM_SEEDS", "16"))))
 def test_random_database_and_reads(gpu_available, oracle_lib, seed, layout, monkeypatch):
     assert gpu_available
     from epik_amd.placer import Placer
-    if layout.startswith("team"):
-        monkeypatch.setenv("EPIK_AMD_KERNEL", layout)
-    else:
-        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
-        monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
+    select_kernel(monkeypatch, layout)
     db, (data, offs) = _random_case(1000 + seed)
     keep = int(np.random.default_rng(seed).choice([1, 3, 7, 12]))
     factor = float(np.random.default_rng(seed + 7).choice([0.0, 0.01, 0.5]))

@@ -5,7 +5,7 @@ Runs the bench workload through several variants IN ONE PROCESS, interleaved ove
 rounds (devices differ by several percent: never compare across runs).  A variant is a
 comma-separated list of key=value:
     lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
-    layout=compact|packed|paired, kernel=wave|team4|team8, wide=0|1|2, ablate=<bitmask>, stamps=1   (env read at placer creation)
+    layout=compact|packed|paired, kernel=wave|team4|team8, wide=0|1|2, front=0|1 (team placement as one kernel | front + streaming kernel), ablate=<bitmask>, stamps=1   (env read at placer creation)
 LEAVES=<n> sets the tree (N = 2n - 1), N_READS the batch.
 Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
 """
@@ -48,6 +48,7 @@ def main():
         os.environ.pop("EPIK_AMD_KERNEL", None)
         if "kernel" in kv:
             os.environ["EPIK_AMD_KERNEL"] = kv["kernel"]
+        os.environ["EPIK_AMD_TEAM_FRONT"] = kv.get("front", "1")
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
         desc = capi.PlacerDesc(
             abi_version=capi.ABI_VERSION, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
