@@ -72,6 +72,8 @@ struct epik_amd_placer {
     size_t front_hdr_bytes = 0;
     uint64_t *d_slow_list = nullptr;
     size_t slow_list_reads = 0;
+    void *d_slice_rows = nullptr, *d_slice_sums = nullptr;  // the slices' results on their way to the merge kernel
+    size_t slice_out_reads = 0;
     uint64_t *d_front_pool = nullptr;
     uint64_t front_pool_cap = 0;                  // descriptors
     uint64_t front_pool_forced = 0;               // EPIK_AMD_TEAM_POOL: that many, whatever the batch (tests)
@@ -79,6 +81,7 @@ struct epik_amd_placer {
     unsigned long long *h_front_cursor = nullptr; // pinned: the same of the last launch that has finished
     uint64_t longest_read_hint = 0;               // epik_amd_placer_choose_counts
     uint32_t front_blocks = 0;                    // grid of the front kernel: the workgroups a device holds
+    uint64_t grid_percent = 100;                  // diagnostic builds: EPIK_AMD_GRID_PERCENT
     uint64_t num_keys = 0;
     uint64_t num_entries = 0;
     // launch geometry per count width (epik_amd::CountBits)
@@ -141,16 +144,17 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
                     std::fprintf(stderr, "  %s %.1f%%", names[i], 100.0 * t[w * 8 + i] * p->team_waves / all);
                 std::fprintf(stderr, "\n");
             }
-            const char *epi[8] = {"correction", "tau", "scan", "rank", "partial-sum", "wait-merge", "publish", "clear"};
-            std::vector<unsigned long long> rows(kDbgWords - 64);
-            (void)hipMemcpy(rows.data(), p->params.dbg + 64, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "slice epilogue, share of all waves' time:");
-            for (int i = 0; i < 8; ++i) {
-                double sum = 0;
-                for (size_t r = 0; r < rows.size() / 8; ++r) sum += (double)rows[r * 8 + i];
-                std::fprintf(stderr, "  %s %.1f%%", epi[i], 100.0 * sum / all);
+            if (p->team_front) {  // the timeline of one wave: code and cycles since the previous entry
+                std::vector<unsigned long long> tr(200000);
+                (void)hipMemcpy(tr.data(), p->params.dbg + 64, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                if (const char *path = std::getenv("EPIK_AMD_TRACE_FILE")) {
+                    if (FILE *f = std::fopen(path, "w")) {
+                        for (size_t i = 1; i < 100000 && tr[2 * i + 1] != 0; ++i)
+                            std::fprintf(f, "%llu %llu\n", tr[2 * i], tr[2 * i + 1] - tr[2 * i - 1]);
+                        std::fclose(f);
+                    }
+                }
             }
-            std::fprintf(stderr, "\n");
             (void)hipFree(p->params.dbg);
             p->params.dbg = nullptr;
         }
@@ -180,6 +184,8 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_total);
     (void)hipFree(p->d_front_hdr);
     (void)hipFree(p->d_slow_list);
+    (void)hipFree(p->d_slice_rows);
+    (void)hipFree(p->d_slice_sums);
     (void)hipFree(p->d_front_pool);
     (void)hipFree(p->d_front_cursor);
     if (p->h_front_cursor) (void)hipHostFree(p->h_front_cursor);
@@ -396,6 +402,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
     pp.log_threshold = d->log_threshold;
 #ifdef EPIK_AMD_ABLATION
     if (const char *ab = std::getenv("EPIK_AMD_ABLATE")) pp.ablate = (uint32_t)std::atoi(ab);
+    if (const char *e = std::getenv("EPIK_AMD_GRID_PERCENT")) p->grid_percent = std::strtoull(e, nullptr, 10);
     if (const char *st = std::getenv("EPIK_AMD_STAMPS"); st && st[0] == '1') {
         CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&pp.dbg), kDbgWords * sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(pp.dbg, 0, kDbgWords * sizeof(unsigned long long)));
@@ -640,9 +647,19 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars)
     }
     if (n > p->slow_list_reads) {
         (void)hipFree(p->d_slow_list);
+    (void)hipFree(p->d_slice_rows);
+    (void)hipFree(p->d_slice_sums);
         p->d_slow_list = nullptr, p->slow_list_reads = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_slow_list), (size_t)n * sizeof(uint64_t)));
         p->slow_list_reads = n;
+    }
+    if (n > p->slice_out_reads) {
+        (void)hipFree(p->d_slice_rows);
+        (void)hipFree(p->d_slice_sums);
+        p->d_slice_rows = p->d_slice_sums = nullptr, p->slice_out_reads = 0;
+        HIP_TRY(hipMalloc(&p->d_slice_rows, (size_t)n * slices * p->params.keep_at_most * 16u));
+        HIP_TRY(hipMalloc(&p->d_slice_sums, (size_t)n * slices * epik_amd::kTeamPartialBytes));
+        p->slice_out_reads = n;
     }
     uint64_t want;
     if (p->front_pool_forced) {
@@ -701,6 +718,10 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     // the team kernel places one read per workgroup, the others one per wave
     uint64_t blocks = p->team ? n : (n + g.waves_per_block - 1) / g.waves_per_block;
     if (blocks > g.max_blocks) blocks = g.max_blocks;
+#ifdef EPIK_AMD_ABLATION
+    // (timing experiments: fewer resident workgroups -- does a launch scale with them?)
+    blocks = std::max<uint64_t>(1, blocks * p->grid_percent / 100u);
+#endif
     p->last_blocks = (uint32_t)blocks;
     p->last_geo = (uint32_t)p->counts;
     const bool timed = p->timing && mode != kFinish;
@@ -726,11 +747,14 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.front_pool_cap = p->front_pool_cap;
             tp.front_cursor = p->d_front_cursor;
             tp.slow_list = p->d_slow_list;
+            tp.slice_rows_out = p->d_slice_rows;
+            tp.slice_sums_out = p->d_slice_sums;
             HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
             const uint64_t front_blocks = std::min<uint64_t>((n + 3) / 4, (uint64_t)p->front_blocks);
             HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
             HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, dim3((unsigned)blocks), g.lds_block_bytes,
                                                  stream));
+            HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)front_blocks), stream));
             tp.read_list = p->d_slow_list;
             tp.read_list_count = p->d_front_cursor + 1;
             HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,

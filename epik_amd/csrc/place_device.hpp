@@ -68,13 +68,25 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
 // Wave reductions; the result is wave-uniform (combined from the four rows' lane 0/16/32/48).
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-    v = max(v, dpp_u32<0xB1>(v));
-    v = max(v, dpp_u32<0x4E>(v));
-    v = max(v, dpp_u32<0x141>(v));
-    v = max(v, dpp_u32<0x140>(v));
-    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return max(max(a, b), max(c, d));
+    // Six v_max with the cross-lane move as their DPP operand (the builtin route costs a copy, a DPP move and a
+    // max per step, and four v_readlane at the end): quads, rows of 16, then row_bcast:15 / :31 carry the row
+    // maxima forward so that lane 63 ends with the wave's.  s_nop 1: a VGPR written by the VALU is readable
+    // as a DPP operand two wait states later.
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
@@ -431,6 +443,22 @@ struct WaveLds {
         s[0] = sv.x, s[1] = sv.y, s[2] = sv.z, s[3] = sv.w;
         c[0] = (uint32_t)cv.x, c[1] = (uint32_t)cv.y, c[2] = (uint32_t)cv.z, c[3] = (uint32_t)cv.w;
     }
+    // ... the four counts as they lie in LDS: one word (8-bit), two (16-bit) or four, rows in ascending order
+    static constexpr int kCountWords = (int)sizeof(CountT);
+    typedef uint32_t vcw __attribute__((ext_vector_type(sizeof(CountT) == 1 ? 1 : sizeof(CountT) == 2 ? 2 : 4)));
+    typedef __attribute__((address_space(3))) vcw count_words_t;
+    __device__ __forceinline__ void load4_packed(uint32_t i0, float (&s)[4], uint32_t (&w)[kCountWords]) const
+    {
+        const v4f sv = *reinterpret_cast<f32x4_t *>(score + i0);
+        s[0] = sv.x, s[1] = sv.y, s[2] = sv.z, s[3] = sv.w;
+        if constexpr (sizeof(CountT) == 1) {
+            w[0] = *reinterpret_cast<u32_t *>(count + i0);
+        } else {
+            const vcw cv = *reinterpret_cast<count_words_t *>(count + i0);
+#pragma unroll
+            for (int q = 0; q < kCountWords; ++q) w[q] = cv[q];
+        }
+    }
     __device__ __forceinline__ void load_scores4(uint32_t i0, float (&s)[4]) const
     {
         const v4f sv = *reinterpret_cast<f32x4_t *>(score + i0);
@@ -683,24 +711,31 @@ struct TeamPartial {
 // sum_scores go to the merge area in LDS (ctx.cand / ctx.partial) and the function returns after
 // clearing the slice; team_merge() then does the part from "10^score of every row" on.
 template <typename Layout, typename CountT, typename Ctx>
-__device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
-                                                         uint64_t read, uint64_t n_kmers, Ctx ctx)
+__device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
+                                                    uint64_t read, uint64_t n_kmers, Ctx ctx)
 {
     // (__builtin_amdgcn_kernarg_segment_ptr() is null inside an out-of-line function: the block comes as kp)
     const PlaceParams &p = *kp;
     const int lane = lane_id();
 #ifdef EPIK_AMD_ABLATION
-    // where the epilogue spends its time: cycles per section, a row of dbg[64 ..] per wave, EPIK_AMD_STAMPS=1
-    unsigned long long epi_last = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    // A timeline of ONE wave (the caller points ctx.trace_ at an LDS counter for it; EPIK_AMD_STAMPS=1): {code,
+    // s_memtime} pairs into dbg[64 ..], nothing from any other wave.
 #define EPI_STAMP(k)                                                                   \
-    if (p.dbg) {                                                                       \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
-        if (lane == 0) p.dbg[64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] += now_ - epi_last; \
-        epi_last = __builtin_amdgcn_s_memtime();                                       \
+    if constexpr (Ctx::kTeam) {                                                        \
+        if (ctx.trace_ && lane == 0) {                                                 \
+            const uint32_t i_ = *ctx.trace_;                                           \
+            *ctx.trace_ = i_ + 1u;                                                     \
+            if (i_ < 100000u) {                                                        \
+                p.dbg[64 + 2 * (size_t)i_] = (unsigned long long)(k);                  \
+                p.dbg[65 + 2 * (size_t)i_] = __builtin_amdgcn_s_memtime();             \
+            }                                                                          \
+        }                                                                              \
     }
 #else
 #define EPI_STAMP(k)
 #endif
+    typedef WaveLds<CountT> Lds_t;
+    EPI_STAMP(10)  // entered
     const uint32_t N = ctx.rows(p);
     const float k_f = (float)ctx.kmer_size(p);
     const float log_thr = ctx.log_threshold(p);
@@ -720,7 +755,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         return __fmaf_rn(r, inv_k, q);
     };
     const bool fast_div = ctx.kmer_size(p) <= 32u;
-    uint32_t touched = 0;
+    uint32_t touched = 0;           // wave-uniform: counted with ballots
     float lane_best_f = -INFINITY;  // this lane's best score
     // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 16: cells behind N hold
     // no count (the dummy row of the out-of-range lanes was cleared by the caller), so rows need no
@@ -728,22 +763,52 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     // arithmetic is branch-free.
     constexpr int kUnroll = 4;
     const uint32_t n_rows_pad = ctx.rows_pad(p);
-    auto correct_rows = [&](auto whole, uint32_t base) {
-        // the lane takes four consecutive rows (one wide LDS access); the last, partial trip of 256
-        // rows (kWhole == false) leaves the lanes behind the end without rows
+    // A trip in two halves -- the LDS reads, then everything else -- so that the loop can ask for the next
+    // trip's rows before it works on this one's (the wave would otherwise sit out an LDS round trip per trip).
+    struct Trip {
+        float raw[kUnroll];
+        uint32_t words[Lds_t::kCountWords];
+    };
+    auto load_trip = [&](auto whole, uint32_t base) {
+        constexpr bool kWhole = decltype(whole)::value;
+        Trip t;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) t.raw[u] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < Lds_t::kCountWords; ++q) t.words[q] = 0u;
+        const uint32_t i0 = base + 4u * (uint32_t)lane;
+        // the last, partial trip of 256 rows (kWhole == false) leaves the lanes behind the end without rows
+        if (kWhole || i0 < n_rows_pad) lds.load4_packed(i0, t.raw, t.words);
+        return t;
+    };
+    auto correct_rows = [&](auto whole, uint32_t base, const Trip &t) {
         constexpr bool kWhole = decltype(whole)::value;
         constexpr int kRows = kUnroll;
         const uint32_t i0 = base + 4u * (uint32_t)lane;
         const bool mine = kWhole || i0 < n_rows_pad;
-        float raw[kRows] = {0.0f, 0.0f, 0.0f, 0.0f}, pre[kRows], s[kRows];
-        uint32_t cnt[kRows] = {0u, 0u, 0u, 0u};
-        if (mine) lds.load4(i0, raw, cnt);
+        float missing[kRows], pre[kRows], s[kRows];
+        bool edge[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            if constexpr (sizeof(CountT) <= 2) {
+                // the count goes from its byte / half-word straight to float32 (one conversion instruction),
+                // and nk - c is exact in float32 (both below 2^16): the same value as float(nk - c) of :420
+                const uint32_t w = sizeof(CountT) == 1 ? (t.words[0] >> (8 * u)) & 0xffu
+                                                       : (t.words[u >> 1] >> (16 * (u & 1))) & (0xffffu & ~lds.kSeen);
+                const float c_f = (float)w;
+                missing[u] = nk_f - c_f;
+                edge[u] = c_f != 0.0f;
+            } else {
+                const uint32_t c = t.words[u] & ~lds.kSeen;
+                missing[u] = (float)(nk_u - c);
+                edge[u] = c != 0u;
+            }
+        }
         float smallest = INFINITY;
 #pragma unroll
         for (int u = 0; u < kRows; ++u) {
-            const uint32_t c = cnt[u] & ~lds.kSeen;
-            pre[u] = __fadd_rn(raw[u], __fmul_rn((float)(nk_u - c), log_thr));  // :420
-            s[u] = div_k(pre[u]);                                               // :421
+            pre[u] = __fadd_rn(t.raw[u], __fmul_rn(missing[u], log_thr));  // :420
+            s[u] = div_k(pre[u]);                                           // :421
             // (rows without a k-mer take part too: theirs is nk * log_thr, tiny only if log_thr is 0 --
             // then the exact division below runs, which is as right and only slower)
             smallest = fminf(smallest, fabsf(pre[u]));
@@ -754,21 +819,29 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         }
 #pragma unroll
         for (int u = 0; u < kRows; ++u) {
-            const uint32_t c = cnt[u] & ~lds.kSeen;
-            s[u] = c ? s[u] : -INFINITY;  // -inf = "not an edge"
-            touched += c ? 1u : 0u;
+            s[u] = edge[u] ? s[u] : -INFINITY;  // -inf = "not an edge"
+            touched += (uint32_t)__popcll(__ballot(edge[u]));
             lane_best_f = fmaxf(lane_best_f, s[u]);
         }
         if (mine) lds.store_scores4(i0, s);  // the count cells stay as they are
+        EPI_STAMP(20)  // one trip of the correction sweep
     };
     {
+        constexpr uint32_t kTripRows = kUnroll * kWave;
+        const uint32_t whole_trips = n_rows_pad / kTripRows;
         uint32_t base = 0;
-        for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave) correct_rows(std::true_type{}, base);
-        if (base < n_rows_pad) correct_rows(std::false_type{}, base);
+        if (whole_trips) {
+            Trip next = load_trip(std::true_type{}, 0u);
+            for (uint32_t trip = 0; trip < whole_trips; ++trip, base += kTripRows) {
+                const Trip cur = next;
+                if (trip + 1 < whole_trips) next = load_trip(std::true_type{}, base + kTripRows);
+                correct_rows(std::true_type{}, base, cur);
+            }
+        }
+        if (base < n_rows_pad) correct_rows(std::false_type{}, base, load_trip(std::false_type{}, base));
     }
     EPI_STAMP(0)  // correction sweep
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
-    touched = wave_sum_u32(touched);
     const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
 
     // ---- select_best_placements (:134-159) + sum_scores (:164-184) --------------------
@@ -787,7 +860,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
     constexpr float kLog2Of10 = 3.32192809488736f;
     uint32_t n_sel, n_cand;
     float best_score;
-    float rel_sum = 0.0f;          // this lane's share of sum_i 10^(score_i - ref_score)
+    float rel_sum = 0.0f, rel_sum_b = 0.0f;  // this lane's share of sum_i 10^(score_i - ref_score), in two halves
     bool ranked_in_place = false;  // cand[] already sorted: rank == index
     uint32_t tau = 1;
     if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
@@ -804,6 +877,7 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
                 tau = 1;
                 break;
             }
+            EPI_STAMP(21)  // one round of tau
             if (got == 0) top = m;
             got += (uint32_t)__popcll(__ballot(cur == m));
             tau = m;
@@ -818,32 +892,59 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
         n_cand = 0;
         // every edge's score is finite, every other row holds -inf: one comparison tells a candidate
         const float tau_f = tau <= 1u ? -FLT_MAX : unord_f32(tau);
-        auto scan_rows = [&](auto whole, uint32_t base) {
+        struct Rows {
+            float row[kUnroll];
+        };
+        auto load_rows = [&](auto whole, uint32_t base) {
             constexpr bool kWhole = decltype(whole)::value;  // as in the correction sweep
+            Rows r;
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) r.row[u] = -INFINITY;
+            const uint32_t i0 = base + 4u * (uint32_t)lane;
+            if (kWhole || i0 < n_rows_pad) lds.load_scores4(i0, r.row);
+            return r;
+        };
+        auto scan_rows = [&](uint32_t base, const Rows &r) {
             constexpr int kRows = kUnroll;
             const uint32_t i0 = base + 4u * (uint32_t)lane;
-            float row[kRows] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (kWhole || i0 < n_rows_pad) lds.load_scores4(i0, row);
+            // -inf where there is no edge (a sum of finite log10 scores never is); exp2(-inf) = 0: rows without
+            // an edge add nothing.  Two partial sums side by side: the four rows' arithmetic pairs up.
+            float term[kRows];
 #pragma unroll
-            for (int u = 0; u < kRows; ++u) {
-                const uint32_t i = i0 + (uint32_t)u;
-                const float sc = row[u];  // -inf where there is no edge (a sum of finite log10 scores never is)
-                // exp2(-inf) = 0: rows without an edge add nothing
-                rel_sum += __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc, ref_score), kLog2Of10));
-                const bool is_cand = sc >= tau_f;
-                const uint64_t m = __ballot(is_cand);
-                if (m) {
-                    const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (is_cand && slot < kCandCap) cand[slot] = v2u{ord_f32(sc), i};
-                    n_cand += (uint32_t)__popcll(m);
+            for (int u = 0; u < kRows; ++u)
+                term[u] = __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(r.row[u], ref_score), kLog2Of10));
+            rel_sum += term[0] + term[2];
+            rel_sum_b += term[1] + term[3];
+            // a candidate among the trip's 256 rows is rare: one test for all four
+            const bool any_cand = r.row[0] >= tau_f || r.row[1] >= tau_f || r.row[2] >= tau_f || r.row[3] >= tau_f;
+            if (__ballot(any_cand) != 0) {
+#pragma unroll
+                for (int u = 0; u < kRows; ++u) {
+                    const bool is_cand = r.row[u] >= tau_f;
+                    const uint64_t m = __ballot(is_cand);
+                    if (m) {
+                        const uint32_t slot = n_cand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (is_cand && slot < kCandCap) cand[slot] = v2u{ord_f32(r.row[u]), i0 + (uint32_t)u};
+                        n_cand += (uint32_t)__popcll(m);
+                    }
                 }
             }
         };
         {
+            constexpr uint32_t kTripRows = kUnroll * kWave;
+            const uint32_t whole_trips = n_rows_pad / kTripRows;
             uint32_t base = 0;
-            for (; base + kUnroll * kWave <= n_rows_pad; base += kUnroll * kWave) scan_rows(std::true_type{}, base);
-            if (base < n_rows_pad) scan_rows(std::false_type{}, base);
+            if (whole_trips) {
+                Rows next = load_rows(std::true_type{}, 0u);
+                for (uint32_t trip = 0; trip < whole_trips; ++trip, base += kTripRows) {
+                    const Rows cur = next;
+                    if (trip + 1 < whole_trips) next = load_rows(std::true_type{}, base + kTripRows);
+                    scan_rows(base, cur);
+                }
+            }
+            if (base < n_rows_pad) scan_rows(base, load_rows(std::false_type{}, base));
         }
+        rel_sum += rel_sum_b;
         if (n_cand > kCandCap) {
             // Too many ties at tau for the candidate buffer: repeated selection over all
             // edges instead (slow, rare).  Leaves cand[0..n_sel) sorted.
@@ -1016,6 +1117,13 @@ __device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__re
 
     // ---- reset the wave's vectors for its next read (place.cpp:335-342) -------------
     lds.clear(n_rows_pad);
+}
+// out of line (see above); team_stream_kernel, which has the registers, takes the body inline
+template <typename Layout, typename CountT, typename Ctx>
+__device__ __attribute__((noinline)) void place_epilogue(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
+                                                         uint64_t read, uint64_t n_kmers, Ctx ctx)
+{
+    place_epilogue_body<Layout, CountT, Ctx>(kp, lds, read, n_kmers, ctx);
 }
 
 

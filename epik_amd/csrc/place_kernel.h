@@ -85,6 +85,10 @@ struct TeamParams {
     uint64_t front_pool_cap;
     unsigned long long *front_cursor;
     uint64_t *slow_list;
+    // what the slices of a read hand to team_merge_kernel: [n_reads][S][keep_at_most] ranked rows
+    // {ord(score), branch, k-mer count, -} (empty slots 0) and [n_reads][S] partial sums (TeamPartial)
+    void *slice_rows_out;
+    void *slice_sums_out;
 };
 // header flags
 constexpr uint32_t kFrontAmbiguous = 1u;  // the read has an ambiguous k-mer (place.cpp:306-313)
@@ -107,6 +111,8 @@ hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_p
 // streaming kernel (one workgroup per read, grid = resident workgroups, LDS as the team kernel's)
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream);
 hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream);
+constexpr size_t kTeamPartialBytes = 24;  // sizeof(TeamPartial) (place_device.hpp)
 hipError_t set_team_stream_lds_limit(int waves, int counts);
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream);

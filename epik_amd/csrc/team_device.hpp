@@ -4,6 +4,8 @@
 // the merge of the slices' results.  Anonymous namespace: each translation unit gets its own copy.
 #ifndef EPIK_AMD_TEAM_DEVICE_HPP
 #define EPIK_AMD_TEAM_DEVICE_HPP
+#include <type_traits>
+
 #include "place_device.hpp"
 
 namespace epik_amd {
@@ -22,21 +24,33 @@ struct TeamEntry {
     static constexpr int kWords = team_entry_bytes(W) / 4;
     uint32_t line;
     uint32_t len[W];
-    __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key)
+    // the entry as it lies in HBM (kWords / 4 times 16 bytes), and its fields from that
+    static constexpr int kQuads = kWords / 4;
+    __device__ static __forceinline__ void fetch(const TeamParams &tp, uint32_t pass, uint32_t key, uint4 (&raw)[kQuads])
     {
         const uint4 *e = reinterpret_cast<const uint4 *>(tp.team_table + ((uint64_t)pass * tp.num_keys + key) * (kWords * 4u));
+#pragma unroll
+        for (int i = 0; i < kQuads; ++i) raw[i] = e[i];
+    }
+    __device__ __forceinline__ void unpack(const uint4 (&raw)[kQuads])
+    {
         uint32_t w[kWords];
 #pragma unroll
-        for (int i = 0; i < kWords / 4; ++i) {
-            const uint4 v = e[i];
-            w[4 * i] = v.x;
-            w[4 * i + 1] = v.y;
-            w[4 * i + 2] = v.z;
-            w[4 * i + 3] = v.w;
+        for (int i = 0; i < kQuads; ++i) {
+            w[4 * i] = raw[i].x;
+            w[4 * i + 1] = raw[i].y;
+            w[4 * i + 2] = raw[i].z;
+            w[4 * i + 3] = raw[i].w;
         }
         line = w[0];
 #pragma unroll
         for (int s = 0; s < W; ++s) len[s] = (w[1 + s / 2] >> (16 * (s & 1))) & 0xffffu;
+    }
+    __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key)
+    {
+        uint4 raw[kQuads];
+        fetch(tp, pass, key, raw);
+        unpack(raw);
     }
     // byte offset of sublist s in the posting region
     __device__ __forceinline__ uint64_t start(int s) const
@@ -50,7 +64,9 @@ struct TeamEntry {
 };
 
 // The slice of the branch range one wave of a team accumulates (see WaveCtx in place_device.hpp).
-template <int W>
+// kGlobalOut: the slice's results go to HBM (team_stream_kernel: a kernel of its own merges them) instead of
+// the workgroup's merge area in LDS.
+template <int W, bool kGlobalOut = false>
 struct TeamCtx {
     static constexpr bool kTeam = true;
     static constexpr uint32_t kCandCap = kTeamCandCap;  // top-k candidates of a slice: at most one per lane
@@ -60,19 +76,10 @@ struct TeamCtx {
     __device__ __forceinline__ uint32_t kmer_size(const PlaceParams &) const { return kmer_size_; }
     __device__ __forceinline__ float log_threshold(const PlaceParams &) const { return log_threshold_; }
     __device__ __forceinline__ uint32_t keep_at_most(const PlaceParams &) const { return keep_; }
-    lds_u32x4 *cand;       // [keep_at_most] ranked rows of this slice for the merge
-    lds_partial *partial;  // this slice's share of sum_scores
-    // team_stream_kernel: the merge area may still be read by the merge of the workgroup's previous read;
-    // merged_ counts the finished merges and must have reached need_ before the slice publishes (null: the
-    // caller's barriers see to it)
-    lds_u32 *merged_ = nullptr;
-    uint32_t need_ = 0;
-    __device__ __forceinline__ void before_publish() const
-    {
-        if (merged_)
-            while ((int32_t)(__hip_atomic_load((uint32_t *)merged_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - need_) < 0)
-                __builtin_amdgcn_s_sleep(1);
-    }
+    std::conditional_t<kGlobalOut, v4u *, lds_u32x4 *> cand;             // [keep_at_most] ranked rows of this slice for the merge
+    std::conditional_t<kGlobalOut, TeamPartial *, lds_partial *> partial;  // this slice's share of sum_scores
+    lds_u32 *trace_ = nullptr;  // diagnostic builds: the wave whose timeline is recorded has its counter here
+    __device__ __forceinline__ void before_publish() const {}
     template <typename Params>
     __device__ __forceinline__ uint32_t rows_pad(const Params &) const { return rows_pad_; }
     template <typename Params>
@@ -111,8 +118,9 @@ struct MergeParams {
     uint32_t *n_rows, *kmer_counts;
 };
 
-__device__ __attribute__((noinline)) void team_merge(MergeParams p, lds_u32x4 *cand, uint32_t cand_stride,
-                                                     lds_partial *partials, uint32_t n_slices, uint64_t read,
+template <typename CandPtr, typename PartialPtr>
+__device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand, uint32_t cand_stride,
+                                                     PartialPtr partials, uint32_t n_slices, uint64_t read,
                                                      uint64_t n_kmers)
 {
     const int lane = lane_id();

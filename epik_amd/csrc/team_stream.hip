@@ -5,7 +5,7 @@
 // team_place_kernel keeps three workgroups on a CU (a read's per-branch vectors fill the LDS), and each
 // of them walks through the phases of a read one after the other: characters -> classes -> table entries ->
 // chunk descriptors (four dependent trips to memory and two meetings of the waves) before the first posting
-// is fetched.  With twelve waves on a CU nothing hides that latency.  Here the placement is two kernels:
+// is fetched.  With twelve waves on a CU nothing hides that latency.  Here the placement is three kernels:
 //
 //   team_front_kernel   one WAVE per read, no per-branch vectors, so the CU is full of waves: encode
 //                       (i2l::to_kmers, place.cpp:294), lookup (phylo_kmer_db::search, :300) and the chunk
@@ -14,10 +14,11 @@
 //                       a header per read;
 //   team_stream_kernel  one workgroup per read as before, but a wave now only loads ITS slice's descriptor
 //                       list (coalesced, the header a read ahead), streams it into its rows (:349-371) and
-//                       runs the slice epilogue (:418-422, its share of :134-184).  The waves of a workgroup
-//                       never meet at a barrier: a slice that is done says so with an LDS counter, the wave
-//                       whose turn it is (read by read, in turn) merges the slices' results once all have,
-//                       and the others are already on the next read.
+//                       runs the slice epilogue (:418-422, its share of :134-184), whose results -- the
+//                       slice's best rows and its share of sum_scores -- go to HBM.  The waves of a
+//                       workgroup share nothing but the LDS allocation: no barrier, no counter;
+//   team_merge_kernel   one wave per read: the slices' rows ranked together, sum_scores, like-weight
+//                       ratios, filter, rows out (:164-199, :241-264).
 //
 // A read whose descriptors did not fit the pool is put on a list and placed by team_place_kernel afterwards.
 // The arithmetic and its order are those of the other kernels: every branch receives its float32 adds from
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint64_t null_desc = null_chunk(p);
     constexpr int T = kTilesPerPass;
+    __shared__ uint4 held_all[4][T * TeamEntry<W>::kQuads * kWave];  // per wave: the entries of a short read's tiles, by lane
+    uint4 *held = held_all[threadIdx.x >> 6];
     unsigned long long chunk_at = 0;  // this wave's piece of the pool: next free descriptor, how many are left
     uint32_t chunk_left = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) tp.front_cursor[2] = p.n_reads;  // (the host sizes the next launch's pool by it)
@@ -84,13 +87,6 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
             return exact;
         };
         const bool one_group = tp.passes == 1 && n_kmers <= (uint64_t)T * stride;  // wave-uniform
-        TeamEntry<W> held[T];  // one_group: the entries of the read's tiles
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            held[t].line = 0;
-#pragma unroll
-            for (int s = 0; s < W; ++s) held[t].len[s] = 0;
-        }
         // ---- chunks per slice -------------------------------------------------------------------------
         if (one_group) {
             uint32_t ch[T], cls[T];
@@ -101,15 +97,25 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
             uint32_t acc[W];
 #pragma unroll
             for (int s = 0; s < W; ++s) acc[s] = 0;
+            // the entries wait in LDS for the second half (in registers, unrolled over tiles and slices, they
+            // cost the kernel three quarters of its waves)
+            uint4 raw[T][TeamEntry<W>::kQuads];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = make_uint4(0u, 0u, 0u, 0u);
                 const Tile tl = tile_from_class(cls[t], len, (uint64_t)t * stride, n_kmers, k, sigma, stride);
-                if (exact_windows(tl)) held[t].load(tp, 0u, tl.key);
+                if (exact_windows(tl)) TeamEntry<W>::fetch(tp, 0u, tl.key, raw[t]);
             }
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int t = 0; t < T; ++t) {
+                TeamEntry<W> e;
+                e.unpack(raw[t]);
 #pragma unroll
-                for (int s = 0; s < W; ++s) acc[s] += (held[t].len[s] + (uint32_t)kWave - 1u) >> 6;
+                for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+#pragma unroll
+                for (int q = 0; q < TeamEntry<W>::kQuads; ++q) held[(t * TeamEntry<W>::kQuads + q) * kWave + lane] = raw[t][q];
+            }
 #pragma unroll
             for (int s = 0; s < W; ++s) {
                 const uint32_t total = wave_sum_u32(acc[s]);
@@ -204,10 +210,16 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
             for (int s = 0; s < W; ++s)
                 run[s] = __builtin_amdgcn_readlane(first_of_slice, (int)kFrontHdrWords + (int)(pass * W) + s);
             if (one_group) {
+#pragma unroll 1
+                for (int t = 0; t < T; ++t) {
+                    uint4 raw[TeamEntry<W>::kQuads];
 #pragma unroll
-                for (int t = 0; t < T; ++t)
+                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[q] = held[(t * TeamEntry<W>::kQuads + q) * kWave + lane];
+                    TeamEntry<W> e;
+                    e.unpack(raw);
 #pragma unroll
-                    for (int s = 0; s < W; ++s) run[s] += write_sublists(held[t].len[s], held[t].start(s), run[s]);
+                    for (int s = 0; s < W; ++s) run[s] += write_sublists(e.len[s], e.start(s), run[s]);
+                }
             } else {
                 for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
                     const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
@@ -232,8 +244,10 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
 }
 
 // ---------------------------------------------------------------------------------
-// Stream + epilogue + merge.  LDS as team_place_kernel's: the W slices' rows | the W descriptor lists |
-// four counters (where the other kernel keeps its tile totals) | partial sums | the slices' ranked rows.
+// Stream + slice epilogue.  LDS: the W slices' rows | the W descriptor lists (a wave's list also holds its
+// top-k candidates and, with 8-bit counts, the "seen" bits of the ambiguous sweep).  A wave takes slice
+// `wave` of reads blockIdx.x, blockIdx.x + gridDim.x, ... and shares nothing with the other waves of its
+// workgroup: no barrier, no counter.
 // ---------------------------------------------------------------------------------
 template <int W, typename CountT>
 __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_kernel(TeamParams tp)
@@ -249,34 +263,34 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
     lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave * tp.slice_bytes);
     lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave * tp.slice_bytes + (size_t)rows_pad * 4);
     lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave * tp.desc_bytes);
-    lds_u32 *sync = (lds_u32 *)reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes);
-    lds_u32 *done = sync;        // slice epilogues finished so far, over all the workgroup's reads
-    lds_u32 *merged = sync + 1;  // merges finished so far
-    lds_partial *partials = (lds_partial *)reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4);
     const uint32_t n_slices = W * tp.passes;
-    lds_u32x4 *merge_cand = (lds_u32x4 *)reinterpret_cast<v4u *>(reinterpret_cast<TeamPartial *>(reinterpret_cast<uint32_t *>(desc_base + (size_t)W * tp.desc_bytes) + W * W + 4) + n_slices);
-    const uint32_t merge_stride = p.keep_at_most;
     const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
     const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
                                                               (rows_pad - 1u) * (uint32_t)sizeof(CountT));
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // = &tp.base
     for (uint32_t i = lane; i < rows_pad; i += kWave) lds.store(i, 0u, 0u);
-    if (threadIdx.x < 4) sync[threadIdx.x] = 0u;
-    __syncthreads();  // the only one
 
     const uint32_t k = p.kmer_size;
+    const uint32_t keep = p.keep_at_most;
     const uint32_t cap = tp.desc_cap;  // descriptors per round (a multiple of the ring; + one trip of spare entries <= 64)
     const uint64_t null_desc = null_chunk(p);
-    uint32_t gen = 0;  // reads this workgroup has merged or is about to: the same in all its waves
+    v4u *rows_out = static_cast<v4u *>(tp.slice_rows_out);
+    TeamPartial *sums_out = static_cast<TeamPartial *>(tp.slice_sums_out);
 #ifdef EPIK_AMD_ABLATION
-    // where the waves spend their time: cycles per (wave, phase), EPIK_AMD_STAMPS=1
-    unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long dbg_last = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    // the timeline of one wave (wave 1 of workgroup 0), EPIK_AMD_STAMPS=1: see EPI_STAMP in place_device.hpp
+    // (its counter sits in the last entry of the wave's own descriptor list, which no round reaches: cap + ring
+    // entries are used, the list has one more only when keep_at_most is large -- diagnostic builds only)
+    __shared__ uint32_t trace_counter;
+    lds_u32 *trace = (p.dbg && blockIdx.x == 0 && wave == 1) ? (lds_u32 *)&trace_counter : nullptr;
+    if (trace && lane == 0) *trace = 0u;
 #define STREAM_STAMP(k)                                                  \
-    if (p.dbg) {                                                         \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
-        dbg_t[k] += now_ - dbg_last;                                     \
-        dbg_last = now_;                                                 \
+    if (trace && lane == 0) {                                            \
+        const uint32_t i_ = *trace;                                      \
+        *trace = i_ + 1u;                                                \
+        if (i_ < 100000u) {                                              \
+            p.dbg[64 + 2 * (size_t)i_] = 100ull + (k);                   \
+            p.dbg[65 + 2 * (size_t)i_] = __builtin_amdgcn_s_memtime();   \
+        }                                                                \
     }
 #else
 #define STREAM_STAMP(k)
@@ -323,31 +337,31 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
         word_cur = word_next;
         desc_cur = read + gridDim.x < p.n_reads ? first_round(word_cur) : null_desc;
         if (read + 2ull * gridDim.x < p.n_reads) word_next = load_header(read + 2ull * gridDim.x);
+        STREAM_STAMP(9)  // next read
         const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
         // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than this
-        // launch's counts hold is marked (the caller chose the count width).  Uniform over the workgroup.
-        if (flags & (kFrontNoRows | kFrontTooNarrow)) {
-            if (threadIdx.x == 0) p.n_rows[read] = (flags & kFrontNoRows) ? 0u : kCountsTooNarrow;
-            continue;
-        }
-        if (flags & kFrontSlow) continue;  // team_place_kernel places it after this launch
+        // launch's counts hold is marked (the caller chose the count width).  team_merge_kernel writes both.
+        // A read whose descriptors are not in the pool is placed by team_place_kernel after this launch.
+        if (flags & (kFrontNoRows | kFrontTooNarrow | kFrontSlow)) continue;
         const uint64_t len = __builtin_amdgcn_readlane(word, 2);
         const uint64_t n_kmers = len - k + 1;  // :322
 
         for (uint32_t pass = 0; pass < tp.passes; ++pass) {
-            TeamCtx<W> ctx;
+            TeamCtx<W, true> ctx;
             ctx.rows_pad_ = rows_pad;
             ctx.kmer_size_ = k;
-            ctx.keep_ = p.keep_at_most;
+            ctx.keep_ = keep;
             ctx.log_threshold_ = p.log_threshold;
             ctx.slice_ = wave;
             ctx.pass_ = pass;
             ctx.base_ = (pass * W + wave) * tp.slice_rows;
             ctx.rows_ = ctx.base_ >= p.num_branches ? 0u : min(tp.slice_rows, p.num_branches - ctx.base_);
-            ctx.cand = merge_cand + (size_t)(pass * W + wave) * merge_stride;
-            ctx.partial = partials + (pass * W + wave);
-            ctx.merged_ = merged;  // the previous read's merge must be over before this slice publishes
-            ctx.need_ = gen;
+            const uint64_t slice_at = read * n_slices + pass * W + wave;
+            ctx.cand = rows_out + slice_at * keep;
+            ctx.partial = sums_out + slice_at;
+#ifdef EPIK_AMD_ABLATION
+            ctx.trace_ = trace;
+#endif
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
             uint32_t my_padded;
             const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded);
@@ -370,7 +384,8 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
                 place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, (int64_t)-1, ctx);
             }
             STREAM_STAMP(2)  // ambiguous k-mers
-            // ---- correction, the slice's best rows and share of sum_scores, reset of the rows -------------
+            // ---- correction, the slice's best rows and share of sum_scores (to HBM: team_merge_kernel),
+            //      reset of the rows
             if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
 #ifdef EPIK_AMD_ABLATION
             if (p.ablate & 2u) {  // (timing experiments: no slice epilogue)
@@ -379,37 +394,44 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
             }
 #endif
             place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
-            STREAM_STAMP(3)  // slice epilogue (with the wait for the previous merge)
+            STREAM_STAMP(3)  // slice epilogue
         }
-        // ---- this wave's slices are in the merge area ------------------------------------------------------
-        if (lane == 0) __hip_atomic_fetch_add((uint32_t *)done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (wave == gen % (uint32_t)W) {  // its turn: merge once every wave is through
-            const uint32_t need = (gen + 1u) * (uint32_t)W;
-            while ((int32_t)(__hip_atomic_load((uint32_t *)done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - need) < 0)
-                __builtin_amdgcn_s_sleep(1);
-            STREAM_STAMP(4)  // waiting for the other slices
-            MergeParams mp;
-            mp.keep_at_most = p.keep_at_most;
-            mp.kmer_size = k;
-            mp.num_branches = p.num_branches;
-            mp.log_threshold = p.log_threshold;
-            mp.keep_factor = p.keep_factor;
-            mp.rows = p.rows;
-            mp.n_rows = p.n_rows;
-            mp.kmer_counts = p.kmer_counts;
-#ifdef EPIK_AMD_ABLATION
-            if (!(p.ablate & 4u))  // (timing experiments: no merge)
-#endif
-            team_merge(mp, merge_cand, merge_stride, partials, n_slices, read, n_kmers);
-            if (lane == 0) __hip_atomic_fetch_add((uint32_t *)merged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            STREAM_STAMP(5)  // merge
-        }
-        ++gen;
     }
-#ifdef EPIK_AMD_ABLATION
-    if (p.dbg && lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&p.dbg[wave * 8 + i], dbg_t[i]);
-#endif
+}
+
+// ---------------------------------------------------------------------------------
+// The merge: one wave per read ranks the slices' rows together and finishes the placement (team_merge:
+// sum_scores :164-184 from the partial sums, like-weight-ratios :241-264, filter_by_ratio :188-199, rows out).
+// In the streaming kernel, by one of the read's four waves, it was a fifth of the read's time.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void team_merge_kernel(TeamParams tp, uint32_t n_slices)
+{
+    const PlaceParams &p = tp.base;
+    const int lane = lane_id();
+    const uint64_t waves_per_block = blockDim.x >> 6;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    MergeParams mp;
+    mp.keep_at_most = p.keep_at_most;
+    mp.kmer_size = p.kmer_size;
+    mp.num_branches = p.num_branches;
+    mp.log_threshold = p.log_threshold;
+    mp.keep_factor = p.keep_factor;
+    mp.rows = p.rows;
+    mp.n_rows = p.n_rows;
+    mp.kmer_counts = p.kmer_counts;
+    v4u *rows_out = static_cast<v4u *>(tp.slice_rows_out);  // (more than 64 slots: team_merge keeps the ranks in them)
+    TeamPartial *sums_out = static_cast<TeamPartial *>(tp.slice_sums_out);
+    for (uint64_t read = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); read < p.n_reads; read += n_waves) {
+        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
+        const uint32_t flags = hdr[1], len = hdr[2];
+        if (flags & kFrontSlow) continue;  // team_place_kernel's
+        if (flags & (kFrontNoRows | kFrontTooNarrow)) {
+            if (lane == 0) p.n_rows[read] = (flags & kFrontNoRows) ? 0u : kCountsTooNarrow;
+            continue;
+        }
+        team_merge(mp, rows_out + read * n_slices * p.keep_at_most, p.keep_at_most, sums_out + read * n_slices, n_slices,
+                   read, (uint64_t)len - p.kmer_size + 1u);
+    }
 }
 
 namespace {
@@ -448,6 +470,12 @@ hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 
         hipLaunchKernelGGL((team_stream_kernel<W, C>), grid, dim3(W * 64), lds_bytes, stream, tp);
         return hipGetLastError();
     });
+}
+
+hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(team_merge_kernel, grid, dim3(256), 0, stream, tp, (uint32_t)waves * tp.passes);
+    return hipGetLastError();
 }
 
 hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whole CU: see place_kernel.hip)

@@ -49,6 +49,7 @@ def main():
         if "kernel" in kv:
             os.environ["EPIK_AMD_KERNEL"] = kv["kernel"]
         os.environ["EPIK_AMD_TEAM_FRONT"] = kv.get("front", "1")
+        os.environ["EPIK_AMD_GRID_PERCENT"] = kv.get("grid", "100")
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
         desc = capi.PlacerDesc(
             abi_version=capi.ABI_VERSION, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
