@@ -149,8 +149,12 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
                 (void)hipMemcpy(tr.data(), p->params.dbg + 64, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                 if (const char *path = std::getenv("EPIK_AMD_TRACE_FILE")) {
                     if (FILE *f = std::fopen(path, "w")) {
-                        for (size_t i = 1; i < 100000 && tr[2 * i + 1] != 0; ++i)
-                            std::fprintf(f, "%llu %llu\n", tr[2 * i], tr[2 * i + 1] - tr[2 * i - 1]);
+                        unsigned long long last = tr[1];  // (entries a call did not reach stay 0)
+                        for (size_t i = 1; i < 100000; ++i) {
+                            if (tr[2 * i + 1] == 0) continue;
+                            std::fprintf(f, "%llu %llu\n", tr[2 * i], tr[2 * i + 1] - last);
+                            last = tr[2 * i + 1];
+                        }
                         std::fclose(f);
                     }
                 }

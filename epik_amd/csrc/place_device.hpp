@@ -718,13 +718,12 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
     const PlaceParams &p = *kp;
     const int lane = lane_id();
 #ifdef EPIK_AMD_ABLATION
-    // A timeline of ONE wave (the caller points ctx.trace_ at an LDS counter for it; EPIK_AMD_STAMPS=1): {code,
+    // A timeline of ONE wave (the caller gives it ten entries from ctx.trace_at_ on; EPIK_AMD_STAMPS=1): {code,
     // s_memtime} pairs into dbg[64 ..], nothing from any other wave.
 #define EPI_STAMP(k)                                                                   \
     if constexpr (Ctx::kTeam) {                                                        \
-        if (ctx.trace_ && lane == 0) {                                                 \
-            const uint32_t i_ = *ctx.trace_;                                           \
-            *ctx.trace_ = i_ + 1u;                                                     \
+        if (ctx.trace_at_ != 0xffffffffu && lane == 0) {                               \
+            const uint32_t i_ = ctx.trace_at_ + ((k) == 10 ? 0u : (uint32_t)(k) + 1u); \
             if (i_ < 100000u) {                                                        \
                 p.dbg[64 + 2 * (size_t)i_] = (unsigned long long)(k);                  \
                 p.dbg[65 + 2 * (size_t)i_] = __builtin_amdgcn_s_memtime();             \
@@ -736,9 +735,15 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
 #endif
     typedef WaveLds<CountT> Lds_t;
     EPI_STAMP(10)  // entered
-    const uint32_t N = ctx.rows(p);
-    const float k_f = (float)ctx.kmer_size(p);
-    const float log_thr = ctx.log_threshold(p);
+    // The arguments of an out-of-line function arrive in vector registers, and whatever is computed from
+    // them counts as divergent: every loop over the rows and every test below would be compiled with exec
+    // masks.  They are the same in all lanes; readfirstlane says so (scalar loops, scalar branches).
+    auto uniform = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    n_kmers = ((uint64_t)uniform((uint32_t)(n_kmers >> 32)) << 32) | uniform((uint32_t)n_kmers);
+    const uint32_t N = uniform(ctx.rows(p));
+    const uint32_t kmer_size = uniform(ctx.kmer_size(p));
+    const float k_f = (float)kmer_size;
+    const float log_thr = __uint_as_float(uniform(__float_as_uint(ctx.log_threshold(p))));
     // ---- score correction (:418-422), dense over N --------------------------------------
     // score[i] becomes the corrected score (-inf = "not an edge"); count[i] keeps the count
     // (and the ambiguous path's flag bit).
@@ -754,7 +759,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         const float r = __fmaf_rn(-q, k_f, x);
         return __fmaf_rn(r, inv_k, q);
     };
-    const bool fast_div = ctx.kmer_size(p) <= 32u;
+    const bool fast_div = kmer_size <= 32u;
     uint32_t touched = 0;           // wave-uniform: counted with ballots
     float lane_best_f = -INFINITY;  // this lane's best score
     // The sweeps run over the padded rows [0, n_pad), n_pad a multiple of 16: cells behind N hold
@@ -762,7 +767,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
     // bounds test.  Four consecutive rows per lane (one 16-byte LDS access), 256 rows per trip; the
     // arithmetic is branch-free.
     constexpr int kUnroll = 4;
-    const uint32_t n_rows_pad = ctx.rows_pad(p);
+    const uint32_t n_rows_pad = uniform(ctx.rows_pad(p));
     // A trip in two halves -- the LDS reads, then everything else -- so that the loop can ask for the next
     // trip's rows before it works on this one's (the wave would otherwise sit out an LDS round trip per trip).
     struct Trip {
@@ -781,8 +786,9 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         if (kWhole || i0 < n_rows_pad) lds.load4_packed(i0, t.raw, t.words);
         return t;
     };
-    auto correct_rows = [&](auto whole, uint32_t base, const Trip &t) {
+    auto correct_rows = [&](auto whole, auto fast, uint32_t base, const Trip &t) {
         constexpr bool kWhole = decltype(whole)::value;
+        constexpr bool kFastDiv = decltype(fast)::value;  // k <= 32: the three-instruction division
         constexpr int kRows = kUnroll;
         const uint32_t i0 = base + 4u * (uint32_t)lane;
         const bool mine = kWhole || i0 < n_rows_pad;
@@ -808,12 +814,12 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
 #pragma unroll
         for (int u = 0; u < kRows; ++u) {
             pre[u] = __fadd_rn(t.raw[u], __fmul_rn(missing[u], log_thr));  // :420
-            s[u] = div_k(pre[u]);                                           // :421
+            s[u] = kFastDiv ? div_k(pre[u]) : __fdiv_rn(pre[u], k_f);       // :421
             // (rows without a k-mer take part too: theirs is nk * log_thr, tiny only if log_thr is 0 --
             // then the exact division below runs, which is as right and only slower)
             smallest = fminf(smallest, fabsf(pre[u]));
         }
-        if (!fast_div || __ballot(smallest < 0x1p-100f) != 0) {  // wave-uniform, practically never
+        if (kFastDiv && __builtin_expect(__ballot(smallest < 0x1p-100f) != 0, 0)) {  // wave-uniform, practically never
 #pragma unroll
             for (int u = 0; u < kRows; ++u) s[u] = __fdiv_rn(pre[u], k_f);
         }
@@ -824,22 +830,33 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             lane_best_f = fmaxf(lane_best_f, s[u]);
         }
         if (mine) lds.store_scores4(i0, s);  // the count cells stay as they are
-        EPI_STAMP(20)  // one trip of the correction sweep
     };
-    {
+    auto correction_sweep = [&](auto fast) {
         constexpr uint32_t kTripRows = kUnroll * kWave;
         const uint32_t whole_trips = n_rows_pad / kTripRows;
         uint32_t base = 0;
         if (whole_trips) {
-            Trip next = load_trip(std::true_type{}, 0u);
-            for (uint32_t trip = 0; trip < whole_trips; ++trip, base += kTripRows) {
-                const Trip cur = next;
-                if (trip + 1 < whole_trips) next = load_trip(std::true_type{}, base + kTripRows);
-                correct_rows(std::true_type{}, base, cur);
+            // two trips per turn, each in registers of its own: the rows of one are on their way while the
+            // other is worked on, and nothing is copied
+            Trip a = load_trip(std::true_type{}, 0u);
+            uint32_t trip = 0;
+            for (; trip + 2 <= whole_trips; trip += 2, base += 2 * kTripRows) {
+                const Trip b = load_trip(std::true_type{}, base + kTripRows);
+                correct_rows(std::true_type{}, fast, base, a);
+                if (trip + 2 < whole_trips) a = load_trip(std::true_type{}, base + 2 * kTripRows);
+                correct_rows(std::true_type{}, fast, base + kTripRows, b);
+            }
+            if (trip < whole_trips) {
+                correct_rows(std::true_type{}, fast, base, a);
+                base += kTripRows;
             }
         }
-        if (base < n_rows_pad) correct_rows(std::false_type{}, base, load_trip(std::false_type{}, base));
-    }
+        if (base < n_rows_pad) correct_rows(std::false_type{}, fast, base, load_trip(std::false_type{}, base));
+    };
+    if (fast_div)
+        correction_sweep(std::true_type{});
+    else
+        correction_sweep(std::false_type{});
     EPI_STAMP(0)  // correction sweep
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
     const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
@@ -853,7 +870,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
     // with the relative terms in float32 (v_exp_f32): ~1e-7 relative on score_sum, i.e. on
     // every like_weight_ratio (bar: 1e-5).  Row scores and 10^ref_score stay in double, and
     // so does everything when 10^ref_score could underflow (the score_sum == 0 rule, :243-251).
-    const uint32_t keep = ctx.keep_at_most(p);
+    const uint32_t keep = uniform(ctx.keep_at_most(p));
     auto *cand = reinterpret_cast<typename WaveLds<CountT>::u32x2_t *>(lds.desc);  // {ord(score), branch}
     constexpr uint32_t kCandCap = Ctx::kCandCap;  // top-k candidates the wave's descriptor list holds
     constexpr int kQ = (int)((kCandCap + kWave - 1) / kWave);  // ... per lane
@@ -877,7 +894,6 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
                 tau = 1;
                 break;
             }
-            EPI_STAMP(21)  // one round of tau
             if (got == 0) top = m;
             got += (uint32_t)__popcll(__ballot(cur == m));
             tau = m;
@@ -935,11 +951,17 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             const uint32_t whole_trips = n_rows_pad / kTripRows;
             uint32_t base = 0;
             if (whole_trips) {
-                Rows next = load_rows(std::true_type{}, 0u);
-                for (uint32_t trip = 0; trip < whole_trips; ++trip, base += kTripRows) {
-                    const Rows cur = next;
-                    if (trip + 1 < whole_trips) next = load_rows(std::true_type{}, base + kTripRows);
-                    scan_rows(base, cur);
+                Rows a = load_rows(std::true_type{}, 0u);  // two trips per turn, as in the correction sweep
+                uint32_t trip = 0;
+                for (; trip + 2 <= whole_trips; trip += 2, base += 2 * kTripRows) {
+                    const Rows b = load_rows(std::true_type{}, base + kTripRows);
+                    scan_rows(base, a);
+                    if (trip + 2 < whole_trips) a = load_rows(std::true_type{}, base + 2 * kTripRows);
+                    scan_rows(base + kTripRows, b);
+                }
+                if (trip < whole_trips) {
+                    scan_rows(base, a);
+                    base += kTripRows;
                 }
             }
             if (base < n_rows_pad) scan_rows(base, load_rows(std::false_type{}, base));

@@ -78,7 +78,7 @@ struct TeamCtx {
     __device__ __forceinline__ uint32_t keep_at_most(const PlaceParams &) const { return keep_; }
     std::conditional_t<kGlobalOut, v4u *, lds_u32x4 *> cand;             // [keep_at_most] ranked rows of this slice for the merge
     std::conditional_t<kGlobalOut, TeamPartial *, lds_partial *> partial;  // this slice's share of sum_scores
-    lds_u32 *trace_ = nullptr;  // diagnostic builds: the wave whose timeline is recorded has its counter here
+    uint32_t trace_at_ = 0xffffffffu;  // diagnostic builds: the wave whose timeline is recorded writes its next entries here
     __device__ __forceinline__ void before_publish() const {}
     template <typename Params>
     __device__ __forceinline__ uint32_t rows_pad(const Params &) const { return rows_pad_; }

@@ -278,19 +278,15 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
     TeamPartial *sums_out = static_cast<TeamPartial *>(tp.slice_sums_out);
 #ifdef EPIK_AMD_ABLATION
     // the timeline of one wave (wave 1 of workgroup 0), EPIK_AMD_STAMPS=1: see EPI_STAMP in place_device.hpp
-    // (its counter sits in the last entry of the wave's own descriptor list, which no round reaches: cap + ring
-    // entries are used, the list has one more only when keep_at_most is large -- diagnostic builds only)
-    __shared__ uint32_t trace_counter;
-    lds_u32 *trace = (p.dbg && blockIdx.x == 0 && wave == 1) ? (lds_u32 *)&trace_counter : nullptr;
-    if (trace && lane == 0) *trace = 0u;
-#define STREAM_STAMP(k)                                                  \
-    if (trace && lane == 0) {                                            \
-        const uint32_t i_ = *trace;                                      \
-        *trace = i_ + 1u;                                                \
-        if (i_ < 100000u) {                                              \
-            p.dbg[64 + 2 * (size_t)i_] = 100ull + (k);                   \
-            p.dbg[65 + 2 * (size_t)i_] = __builtin_amdgcn_s_memtime();   \
-        }                                                                \
+    const bool traced = p.dbg && blockIdx.x == 0 && wave == 1;
+    uint32_t trace_at = 0;
+#define STREAM_STAMP(k)                                                       \
+    if (traced) {                                                             \
+        if (lane == 0 && trace_at < 100000u) {                                \
+            p.dbg[64 + 2 * (size_t)trace_at] = 100ull + (k);                  \
+            p.dbg[65 + 2 * (size_t)trace_at] = __builtin_amdgcn_s_memtime();  \
+        }                                                                     \
+        ++trace_at;                                                           \
     }
 #else
 #define STREAM_STAMP(k)
@@ -359,9 +355,6 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
             const uint64_t slice_at = read * n_slices + pass * W + wave;
             ctx.cand = rows_out + slice_at * keep;
             ctx.partial = sums_out + slice_at;
-#ifdef EPIK_AMD_ABLATION
-            ctx.trace_ = trace;
-#endif
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
             uint32_t my_padded;
             const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded);
@@ -392,6 +385,9 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
                 lds.clear(rows_pad);
                 continue;
             }
+#endif
+#ifdef EPIK_AMD_ABLATION
+            if (traced) ctx.trace_at_ = trace_at, trace_at += 10;  // the epilogue's entries
 #endif
             place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
             STREAM_STAMP(3)  // slice epilogue
