@@ -91,8 +91,11 @@ struct epik_amd_placer {
         uint32_t lds_block_bytes = 0;
         uint32_t max_blocks = 0;
         uint32_t resident_waves = 0;  // per CU
+        // team_stream_kernel (team placement as front + streaming + merge kernels): workgroups of 4 waves
+        uint32_t stream_lds_bytes = 0, stream_blocks = 0;
     } geo[3];
     uint32_t last_blocks = 0;
+    bool last_streamed = false;  // the last launch went through team_stream_kernel
     uint32_t last_geo = 0;
     // staging buffers for the host-pointer entry point (grown on demand)
     uint8_t *d_seqs = nullptr;
@@ -443,15 +446,21 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
             // larger than team_place_kernel holds at once only queues -- that kernel then gets the few reads
             // the front kernel left it, or the launches of a k-mer-space shard, which size their own)
             int by_query = 0;
-            if (p->team_front) {
-                CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts));
-                CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
-            } else {
-                CREATE_TRY(epik_amd::team_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
-            }
+            CREATE_TRY(epik_amd::team_occupancy(plan.team_waves, counts, g.lds_block_bytes, &by_query));
             per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(per_cu, (uint32_t)std::max(by_query, 1)));
             g.max_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
             g.resident_waves = per_cu * (uint32_t)plan.team_waves;
+            if (p->team_front) {
+                // the streaming kernel: its own workgroups (4 waves), LDS and registers; the grid a multiple of
+                // the workgroups that share a read
+                g.stream_lds_bytes = (uint32_t)epik_amd::stream_lds_bytes(g.lds_wave_bytes, desc_bytes);
+                uint32_t stream_per_cu = epik_amd::stream_resident_blocks(plan.team_waves, g.stream_lds_bytes);
+                CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts));
+                CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, g.stream_lds_bytes, &by_query));
+                stream_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(stream_per_cu, (uint32_t)std::max(by_query, 1)));
+                const uint32_t parts = (uint32_t)plan.team_waves / (uint32_t)epik_amd::kStreamWaves;
+                g.stream_blocks = std::max(parts, (uint32_t)prop.multiProcessorCount * stream_per_cu / parts * parts);
+            }
         }
         if (p->team_front) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_front_cursor), 3 * sizeof(unsigned long long)));
@@ -727,6 +736,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     blocks = std::max<uint64_t>(1, blocks * p->grid_percent / 100u);
 #endif
     p->last_blocks = (uint32_t)blocks;
+    p->last_streamed = false;
     p->last_geo = (uint32_t)p->counts;
     const bool timed = p->timing && mode != kFinish;
     if (timed) HIP_TRY(hipEventRecord(p->ev_start, stream));
@@ -741,7 +751,8 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         tp.desc_cap = epik_amd::kTeamDescCap;
         tp.slice_bytes = g.lds_wave_bytes;
         tp.desc_bytes = epik_amd::team_desc_bytes(pp.keep_at_most);
-        if (mode == kPlace && p->team_front) {
+        // (the streaming kernel numbers a read's slices in 32 bits)
+        if (mode == kPlace && p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32)) {
             // front kernel (a wave per read), streaming kernel (a workgroup per read), and team_place_kernel
             // for the reads whose descriptors found the pool full
             if (const int rc = reserve_front(p, n, total_chars); rc != EPIK_AMD_OK) return rc;
@@ -756,8 +767,15 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
             const uint64_t front_blocks = std::min<uint64_t>((n + 3) / 4, (uint64_t)p->front_blocks);
             HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
-            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, dim3((unsigned)blocks), g.lds_block_bytes,
-                                                 stream));
+            const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
+            uint64_t stream_blocks = std::min<uint64_t>(n * parts, g.stream_blocks);
+#ifdef EPIK_AMD_ABLATION
+            stream_blocks = std::max<uint64_t>(parts, stream_blocks * p->grid_percent / 100u / parts * parts);
+#endif
+            p->last_blocks = (uint32_t)stream_blocks;
+            p->last_streamed = true;
+            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, dim3((unsigned)stream_blocks),
+                                                 g.stream_lds_bytes, stream));
             HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)front_blocks), stream));
             tp.read_list = p->d_slow_list;
             tp.read_list_count = p->d_front_cursor + 1;
@@ -1044,9 +1062,11 @@ int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_bl
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
     const auto &g = p->geo[p->last_geo];
-    if (waves_per_block) *waves_per_block = g.waves_per_block;
-    if (blocks) *blocks = p->last_blocks ? p->last_blocks : g.max_blocks;
-    if (lds_bytes) *lds_bytes = g.lds_block_bytes;
+    // (the team placement as front + streaming + merge kernels reports its streaming kernel)
+    const bool streaming = p->team && p->team_front && p->last_streamed;
+    if (waves_per_block) *waves_per_block = streaming ? (uint32_t)epik_amd::kStreamWaves : g.waves_per_block;
+    if (blocks) *blocks = p->last_blocks ? p->last_blocks : streaming ? g.stream_blocks : g.max_blocks;
+    if (lds_bytes) *lds_bytes = streaming ? g.stream_lds_bytes : g.lds_block_bytes;
     return EPIK_AMD_OK;
 }
 

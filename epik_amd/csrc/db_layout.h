@@ -86,6 +86,23 @@ constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes
     return (size_t)waves * slice_bytes + (size_t)waves * desc_bytes + ((size_t)waves * waves + 4) * 4 +
            (size_t)waves * passes * 24 + (size_t)waves * passes * keep * 16;
 }
+// team_stream_kernel (team_stream.hip): workgroups of kStreamWaves independent waves, each with one slice's rows
+// and descriptor list; with 8 slices per pass two workgroups share a read.  Compiled for 3 waves per SIMD with
+// 4 slices (a slice of a large tree leaves room for no more) and 5 with 8 (the slice epilogue needs 68 VGPRs,
+// the streaming loop fewer; only the cold ambiguous sweep spills).
+constexpr int kStreamWaves = 4;
+constexpr uint32_t stream_waves_per_simd(int slices_per_pass)
+{
+    return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : slices_per_pass == 4 ? 3u : 5u;
+}
+constexpr size_t stream_lds_bytes(uint32_t slice_bytes, uint32_t desc_bytes) { return (size_t)kStreamWaves * (slice_bytes + desc_bytes); }
+constexpr uint32_t stream_resident_blocks(int slices_per_pass, size_t lds_bytes)
+{
+    if (lds_bytes > kLdsPerCu) return 0;
+    const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
+    const uint32_t by_lds = 128u / (units ? units : 1u), by_regs = stream_waves_per_simd(slices_per_pass);
+    return by_lds < by_regs ? by_lds : by_regs;
+}
 constexpr uint32_t team_resident_blocks(int waves, size_t lds_bytes)
 {
     if (lds_bytes > kLdsPerCu) return 0;

@@ -243,26 +243,58 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
     }
 }
 
+// The slice epilogue, out of line, with everything it needs in at most 16 argument registers: a larger set
+// of arguments goes through the stack (scratch memory), a round trip to the caches at every call.
+struct SliceArgs {
+    uint32_t rows_pad, rows, base, kmer_size, keep;
+    float log_threshold;
+    uint32_t slice_at;  // read * slices + slice: where the slice's results go
+    uint32_t trace_at;  // diagnostic builds
+};
+template <int W, typename CountT>
+__device__ __attribute__((noinline)) void slice_epilogue(const TeamParams *__restrict__ ktp, WaveLds<CountT> lds,
+                                                         uint32_t n_kmers, SliceArgs a)
+{
+    TeamCtx<W, true> ctx;
+    ctx.rows_pad_ = a.rows_pad;
+    ctx.rows_ = a.rows;
+    ctx.base_ = a.base;
+    ctx.slice_ = ctx.pass_ = 0;  // (what the ambiguous sweep looks lists up by: not used here)
+    ctx.kmer_size_ = a.kmer_size;
+    ctx.keep_ = a.keep;
+    ctx.log_threshold_ = a.log_threshold;
+    ctx.cand = static_cast<v4u *>(ktp->slice_rows_out) + (uint64_t)a.slice_at * a.keep;
+    ctx.partial = static_cast<TeamPartial *>(ktp->slice_sums_out) + a.slice_at;
+    ctx.trace_at_ = a.trace_at;
+    place_epilogue_body<TeamChunks, CountT>(&ktp->base, lds, 0ull, (uint64_t)n_kmers, ctx);
+}
+
 // ---------------------------------------------------------------------------------
-// Stream + slice epilogue.  LDS: the W slices' rows | the W descriptor lists (a wave's list also holds its
-// top-k candidates and, with 8-bit counts, the "seen" bits of the ambiguous sweep).  A wave takes slice
-// `wave` of reads blockIdx.x, blockIdx.x + gridDim.x, ... and shares nothing with the other waves of its
-// workgroup: no barrier, no counter.
+// Stream + slice epilogue.  LDS: the rows of the workgroup's kStreamWaves slices | their descriptor lists (a
+// wave's list also holds its top-k candidates and, with 8-bit counts, the "seen" bits of the ambiguous sweep).
+// A wave takes one slice of every read of its workgroup and shares nothing with the other waves: no barrier,
+// no counter.  (A workgroup is four waves whatever the number of slices: what counts is how many waves a CU
+// holds, and with 8 slices per pass the slices are small enough for twenty.)
 // ---------------------------------------------------------------------------------
 template <int W, typename CountT>
-__global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_kernel(TeamParams tp)
+__global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef WaveLds<CountT> Lds;
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // W slices per pass, kStreamWaves waves per workgroup: W / kStreamWaves consecutive workgroups share a read
+    constexpr uint32_t kParts = W / kStreamWaves;
+    static_assert(W % kStreamWaves == 0, "slices per pass: a multiple of the workgroup's waves");
+    const uint32_t wave = (blockIdx.x % kParts) * kStreamWaves + wave_in_block;  // this wave's slice of a pass
+    const uint64_t first_read = blockIdx.x / kParts, read_stride = gridDim.x / kParts;  // (the grid is a multiple of kParts)
     const uint32_t rows_pad = tp.rows_pad;
     Lds lds;
-    unsigned char *desc_base = lds_raw + (size_t)W * tp.slice_bytes;
-    lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave * tp.slice_bytes);
-    lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave * tp.slice_bytes + (size_t)rows_pad * 4);
-    lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave * tp.desc_bytes);
+    unsigned char *desc_base = lds_raw + (size_t)kStreamWaves * tp.slice_bytes;
+    lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave_in_block * tp.slice_bytes);
+    lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave_in_block * tp.slice_bytes + (size_t)rows_pad * 4);
+    lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave_in_block * tp.desc_bytes);
     const uint32_t n_slices = W * tp.passes;
     const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
     const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
@@ -278,7 +310,7 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
     TeamPartial *sums_out = static_cast<TeamPartial *>(tp.slice_sums_out);
 #ifdef EPIK_AMD_ABLATION
     // the timeline of one wave (wave 1 of workgroup 0), EPIK_AMD_STAMPS=1: see EPI_STAMP in place_device.hpp
-    const bool traced = p.dbg && blockIdx.x == 0 && wave == 1;
+    const bool traced = p.dbg && blockIdx.x == 0 && wave_in_block == 1;
     uint32_t trace_at = 0;
 #define STREAM_STAMP(k)                                                       \
     if (traced) {                                                             \
@@ -322,17 +354,17 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
     };
     uint32_t word_cur = 0, word_next = 0;
     uint64_t desc_cur = null_desc;
-    if (blockIdx.x < p.n_reads) {
-        word_cur = load_header(blockIdx.x);
-        if ((uint64_t)blockIdx.x + gridDim.x < p.n_reads) word_next = load_header((uint64_t)blockIdx.x + gridDim.x);
+    if (first_read < p.n_reads) {
+        word_cur = load_header(first_read);
+        if (first_read + read_stride < p.n_reads) word_next = load_header(first_read + read_stride);
         desc_cur = first_round(word_cur);
     }
-    for (uint64_t read = blockIdx.x; read < p.n_reads; read += gridDim.x) {
+    for (uint64_t read = first_read; read < p.n_reads; read += read_stride) {
         const uint32_t word = word_cur;
         const uint64_t my_desc = desc_cur;
         word_cur = word_next;
-        desc_cur = read + gridDim.x < p.n_reads ? first_round(word_cur) : null_desc;
-        if (read + 2ull * gridDim.x < p.n_reads) word_next = load_header(read + 2ull * gridDim.x);
+        desc_cur = read + read_stride < p.n_reads ? first_round(word_cur) : null_desc;
+        if (read + 2ull * read_stride < p.n_reads) word_next = load_header(read + 2ull * read_stride);
         STREAM_STAMP(9)  // next read
         const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
         // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than this
@@ -386,10 +418,19 @@ __global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_stream_ke
                 continue;
             }
 #endif
+            SliceArgs args;
+            args.rows_pad = rows_pad;
+            args.rows = ctx.rows_;
+            args.base = ctx.base_;
+            args.kmer_size = k;
+            args.keep = keep;
+            args.log_threshold = p.log_threshold;
+            args.slice_at = (uint32_t)slice_at;  // (the host keeps reads * slices below 2^32 for this kernel)
+            args.trace_at = 0xffffffffu;
 #ifdef EPIK_AMD_ABLATION
-            if (traced) ctx.trace_at_ = trace_at, trace_at += 10;  // the epilogue's entries
+            if (traced) args.trace_at = trace_at, trace_at += 10;  // the epilogue's entries
 #endif
-            place_epilogue<TeamChunks, CountT>(kp, lds, read, n_kmers, ctx);
+            slice_epilogue<W, CountT>(reinterpret_cast<const TeamParams *>(kp), lds, (uint32_t)n_kmers, args);
             STREAM_STAMP(3)  // slice epilogue
         }
     }
@@ -463,7 +504,7 @@ hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 g
 hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
     return stream_dispatch(waves, counts, [&]<int W, typename C>() {
-        hipLaunchKernelGGL((team_stream_kernel<W, C>), grid, dim3(W * 64), lds_bytes, stream, tp);
+        hipLaunchKernelGGL((team_stream_kernel<W, C>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp);
         return hipGetLastError();
     });
 }
@@ -485,7 +526,7 @@ hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whol
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
 {
     return stream_dispatch(waves, counts, [&]<int W, typename C>() {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C>, W * 64, lds_bytes);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C>, kStreamWaves * 64, lds_bytes);
     });
 }
 
