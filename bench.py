@@ -197,8 +197,14 @@ def image_bytes(plan) -> int:
     return int(plan.table_bytes + plan.filter_bytes + plan.posting_bytes)
 
 
-def kernel_name(plan) -> str:
-    return f"team_place_kernel<{plan.team_waves}>" if plan.kernel == 1 else "place_reads_kernel"
+def kernel_name(plan, placing: bool = True) -> str:
+    """What the HIP events around a launch time: one kernel, or -- placing on a large tree -- the three
+    kernels of the team placement back to back on the stream (epik_amd/csrc/team_stream.hip)."""
+    if plan.kernel != 1:
+        return "place_reads_kernel"
+    if placing and os.environ.get("EPIK_AMD_TEAM_FRONT", "1") != "0" and plan.team_waves * plan.team_passes <= 61:
+        return f"team_front_kernel<{plan.team_waves}> + team_stream_kernel<{plan.team_waves}> + team_merge_kernel"
+    return f"team_place_kernel<{plan.team_waves}>"
 
 
 def main():
@@ -338,7 +344,7 @@ def main():
         return {"bound": "hbm+mall" if working_set <= 2 * MALL_BYTES else "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(workload_name), "working_set_bytes": working_set, "mall_bytes": MALL_BYTES,
-                "kernel": kernel_name(pl_plan), "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": kernel_name(pl_plan, not kmer_shard), "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_read": alg_bytes / n}
 
     if rank == 0:

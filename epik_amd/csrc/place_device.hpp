@@ -887,18 +887,23 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         ranked_in_place = true;
     } else {
         n_sel = keep < touched ? keep : touched;  // :137
-        uint32_t cur = lane_best, got = 0, top = 0;
-        while (got < n_sel) {
-            const uint32_t m = wave_max_u32(cur);
-            if (m == 0) {  // fewer lanes hold edges than rows wanted: every edge is a candidate
-                tau = 1;
-                break;
-            }
-            if (got == 0) top = m;
-            got += (uint32_t)__popcll(__ballot(cur == m));
-            tau = m;
-            if (cur == m) cur = 0;
+        // tau = the n_sel-th largest of the 64 lane maxima (1 if fewer lanes than that hold an edge: every
+        // edge is a candidate), found bit by bit from the top: one comparison and a ballot per bit, the rest
+        // scalar.  Scores of one read lie close together, so the search usually starts below the bits they
+        // share with the largest one.  (Seven rounds of wave maximum + knock-out took three times as long.)
+        const uint32_t top = wave_max_u32(lane_best);  // != 0: touched != 0
+        uint32_t prefix = 0;
+        int bit = 31;
+        {
+            constexpr int kShared = 20;  // try: everything above the low 20 bits as in `top`
+            const uint32_t trial = top & ~((1u << kShared) - 1u);
+            if (trial != 0 && (uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial, bit = kShared - 1;
         }
+        for (; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            if ((uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial;
+        }
+        tau = prefix ? prefix : 1u;
         best_score = unord_f32(top);
     }
     EPI_STAMP(1)  // tau

@@ -77,13 +77,15 @@ def main():
         "other_workloads_same_sources": {},
         "previous": old.get("previous", {}),
     }
-    for name, kern, f, out in (("k=11 database (1.13 GB on the device)", "place_reads_kernel", "pmc_summary_k11.txt",
-                                "r02_pmc_summary_k11.txt"),
-                               ("N=9999 tree, team kernel", "team_place_kernel", "pmc_summary_n9999.txt",
-                                "r02_pmc_summary_n9999_team.txt")):
-        cc = counters(os.path.join(src, f), kern)
-        doc["other_workloads_same_sources"][name] = {"hbm_bytes_per_launch": cc["TCC_EA0_RDREQ_128B_sum"] * 128.0,
-                                                      "l2_hit_rate": cc["TCC_HIT_sum"] / cc["TCC_REQ_sum"],
+    for name, kerns, f, out in (("k=11 database (1.13 GB on the device)", ("place_reads_kernel",), "pmc_summary_k11.txt",
+                                 "r02_pmc_summary_k11.txt"),
+                                ("N=9999 tree, team placement (front + streaming + merge kernels, summed)",
+                                 ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"), "pmc_summary_n9999.txt",
+                                 "r02_pmc_summary_n9999_team.txt")):
+        per_kernel = [counters(os.path.join(src, f), kern) for kern in kerns]
+        total = lambda key: sum(c.get(key, 0.0) for c in per_kernel)  # noqa: E731
+        doc["other_workloads_same_sources"][name] = {"hbm_bytes_per_launch": total("TCC_EA0_RDREQ_128B_sum") * 128.0,
+                                                      "l2_hit_rate": total("TCC_HIT_sum") / total("TCC_REQ_sum"),
                                                       "source": "profiles/" + out}
     json.dump(doc, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("traffic:", doc["hbm_bytes_per_launch"], "sha", doc["kernel_source_sha"])

@@ -13,7 +13,8 @@ for f in sorted(glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv
     run = f.split(os.sep)[-3]
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        for key in ("place_reads_kernel", "team_place_kernel", "stream_seq", "stream_rnd"):
+        for key in ("place_reads_kernel", "team_place_kernel", "team_front_kernel", "team_stream_kernel",
+                    "team_merge_kernel", "stream_seq", "stream_rnd"):
             if key in name:
                 acc[(run.split("_")[0], key, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (run, kern, ctr), vals in sorted(acc.items()):

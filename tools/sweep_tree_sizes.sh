@@ -1,6 +1,7 @@
 #!/bin/bash
 # reads/s against tree size, kernel and number of passes (what db_image.cpp's kernel threshold and
 # choose_team were set from): bash tools/sweep_tree_sizes.sh > gpurun_out/sweep.txt   (on the GPU box)
+# SWEEP=short: the sizes around the thresholds only.
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/sweep
 run() { # tag env... -- args
@@ -16,9 +17,11 @@ except Exception as e:
     print("$tag", "no result", e)
 PY
 }
+if [ "$SWEEP" != "short" ]; then
 run n999_default --
 run n1303_default -- --leaves 652
 run n1999_default -- --leaves 1000
+fi
 for leaves in 2000 2500 3000 3750; do
   n=$((2*leaves-1))
   run n${n}_wave EPIK_AMD_KERNEL=wave -- --leaves $leaves --reads-per-step 500000
@@ -26,10 +29,13 @@ for leaves in 2000 2500 3000 3750; do
 done
 run n9999_wave EPIK_AMD_KERNEL=wave -- --leaves 5000 --reads-per-step 500000
 run n9999_team4 EPIK_AMD_KERNEL=team4 -- --leaves 5000
+run n9999_team4_one_kernel EPIK_AMD_KERNEL=team4 EPIK_AMD_TEAM_FRONT=0 -- --leaves 5000
 run n9999_team8 EPIK_AMD_KERNEL=team8 -- --leaves 5000 --reads-per-step 500000
 run n9999_team4x2 EPIK_AMD_KERNEL=team4x2 -- --leaves 5000 --reads-per-step 500000
 for p in 1 2; do run n14999_team4x$p EPIK_AMD_KERNEL=team4x$p -- --leaves 7500 --reads-per-step 200000; done
 for p in 1 2 3; do run n19999_team4x$p EPIK_AMD_KERNEL=team4x$p -- --leaves 10000 --reads-per-step 200000; done
+if [ "$SWEEP" != "short" ]; then
 run n19999_wave EPIK_AMD_KERNEL=wave -- --leaves 10000 --reads-per-step 200000
+fi
 for p in 2 3 4; do run n29999_team4x$p EPIK_AMD_KERNEL=team4x$p -- --leaves 15000 --reads-per-step 100000; done
 run n49999_default -- --leaves 25000 --reads-per-step 100000
