@@ -648,7 +648,7 @@ enum launch_mode { kPlace = epik_amd::kTeamModePlace, kAccumulate = epik_amd::kT
 // else 0).  The pool is sized from what the image says a k-mer's descriptors take and from what earlier
 // launches asked for; a read that finds it full is placed by team_place_kernel, so the estimate only
 // decides speed.  Grown, never shrunk; growing frees the old buffer (which waits for the device).
-static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars)
+static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, bool with_pool)
 {
     const uint32_t slices = (uint32_t)p->team_waves * p->team_passes;
     const size_t hdr_bytes = (size_t)n * epik_amd::front_hdr_stride(slices);
@@ -660,8 +660,6 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars)
     }
     if (n > p->slow_list_reads) {
         (void)hipFree(p->d_slow_list);
-    (void)hipFree(p->d_slice_rows);
-    (void)hipFree(p->d_slice_sums);
         p->d_slow_list = nullptr, p->slow_list_reads = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_slow_list), (size_t)n * sizeof(uint64_t)));
         p->slow_list_reads = n;
@@ -674,6 +672,7 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars)
         HIP_TRY(hipMalloc(&p->d_slice_sums, (size_t)n * slices * epik_amd::kTeamPartialBytes));
         p->slice_out_reads = n;
     }
+    if (!with_pool) return EPIK_AMD_OK;  // (finish: the totals come from the caller, nothing is looked up)
     uint64_t want;
     if (p->front_pool_forced) {
         want = p->front_pool_forced;
@@ -752,10 +751,12 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         tp.slice_bytes = g.lds_wave_bytes;
         tp.desc_bytes = epik_amd::team_desc_bytes(pp.keep_at_most);
         // (the streaming kernel numbers a read's slices in 32 bits)
-        if (mode == kPlace && p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32)) {
-            // front kernel (a wave per read), streaming kernel (a workgroup per read), and team_place_kernel
-            // for the reads whose descriptors found the pool full
-            if (const int rc = reserve_front(p, n, total_chars); rc != EPIK_AMD_OK) return rc;
+        if (p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32)) {
+            // Placing: front kernel (a wave per read), streaming kernel (a wave per slice of a read), merge
+            // kernel (a wave per read), and team_place_kernel for the reads whose descriptors found the pool
+            // full.  The halves of a k-mer-space-sharded placement: accumulate = front + streaming (+ the
+            // other kernel for the rest), finish = headers + streaming + merge.
+            if (const int rc = reserve_front(p, n, total_chars, mode != kFinish); rc != EPIK_AMD_OK) return rc;
             tp.front_hdr = p->d_front_hdr;
             tp.front_hdr_stride = epik_amd::front_hdr_stride((uint32_t)p->team_waves * p->team_passes);
             tp.front_pool = p->d_front_pool;
@@ -764,9 +765,13 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.slow_list = p->d_slow_list;
             tp.slice_rows_out = p->d_slice_rows;
             tp.slice_sums_out = p->d_slice_sums;
-            HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
             const uint64_t front_blocks = std::min<uint64_t>((n + 3) / 4, (uint64_t)p->front_blocks);
-            HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
+            if (mode == kFinish) {
+                HIP_TRY(epik_amd::launch_team_headers(tp, p->team_waves, p->counts, stream));
+            } else {
+                HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
+                HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
+            }
             const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
             uint64_t stream_blocks = std::min<uint64_t>(n * parts, g.stream_blocks);
 #ifdef EPIK_AMD_ABLATION
@@ -774,16 +779,18 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
 #endif
             p->last_blocks = (uint32_t)stream_blocks;
             p->last_streamed = true;
-            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, dim3((unsigned)stream_blocks),
+            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)stream_blocks),
                                                  g.stream_lds_bytes, stream));
-            HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)front_blocks), stream));
-            tp.read_list = p->d_slow_list;
-            tp.read_list_count = p->d_front_cursor + 1;
-            HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,
-                                          stream));
-            // what this launch asked of the pool, for the size of the next one's (read whenever it has arrived)
-            HIP_TRY(hipMemcpyAsync(p->h_front_cursor, p->d_front_cursor, 3 * sizeof(unsigned long long),
-                                   hipMemcpyDeviceToHost, stream));
+            if (mode != kAccumulate) HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)front_blocks), stream));
+            if (mode != kFinish) {
+                tp.read_list = p->d_slow_list;
+                tp.read_list_count = p->d_front_cursor + 1;
+                HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks),
+                                              g.lds_block_bytes, stream));
+                // what this launch asked of the pool, for the size of the next one's (read whenever it has arrived)
+                HIP_TRY(hipMemcpyAsync(p->h_front_cursor, p->d_front_cursor, 3 * sizeof(unsigned long long),
+                                       hipMemcpyDeviceToHost, stream));
+            }
         } else {
             HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks), g.lds_block_bytes,
                                           stream));

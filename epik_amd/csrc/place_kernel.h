@@ -110,7 +110,9 @@ hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_p
 // team_stream.hip: the front kernel (any grid of 256-thread workgroups, one read per wave) and the
 // streaming kernel (one workgroup per read, grid = resident workgroups, LDS as the team kernel's)
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream);
-hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
+                              hipStream_t stream);
+hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipStream_t stream);
 hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream);
 constexpr size_t kTeamPartialBytes = 24;  // sizeof(TeamPartial) (place_device.hpp)
 hipError_t set_team_stream_lds_limit(int waves, int counts);

@@ -276,7 +276,10 @@ __device__ __attribute__((noinline)) void slice_epilogue(const TeamParams *__res
 // no counter.  (A workgroup is four waves whatever the number of slices: what counts is how many waves a CU
 // holds, and with 8 slices per pass the slices are small enough for twenty.)
 // ---------------------------------------------------------------------------------
-template <int W, typename CountT>
+// kMode: kTeamModePlace; kTeamModeAccumulate / kTeamModeFinish = the two halves of a k-mer-space-sharded
+// placement (include/epik_amd.h): stream only, the slice's raw sums and counts to HBM / the totals back from
+// HBM, slice epilogue (the headers then come from team_header_kernel: there is no front end).
+template <int W, typename CountT, int kMode>
 __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     auto first_round = [&](uint32_t word) {
         const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
         uint64_t d = null_desc;
-        if (!(flags & (kFrontSlow | kFrontNoRows | kFrontTooNarrow))) {
+        if (kMode != kTeamModeFinish && !(flags & (kFrontSlow | kFrontNoRows | kFrontTooNarrow))) {
             uint32_t my_padded;
             const uint64_t *list = slice_list(word, (int)(kFrontHdrWords + wave), my_padded);
             const uint32_t n_first = my_padded < cap ? my_padded : cap;
@@ -370,6 +373,17 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
         // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than this
         // launch's counts hold is marked (the caller chose the count width).  team_merge_kernel writes both.
         // A read whose descriptors are not in the pool is placed by team_place_kernel after this launch.
+        if (kMode == kTeamModeAccumulate && (flags & (kFrontNoRows | kFrontTooNarrow))) {  // an all-zero partial vector
+            for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+                const uint32_t base = (pass * W + wave) * tp.slice_rows;
+                const uint32_t rows = base >= p.num_branches ? 0u : min(tp.slice_rows, p.num_branches - base);
+                for (uint32_t i = lane; i < rows; i += kWave) {
+                    p.partial_scores[read * p.num_branches + base + i] = 0.0f;
+                    p.partial_counts[read * p.num_branches + base + i] = 0u;
+                }
+            }
+            continue;
+        }
         if (flags & (kFrontNoRows | kFrontTooNarrow | kFrontSlow)) continue;
         const uint64_t len = __builtin_amdgcn_readlane(word, 2);
         const uint64_t n_kmers = len - k + 1;  // :322
@@ -387,6 +401,25 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             const uint64_t slice_at = read * n_slices + pass * W + wave;
             ctx.cand = rows_out + slice_at * keep;
             ctx.partial = sums_out + slice_at;
+            if constexpr (kMode == kTeamModeFinish) {
+                // second half of a k-mer-space-sharded placement: the slice's totals come back from HBM, with
+                // the read's ambiguous record (the average of the first ambiguous key that reached the branch
+                // over all shards, place.cpp:385-388) added as the one-pass loop adds it (:409-410)
+                const int64_t slot = p.amb_slot ? (int64_t)p.amb_slot[read] : -1;
+                for (uint32_t i = lane; i < ctx.rows_; i += kWave) {
+                    const uint64_t at = read * p.num_branches + ctx.base_ + i;
+                    float sc = p.partial_scores[at];
+                    uint32_t c = p.partial_counts[at];
+                    if (slot >= 0) {
+                        const float avg = p.amb_avg[(uint64_t)slot * p.num_branches + ctx.base_ + i];
+                        if (avg > 0.0f) {
+                            sc = __fadd_rn(sc, avg);
+                            c += 1u;
+                        }
+                    }
+                    lds.store(i, __float_as_uint(sc), c);
+                }
+            } else {
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
             uint32_t my_padded;
             const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded);
@@ -406,9 +439,24 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ----------------------
             if (flags & kFrontAmbiguous) {
                 const uint8_t *seq = p.seqs + p.seq_offsets[read];
-                place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, (int64_t)-1, ctx);
+                const int64_t amb_slot = (kMode == kTeamModeAccumulate && p.amb_slot) ? (int64_t)p.amb_slot[read] : -1;
+                place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, amb_slot, ctx);
             }
             STREAM_STAMP(2)  // ambiguous k-mers
+            }
+            if constexpr (kMode == kTeamModeAccumulate) {
+                // k-mer-space shard: the slice's raw sums and counts leave for HBM; the rows are reset
+                for (uint32_t i = lane; i < rows_pad; i += kWave) {
+                    const uint2 cv = lds.load(i);
+                    if (i < ctx.rows_) {
+                        const uint64_t at = read * p.num_branches + ctx.base_ + i;
+                        p.partial_scores[at] = __uint_as_float(cv.x);
+                        p.partial_counts[at] = (uint16_t)(cv.y & ~(uint32_t)Lds::kSeen);
+                    }
+                    lds.store(i, 0u, 0u);
+                }
+                continue;
+            }
             // ---- correction, the slice's best rows and share of sum_scores (to HBM: team_merge_kernel),
             //      reset of the rows
             if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
@@ -434,6 +482,20 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             STREAM_STAMP(3)  // slice epilogue
         }
     }
+}
+
+// The headers of a batch whose descriptors nobody needs (finish): length and the two "no placement" flags.
+__global__ __launch_bounds__(256) void team_header_kernel(TeamParams tp, uint32_t n_slices, uint64_t max_kmers)
+{
+    const PlaceParams &p = tp.base;
+    const uint64_t read = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= p.n_reads) return;
+    const uint64_t len = p.seq_offsets[read + 1] - p.seq_offsets[read];
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
+    hdr[0] = 0u;
+    hdr[1] = len < p.kmer_size ? kFrontNoRows : len - p.kmer_size + 1 > max_kmers ? kFrontTooNarrow : 0u;
+    hdr[2] = (uint32_t)len;
+    for (uint32_t s2 = 0; s2 < n_slices; ++s2) hdr[kFrontHdrWords + s2] = 0u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -474,15 +536,23 @@ __global__ __launch_bounds__(256) void team_merge_kernel(TeamParams tp, uint32_t
 namespace {
 
 template <typename F>
-hipError_t stream_dispatch(int waves, int counts, F &&f)
+hipError_t stream_dispatch(int waves, int counts, int mode, F &&f)
 {
-#define EPIK_STREAM_CASE(W, C) \
-    if (waves == W && counts == C) \
-        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>>();
-    EPIK_STREAM_CASE(4, kCounts8) EPIK_STREAM_CASE(4, kCounts16) EPIK_STREAM_CASE(4, kCounts32)
-    EPIK_STREAM_CASE(8, kCounts8) EPIK_STREAM_CASE(8, kCounts16) EPIK_STREAM_CASE(8, kCounts32)
+#define EPIK_STREAM_CASE(W, C, M) \
+    if (waves == W && counts == C && mode == M) \
+        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M>();
+#define EPIK_STREAM_MODES(W, C) EPIK_STREAM_CASE(W, C, kTeamModePlace) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate) EPIK_STREAM_CASE(W, C, kTeamModeFinish)
+    EPIK_STREAM_MODES(4, kCounts8) EPIK_STREAM_MODES(4, kCounts16) EPIK_STREAM_MODES(4, kCounts32)
+    EPIK_STREAM_MODES(8, kCounts8) EPIK_STREAM_MODES(8, kCounts16) EPIK_STREAM_MODES(8, kCounts32)
+#undef EPIK_STREAM_MODES
 #undef EPIK_STREAM_CASE
     return hipErrorInvalidValue;
+}
+
+uint64_t max_kmers_of(int counts)
+{
+    return counts == kCounts8 ? WaveLds<uint8_t>::kMaxKmers : counts == kCounts16 ? WaveLds<uint16_t>::kMaxKmers
+                                                                                : WaveLds<uint32_t>::kMaxKmers;
 }
 
 }  // namespace
@@ -490,21 +560,27 @@ hipError_t stream_dispatch(int waves, int counts, F &&f)
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream)
 {
     // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them)
-    const uint64_t max_kmers = counts == kCounts8 ? WaveLds<uint8_t>::kMaxKmers
-                               : counts == kCounts16 ? WaveLds<uint16_t>::kMaxKmers : WaveLds<uint32_t>::kMaxKmers;
     if (waves == 4)
-        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(256), 0, stream, tp, max_kmers);
+        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(256), 0, stream, tp, max_kmers_of(counts));
     else if (waves == 8)
-        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(256), 0, stream, tp, max_kmers);
+        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(256), 0, stream, tp, max_kmers_of(counts));
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, dim3 grid, size_t lds_bytes, hipStream_t stream)
+hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipStream_t stream)
 {
-    return stream_dispatch(waves, counts, [&]<int W, typename C>() {
-        hipLaunchKernelGGL((team_stream_kernel<W, C>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp);
+    const dim3 grid((unsigned)((tp.base.n_reads + 255) / 256));
+    hipLaunchKernelGGL(team_header_kernel, grid, dim3(256), 0, stream, tp, (uint32_t)waves * tp.passes, max_kmers_of(counts));
+    return hipGetLastError();
+}
+
+hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
+                              hipStream_t stream)
+{
+    return stream_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
+        hipLaunchKernelGGL((team_stream_kernel<W, C, M>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp);
         return hipGetLastError();
     });
 }
@@ -517,16 +593,20 @@ hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStre
 
 hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whole CU: see place_kernel.hip)
 {
-    return stream_dispatch(waves, counts, [&]<int W, typename C>() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-    });
+    hipError_t err = hipSuccess;
+    for (int mode = 0; mode < 3 && err == hipSuccess; ++mode)
+        err = stream_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+        });
+    return err;
 }
 
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
 {
-    return stream_dispatch(waves, counts, [&]<int W, typename C>() {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C>, kStreamWaves * 64, lds_bytes);
+    return stream_dispatch(waves, counts, kTeamModePlace, [&]<int W, typename C, int M>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C, M>, kStreamWaves * 64,
+                                                            lds_bytes);
     });
 }
 

@@ -7,19 +7,17 @@ to the 1e-5 bar."""
 import numpy as np
 import pytest
 
-from conftest import assert_rows_match, mixed_reads
+from conftest import assert_rows_match, mixed_reads, select_kernel
 from epik_amd import alphabet, dist as edist, synth
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["paired", "compact", "team4", "team8"])
+@pytest.fixture(autouse=True, params=["paired", "compact", "team4", "team8", "team4-classic", "team4-smallpool"])
 def db_layout(request, monkeypatch):
-    if request.param.startswith("team"):
-        monkeypatch.setenv("EPIK_AMD_KERNEL", request.param)
-    else:
-        monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
-        monkeypatch.setenv("EPIK_AMD_LAYOUT", request.param)
+    """The halves of a sharded placement on the one-wavefront kernels, and on the team kernels as front +
+    streaming (+ merge) kernels, as team_place_kernel alone (-classic), and mixed (-smallpool)."""
+    select_kernel(monkeypatch, request.param)
     return request.param
 
 
