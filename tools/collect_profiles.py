@@ -30,6 +30,9 @@ FILES = {
     "pmc_summary_n9999.txt": "r02_pmc_summary_n9999_team.txt",
     "sq_counters_headline.txt": "r02_sq_counters.txt",
     "sq_counters_n9999_team.txt": "r02_sq_counters_n9999_team.txt",
+    "team_instruction_counts.txt": "r02_team_instruction_counts.txt",
+    "team_stream_wave_timeline.txt": "r02_team_stream_wave_timeline.txt",
+    "sweep_tree_sizes_passes.txt": "r02_sweep_tree_sizes_passes.txt",
 }
 
 

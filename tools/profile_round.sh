@@ -3,7 +3,8 @@
 #   bash tools/profile_round.sh r02_a        (on the GPU box; results under gpurun_out/<tag>/)
 # bench lines, rocprofv3 --kernel-trace --stats summaries of the same commands, and the PMC passes
 # (separate rocprofv3 --pmc runs, tools/pmc_passes.sh) for the headline workload, the HBM-resident
-# database (k = 11) and the large tree (N = 9 999, team kernel).
+# database (k = 11) and the large tree (N = 9 999, team kernels); SQ counters, per-phase instruction counts and a
+# single-wave timeline of the team kernels; the tree-size sweep.
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r02}
 OUT=$R/gpurun_out/$TAG
@@ -11,6 +12,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 log() { echo "[profile_round] $*"; }
 
+# PART=1: bench lines, kernel traces, PMC passes; PART=2: SQ counters, instruction counts, timeline, sweep
+# (a GPU call is limited to 20 minutes: two calls); default: both.
+PART=${PART:-12}
+if [[ $PART == *1* ]]; then
 log "full default bench line"
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || log "bench failed"
 
@@ -36,5 +41,20 @@ for cfg in "headline:" "k11:--kmer-size 11" "n9999:--leaves 5000"; do
   (cd $R && BENCH_ARGS="$args" bash tools/pmc_passes.sh ${TAG}_$name > $OUT/pmc_$name.log 2>&1)
   cp $R/gpurun_out/pmc_${TAG}_$name/summary.txt $OUT/pmc_summary_$name.txt 2>/dev/null
 done
+fi
+if [[ $PART == *2* ]]; then
+for cfg in "headline:" "n9999_team:--leaves 5000"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  log "SQ / TCP counter passes: $name"
+  (cd $R && BENCH_ARGS="$args" bash tools/pmc_sq.sh ${TAG}_sq_$name > $OUT/sq_$name.log 2>&1)
+  cp $R/gpurun_out/pmc_${TAG}_sq_$name/summary.txt $OUT/sq_counters_$name.txt 2>/dev/null
+done
+log "instruction counts of the team kernels by phase (diagnostic build)"
+(cd $R && make -C epik_amd/csrc ablate > /dev/null 2>&1 && bash tools/pmc_insts_team.sh > $OUT/team_instruction_counts.txt 2>&1)
+log "timeline of one wave of the streaming kernel (diagnostic build)"
+(cd $R && EPIK_AMD_TRACE_FILE=$OUT/team_stream_wave_trace.txt LEAVES=5000 ROUNDS=1 python3 tools/ablate.py lib=_ablate,kernel=team4,wide=2,stamps=1 > $OUT/team_stream_wave_trace.log 2>&1 && python3 tools/trace_summary.py $OUT/team_stream_wave_trace.txt > $OUT/team_stream_wave_timeline.txt)
+log "tree sizes, kernels, passes"
+(cd $R && bash tools/sweep_tree_sizes.sh > $OUT/sweep_tree_sizes_passes.txt 2>&1)
+fi
 log done
 ls $OUT

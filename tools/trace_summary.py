@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summary of the single-wave timeline a diagnostic build writes (EPIK_AMD_STAMPS=1, EPIK_AMD_TRACE_FILE=<path>;
+team_stream.hip / place_device.hpp): cycles per read of one wave of team_stream_kernel by section.  Every entry
+costs the wave about as much as the section called "(empty)" shows -- subtract it from each event.
+
+    python tools/trace_summary.py gpurun_out/<tag>/team_stream_wave_trace.txt
+"""
+import collections
+import sys
+
+NAMES = {109: "loop top (headers, prefetch of the next read's descriptors)", 100: "descriptors -> LDS", 101: "stream (a round)",
+         102: "ambiguous k-mers", 103: "epilogue return", 10: "epilogue entered", 0: "correction sweep", 1: "tau",
+         2: "scan sweep", 3: "rank", 4: "partial sum", 5: "(empty)", 6: "publish", 7: "clear"}
+
+
+def main():
+    rows = [tuple(map(int, line.split())) for line in open(sys.argv[1])]
+    reads, cur = [], []
+    for code, cycles in rows:
+        if code == 109 and cur:
+            reads.append(cur)
+            cur = []
+        cur.append((code, cycles))
+    reads = reads[50:-5]  # steady state
+    total, count = collections.Counter(), collections.Counter()
+    for r in reads:
+        for code, cycles in r:
+            total[code] += cycles
+            count[code] += 1
+    n = len(reads)
+    per_read = sum(total.values()) / n
+    print(f"{n} reads of one wave (one slice of each); {per_read:.0f} cycles per read with the stamps")
+    for code in (109, 100, 101, 102, 10, 0, 1, 2, 3, 4, 5, 6, 7, 103):
+        if count[code]:
+            print(f"  {NAMES[code]:62s} {total[code] / n:8.0f} cycles per read ({100 * total[code] / n / per_read:4.1f} %), "
+                  f"{count[code] / n:4.2f} per read, {total[code] / count[code]:7.0f} each")
+
+
+if __name__ == "__main__":
+    main()
