@@ -104,9 +104,9 @@ int epik_amd_placer_create(const epik_amd_placer_desc *desc, epik_amd_placer **o
  * What create() would decide for this database on a device with `free_bytes` of free memory, and how
  * large the device image is -- without a device (capacity planning against 288 GB; no reference
  * counterpart: the reference keeps its hash map in host RAM, main.cpp:277).  `kernel` 0: one wavefront
- * places a read (trees whose score vector leaves enough waves on a CU); 1: a workgroup of `team_waves`
- * waves places a read, the branch range split into team_waves * team_passes slices of `slice_rows`
- * branches (large trees; place.cpp:92-96 bounds the tree by nothing, and neither does this).
+ * places a read (trees whose score vector leaves enough waves on a CU); 1: the branch range is split into
+ * team_waves * team_passes slices of `slice_rows` branches and a wavefront places one slice of a read
+ * (large trees; place.cpp:92-96 bounds the tree by nothing, and neither does this).
  * The environment overrides of create() (EPIK_AMD_LAYOUT, EPIK_AMD_KERNEL) apply here too.
  */
 typedef struct {
@@ -149,7 +149,8 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
 /*
  * Same computation with every buffer already resident in device memory, enqueued
  * on `stream` (a hipStream_t passed as void*; NULL = the default stream) without
- * synchronising.  d_kmer_counts may be NULL.
+ * synchronising.  d_kmer_counts may be NULL.  The launches of one handle share its scratch
+ * memory (large trees): enqueue them on one stream, or order them.
  */
 int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
                                  uint64_t n, void *d_rows, void *d_n_rows, void *d_kmer_counts,
@@ -223,7 +224,7 @@ int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets,
                                   void *stream);
 
 /* Launch geometry actually used (for reports): waves per workgroup (one read per wave with the
- * one-wavefront kernel, one read per workgroup with the team kernel), workgroups of the last launch,
+ * one-wavefront kernel, one slice of a read per wave on large trees), workgroups of the last launch,
  * dynamic LDS bytes per workgroup. */
 int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,
                                 uint32_t *blocks, uint32_t *lds_bytes);
