@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Lints the generated ISA of place_kernel.hip for the one hazard hipcc cannot see.
+"""Lints the generated ISA of the kernels that stream postings (place_kernel.hip, team_kernel.hip,
+team_stream.hip) for the one hazard hipcc cannot see.
 
 The ring's posting loads are issued from inline asm (uncounted by hipcc's s_waitcnt
 bookkeeping), so a compiler-generated copy of a ring register made while its load is
@@ -30,7 +31,7 @@ def regs_of(token):
 def kernels(lines):
     name, body = None, []
     for line in lines:
-        m = re.match(r"^(_ZN8epik_amd18place_reads_kernel\w+):", line)
+        m = re.match(r"^(_ZN8epik_amd\d+(?:place_reads|team_place|team_stream|finish_reads)_kernel\w+):", line)
         if m:
             name, body = m.group(1), []
             continue
@@ -94,6 +95,7 @@ def lint_loop(name, body, events, problems):
 
 def lint(path):
     problems = []
+    linted = 0
     for name, body in kernels(open(path).read().split("\n")):
         # asm statements in program order: (line, kind, regs), kind in {"wait", "drain", "load"}
         events, in_asm = [], False
@@ -108,8 +110,8 @@ def lint(path):
             elif in_asm and s.startswith("s_waitcnt vmcnt("):
                 events.append((n, "drain" if "vmcnt(0)" in s else "wait", set()))
         if not any(e[1] == "load" for e in events):
-            problems.append(f"{name}: no asm ring loads found")
-            continue
+            continue  # a kernel without a stream (the finish halves of a sharded placement)
+        linted += 1
         # the kernel may hold several copies of the ring loop (first pass / further passes):
         # each ends with its tail's `s_waitcnt vmcnt(0)`
         group = []
@@ -120,6 +122,8 @@ def lint(path):
             else:
                 group.append(e)
         lint_loop(name, body, group, problems)
+    if linted == 0:
+        problems.append(f"{path}: no kernel with asm ring loads found")
     return problems
 
 
