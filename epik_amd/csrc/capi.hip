@@ -468,7 +468,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
                                      hipHostMallocDefault));
             p->h_front_cursor[0] = p->h_front_cursor[1] = p->h_front_cursor[2] = 0;
             if (const char *e = std::getenv("EPIK_AMD_TEAM_POOL")) p->front_pool_forced = std::strtoull(e, nullptr, 10);
-            p->front_blocks = (uint32_t)prop.multiProcessorCount * 8u;  // 32 waves per CU: all it holds
+            p->front_blocks = (uint32_t)prop.multiProcessorCount * 32u;  // workgroups of one wave: all a CU holds
         }
     } else {
         for (int counts = 0; counts < 3; ++counts) {
@@ -682,7 +682,7 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, b
         const double per_kmer = (double)p->plan.team_chunks / (double)std::max<uint64_t>(p->plan.present_codes, 1);
         const uint64_t chars = total_chars ? total_chars : n * (p->longest_read_hint ? p->longest_read_hint : 160u);
         // ... and what the waves of the front kernel leave unused of the pieces they take the pool in
-        const uint64_t front_waves = std::min<uint64_t>(n, (uint64_t)p->front_blocks * 4u);
+        const uint64_t front_waves = std::min<uint64_t>(n, (uint64_t)p->front_blocks);
         double est = (double)chars * per_kmer * 1.1 + (double)n * slices * epik_amd::kTeamRing +
                      (double)front_waves * epik_amd::kFrontPoolChunk;
         // what the last finished launch asked for per read, if that is more
@@ -765,7 +765,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.slow_list = p->d_slow_list;
             tp.slice_rows_out = p->d_slice_rows;
             tp.slice_sums_out = p->d_slice_sums;
-            const uint64_t front_blocks = std::min<uint64_t>((n + 3) / 4, (uint64_t)p->front_blocks);
+            const uint64_t front_blocks = std::min<uint64_t>(n, (uint64_t)p->front_blocks);  // (front, merge: a read per wave)
             if (mode == kFinish) {
                 HIP_TRY(epik_amd::launch_team_headers(tp, p->team_waves, p->counts, stream));
             } else {

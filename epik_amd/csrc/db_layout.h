@@ -87,9 +87,10 @@ constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes
            (size_t)waves * passes * 24 + (size_t)waves * passes * keep * 16;
 }
 // team_stream_kernel (team_stream.hip): workgroups of kStreamWaves independent waves, each with one slice's rows
-// and descriptor list; with 8 slices per pass two workgroups share a read.  Compiled for 3 waves per SIMD with
-// 4 slices (a slice of a large tree leaves room for no more) and 5 with 8 (the slice epilogue needs 68 VGPRs,
-// the streaming loop fewer; only the cold ambiguous sweep spills).
+// and descriptor list; with 8 slices per pass two workgroups share a read.  Compiled for 4 waves per SIMD with
+// 4 slices (128 vector registers: the LDS of a large tree leaves room for three of its waves, and the fourth
+// wave's registers go to the front and merge kernels, which run beside it) and 5 with 8 (the slice epilogue
+// needs 70 VGPRs, the streaming loop fewer; only the cold ambiguous sweep spills).
 constexpr int kStreamWaves = 4;
 constexpr uint32_t stream_waves_per_simd(int slices_per_pass)
 {

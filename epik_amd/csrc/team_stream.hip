@@ -41,8 +41,9 @@ namespace epik_amd {
 // a time: one atomic add per read on a single counter costs more than everything else here (measured: 8 ns
 // each, device-wide).
 // ---------------------------------------------------------------------------------
+// (Workgroups of one wave, 3 KB of LDS each.)
 template <int W>
-__global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t max_kmers)
+__global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t max_kmers)
 {
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
@@ -54,8 +55,7 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint64_t null_desc = null_chunk(p);
     constexpr int T = kTilesPerPass;
-    __shared__ uint4 held_all[4][T * TeamEntry<W>::kQuads * kWave];  // per wave: the entries of a short read's tiles, by lane
-    uint4 *held = held_all[threadIdx.x >> 6];
+    __shared__ uint4 held[T * TeamEntry<W>::kQuads * kWave];  // the entries of a short read's tiles, by lane
     unsigned long long chunk_at = 0;  // this wave's piece of the pool: next free descriptor, how many are left
     uint32_t chunk_left = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) tp.front_cursor[2] = p.n_reads;  // (the host sizes the next launch's pool by it)
@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void team_front_kernel(TeamParams tp, uint64_t
             chunk_at += total;
             chunk_left -= total;
         }
-        const bool fits = off + total <= tp.front_pool_cap;
+        // A read with an ambiguous k-mer (place.cpp:306-313, 373-415) is left to team_place_kernel: its sweep
+        // of the resolved keys (double-precision pow) needs more registers than everything else together, and
+        // the streaming kernel without it leaves room on a SIMD for the kernels that run beside it.
+        const bool fits = off + total <= tp.front_pool_cap && !any_amb;
         uint32_t flags = any_amb ? kFrontAmbiguous : 0u;
         if (!fits) {
             flags |= kFrontSlow;
@@ -436,13 +439,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_round, score_top, count_top);
                 STREAM_STAMP(1)  // stream
             }
-            // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ----------------------
-            if (flags & kFrontAmbiguous) {
-                const uint8_t *seq = p.seqs + p.seq_offsets[read];
-                const int64_t amb_slot = (kMode == kTeamModeAccumulate && p.amb_slot) ? (int64_t)p.amb_slot[read] : -1;
-                place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, amb_slot, ctx);
-            }
-            STREAM_STAMP(2)  // ambiguous k-mers
+            // (no ambiguous k-mers here: the front kernel leaves such a read to team_place_kernel)
             }
             if constexpr (kMode == kTeamModeAccumulate) {
                 // k-mer-space shard: the slice's raw sums and counts leave for HBM; the rows are reset
@@ -561,9 +558,9 @@ hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 g
 {
     // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them)
     if (waves == 4)
-        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(256), 0, stream, tp, max_kmers_of(counts));
+        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(64), 0, stream, tp, max_kmers_of(counts));
     else if (waves == 8)
-        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(256), 0, stream, tp, max_kmers_of(counts));
+        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(64), 0, stream, tp, max_kmers_of(counts));
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
