@@ -246,8 +246,10 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
     }
 }
 
-// The slice epilogue, out of line, with everything it needs in at most 16 argument registers: a larger set
-// of arguments goes through the stack (scratch memory), a round trip to the caches at every call.
+// The slice epilogue.  (While the streaming kernel still held the ambiguous sweep it was a function out of
+// line, and then with at most 16 argument registers: a larger set of arguments goes through the stack --
+// scratch memory --, a round trip to the caches at every call.  Without that callee the kernel takes 96
+// vector registers with the epilogue inline, and no scratch.)
 struct SliceArgs {
     uint32_t rows_pad, rows, base, kmer_size, keep;
     float log_threshold;
@@ -255,7 +257,7 @@ struct SliceArgs {
     uint32_t trace_at;  // diagnostic builds
 };
 template <int W, typename CountT>
-__device__ __attribute__((noinline)) void slice_epilogue(const TeamParams *__restrict__ ktp, WaveLds<CountT> lds,
+__device__ __forceinline__ void slice_epilogue(const TeamParams *__restrict__ ktp, WaveLds<CountT> lds,
                                                          uint32_t n_kmers, SliceArgs a)
 {
     TeamCtx<W, true> ctx;
