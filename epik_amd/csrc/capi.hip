@@ -744,6 +744,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         tp.base = pp;
         tp.team_table = p->team_table;
         tp.num_keys = p->num_keys;
+        tp.team_paired = p->plan.team_paired ? 1u : 0u;
         tp.passes = p->team_passes;
         tp.slice_rows = p->team_slice_rows;
         tp.rows_pad = p->team_rows_pad;
@@ -1052,6 +1053,7 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
         tp.base = pp;
         tp.team_table = p->team_table;
         tp.num_keys = p->num_keys;
+        tp.team_paired = p->plan.team_paired ? 1u : 0u;
         tp.passes = p->team_passes;
         HIP_TRY(epik_amd::launch_team_algorithmic_bytes(tp, p->team_waves, p->d_total, s));
     } else {

@@ -222,7 +222,18 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
         const uint32_t slices = (uint32_t)c.waves * c.passes;
         std::vector<uint32_t> cnt(slices);
         uint64_t lines = 0;
+        // A table entry is 16 bytes, a lookup fetches a 128-byte line: with 4 letters the table is keyed, as the
+        // paired layout of the one-wavefront kernels, by the (k-1)-mer X two consecutive k-mers of a read share
+        // -- block X = the entries of a.X (slots 0-3) and X.b (slots 4-7), one line -- so that two lookups
+        // cost one fetch (the front kernel is bound by exactly these fetches).  Every entry is stored twice.
+        plan.team_paired = d->alphabet_size == 4 && team_entry_bytes(c.waves) == 16 && d->kmer_size >= 2 &&
+                           !(std::getenv("EPIK_AMD_TEAM_TABLE") && std::strcmp(std::getenv("EPIK_AMD_TEAM_TABLE"), "plain") == 0);
+        if (plan.team_paired) plan.team_quarter_lines.assign((size_t)c.passes * 4, 0);
+        std::vector<uint64_t> pass_lines(c.passes, 0);  // lines of each pass so far (a pass's lines are numbered from the region's start: see build)
+        const uint64_t quarter = d->num_keys / 4;
         for (uint64_t key = 0; key < d->num_keys; ++key) {
+            if (plan.team_paired && quarter && key % quarter == 0 && key / quarter < 4)
+                for (uint32_t p = 0; p < c.passes; ++p) plan.team_quarter_lines[(size_t)p * 4 + key / quarter] = pass_lines[p];
             const uint64_t len = src.kept_len(key);
             if (len == 0) continue;
             std::fill(cnt.begin(), cnt.end(), 0u);
@@ -235,11 +246,12 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
                     plan.team_chunks += (cnt[p * c.waves + w] + 63u) / 64u;
                 }
                 lines += (bytes + 127u) / 128u;
+                pass_lines[p] += (bytes + 127u) / 128u;
             }
         }
         if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
         plan.posting_bytes = lines * 128u + 512u;  // +512: room behind the last list (descriptors are exact)
-        plan.table_bytes = (uint64_t)c.passes * d->num_keys * (uint64_t)team_entry_bytes(c.waves);
+        plan.table_bytes = (uint64_t)c.passes * d->num_keys * (uint64_t)team_entry_bytes(c.waves) * (plan.team_paired ? 2u : 1u);
         return EPIK_AMD_OK;
     }
 
@@ -295,12 +307,36 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             const uint32_t rows = plan.team_slice_rows, top = plan.team_rows_pad - 1u;
             const size_t entry_bytes = (size_t)team_entry_bytes(W);
             std::vector<std::vector<epik_amd_pkdb_value>> sub((size_t)W);
+            // sublist lengths of a code in a pass, and the 128-byte lines its sublists take
+            auto slice_counts = [&](uint64_t key, uint32_t first_slice, uint32_t *cnt) {
+                for (int w = 0; w < W; ++w) cnt[w] = 0;
+                const uint64_t len = src.kept_len(key);
+                const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+                for (uint64_t i = 0; i < len; ++i) {
+                    const uint32_t slice = v[i].branch / rows;
+                    if (slice >= first_slice && slice < first_slice + (uint32_t)W) ++cnt[slice - first_slice];
+                }
+                uint32_t bytes = 0;
+                for (int w = 0; w < W; ++w) bytes += pad4(cnt[w] * 6u);
+                return (uint64_t)((bytes + 127u) / 128u);
+            };
+            auto put_entry = [&](uint8_t *entry, uint64_t line, const uint32_t *cnt, uint64_t n_lines) {
+                if (n_lines == 0) return;  // zero-filled: an absent code has len[] = 0
+                put_u32(entry, (uint32_t)line);
+                for (int w = 0; w < W; ++w) {
+                    const uint16_t n = (uint16_t)cnt[w];
+                    std::memcpy(entry + 4 + 2 * w, &n, 2);
+                }
+            };
             uint64_t line = 0;
+            std::vector<uint32_t> cnt((size_t)W);
             for (uint32_t pass = 0; pass < plan.team_passes; ++pass) {
-                RecordWriter entries(table, entry_bytes, num_keys);
                 const uint32_t first_slice = pass * (uint32_t)W;
+                const uint64_t pass_first_line = line;
+                // ---- the postings of the pass, in code order (and, unpaired, the table with them) ----------
+                RecordWriter entries(table, entry_bytes, plan.team_paired ? 0 : num_keys);
                 for (uint64_t key = 0; key < num_keys; ++key) {
-                    uint8_t *entry = entries.next();  // zero-filled: an absent code has len[] = 0
+                    uint8_t *entry = plan.team_paired ? nullptr : entries.next();
                     const uint64_t len = src.kept_len(key);
                     if (len == 0) continue;
                     for (auto &s : sub) s.clear();
@@ -311,18 +347,41 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
                             sub[slice - first_slice].push_back({v[i].branch - slice * rows, v[i].score});
                     }
                     uint32_t bytes = 0;
-                    for (int w = 0; w < W; ++w) bytes += pad4((uint32_t)sub[w].size() * 6u);
+                    for (int w = 0; w < W; ++w) {
+                        cnt[w] = (uint32_t)sub[w].size();
+                        bytes += pad4(cnt[w] * 6u);
+                    }
                     if (bytes == 0) continue;
                     const uint64_t n_lines = (bytes + 127u) / 128u;
                     uint8_t *dst = postings.reserve((size_t)n_lines * 128u);
-                    put_u32(entry, (uint32_t)line);
+                    if (entry) put_entry(entry, line, cnt.data(), n_lines);
                     for (int w = 0; w < W; ++w) {
-                        const uint16_t n = (uint16_t)sub[w].size();
-                        std::memcpy(entry + 4 + 2 * w, &n, 2);
                         write_chunks(dst, sub[w].data(), sub[w].size(), top);
                         dst += pad4((uint32_t)sub[w].size() * 6u);
                     }
                     line += n_lines;
+                }
+                if (!plan.team_paired) continue;
+                // ---- the paired table of the pass: block X = entries of a.X (slots 0-3) and X.b (slots 4-7).
+                // The line of a code is the number of lines of all codes of the pass in front of it: five
+                // cursors walk the key space in step -- one per quarter (a.X, a fixed, X rising) and one over
+                // all codes (X.b) -- so no per-code array is needed; the lists are counted again for it.
+                const uint64_t blocks = num_keys / 4;  // 4^(k-1)
+                RecordWriter out(table, 8 * entry_bytes, blocks);
+                uint64_t quarter_line[4], seq_line = pass_first_line;
+                for (int a = 0; a < 4; ++a) quarter_line[a] = pass_first_line + plan.team_quarter_lines[(size_t)pass * 4 + a];
+                for (uint64_t x = 0; x < blocks; ++x) {
+                    uint8_t *block = out.next();
+                    for (uint32_t a = 0; a < 4; ++a) {
+                        const uint64_t n_lines = slice_counts(a * blocks + x, first_slice, cnt.data());
+                        put_entry(block + entry_bytes * a, quarter_line[a], cnt.data(), n_lines);
+                        quarter_line[a] += n_lines;
+                    }
+                    for (uint32_t bb = 0; bb < 4; ++bb) {
+                        const uint64_t n_lines = slice_counts(x * 4 + bb, first_slice, cnt.data());
+                        put_entry(block + entry_bytes * (4 + bb), seq_line, cnt.data(), n_lines);
+                        seq_line += n_lines;
+                    }
                 }
             }
             postings.reserve(512);

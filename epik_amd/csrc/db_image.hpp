@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "db_layout.h"
 #include "epik_amd.h"
@@ -44,6 +45,8 @@ struct Plan {
     int team_waves = 0;
     uint32_t team_passes = 0, team_slice_rows = 0, team_rows_pad = 0;
     uint64_t team_chunks = 0;  // chunks of <= 64 postings over all sublists (what a read's descriptors take: capi.hip)
+    bool team_paired = false;  // the team table keyed by the (k-1)-mer two consecutive k-mers share (4 letters, 16-byte entries)
+    std::vector<uint64_t> team_quarter_lines;  // paired: [pass][4] posting lines of the pass in front of each quarter of the key space
     // device image
     uint64_t table_bytes = 0, filter_bytes = 0, posting_bytes = 0;
     uint64_t kept_entries = 0, present_codes = 0;

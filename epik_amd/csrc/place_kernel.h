@@ -60,8 +60,11 @@ constexpr uint32_t kCountsTooNarrow = 0xffffffffu;
 struct TeamParams {
     PlaceParams base;            // first member: the out-of-line device functions get &base
                                  // (base.postings = the sliced posting region; base.table / filter unused)
-    const uint8_t *team_table;   // [passes][num_keys] entries of team_entry_bytes(W)
+    const uint8_t *team_table;   // [passes][num_keys] entries of team_entry_bytes(W); paired: [passes][num_keys / 4][8]
     uint64_t num_keys;
+    uint32_t team_paired;        // the table is keyed by the (k-1)-mer X two consecutive k-mers share (4 letters): block X =
+                                 // the entries of a.X (slots 0-3) and X.b (slots 4-7); a k-mer at an even position of the
+                                 // read is looked up as a.X, the next one as X.b -- the same 128-byte line
     uint32_t passes;             // P: the tree is placed in P passes of W slices each
     uint32_t slice_rows;         // branches per slice; slice s = pass * W + wave starts at branch s * slice_rows
     uint32_t rows_pad;           // LDS rows per slice: slice_rows + the dummy row, rounded up to 64

@@ -26,9 +26,20 @@ struct TeamEntry {
     uint32_t len[W];
     // the entry as it lies in HBM (kWords / 4 times 16 bytes), and its fields from that
     static constexpr int kQuads = kWords / 4;
-    __device__ static __forceinline__ void fetch(const TeamParams &tp, uint32_t pass, uint32_t key, uint4 (&raw)[kQuads])
+    // `position`: where in the read the k-mer starts (its parity picks the form a paired table holds it in;
+    // a lookup by code alone passes 0)
+    __device__ static __forceinline__ void fetch(const TeamParams &tp, uint32_t pass, uint32_t key, uint32_t position,
+                                                 uint4 (&raw)[kQuads])
     {
-        const uint4 *e = reinterpret_cast<const uint4 *>(tp.team_table + ((uint64_t)pass * tp.num_keys + key) * (kWords * 4u));
+        uint64_t index = (uint64_t)pass * tp.num_keys + key;
+        if (tp.team_paired) {  // (wave-uniform)
+            const uint32_t shift = 2u * tp.base.kmer_size - 2u;  // X = k-1 letters of 2 bits
+            const bool as_prefix = (position & 1u) != 0;
+            const uint32_t block = as_prefix ? key >> 2 : key & ((1u << shift) - 1u);
+            const uint32_t slot = as_prefix ? 4u + (key & 3u) : key >> shift;
+            index = ((uint64_t)pass * (tp.num_keys / 4u) + block) * 8u + slot;
+        }
+        const uint4 *e = reinterpret_cast<const uint4 *>(tp.team_table + index * (kWords * 4u));
 #pragma unroll
         for (int i = 0; i < kQuads; ++i) raw[i] = e[i];
     }
@@ -46,10 +57,10 @@ struct TeamEntry {
 #pragma unroll
         for (int s = 0; s < W; ++s) len[s] = (w[1 + s / 2] >> (16 * (s & 1))) & 0xffffu;
     }
-    __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key)
+    __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key, uint32_t position = 0u)
     {
         uint4 raw[kQuads];
-        fetch(tp, pass, key, raw);
+        fetch(tp, pass, key, position, raw);
         unpack(raw);
     }
     // byte offset of sublist s in the posting region

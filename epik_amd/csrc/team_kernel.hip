@@ -187,7 +187,7 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                         }
                         if (exact) {
                             TeamEntry<W> e;
-                            e.load(tp, pass, tl.key);
+                            e.load(tp, pass, tl.key, (uint32_t)tile_pos + (uint32_t)lane);
 #pragma unroll
                             for (int s = 0; s < W; ++s) {
                                 llen[s] = e.len[s];

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
 #pragma unroll
                 for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = make_uint4(0u, 0u, 0u, 0u);
                 const Tile tl = tile_from_class(cls[t], len, (uint64_t)t * stride, n_kmers, k, sigma, stride);
-                if (exact_windows(tl)) TeamEntry<W>::fetch(tp, 0u, tl.key, raw[t]);
+                if (exact_windows(tl)) TeamEntry<W>::fetch(tp, 0u, tl.key, (uint32_t)t * stride + (uint32_t)lane, raw[t]);
             }
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
                     const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
                     if (exact_windows(tl)) {
                         TeamEntry<W> e;
-                        e.load(tp, pass, tl.key);
+                        e.load(tp, pass, tl.key, (uint32_t)tile_pos + (uint32_t)lane);
 #pragma unroll
                         for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
                     }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
                     e.line = 0;
 #pragma unroll
                     for (int s = 0; s < W; ++s) e.len[s] = 0;
-                    if (exact_windows(tl)) e.load(tp, pass, tl.key);
+                    if (exact_windows(tl)) e.load(tp, pass, tl.key, (uint32_t)tile_pos + (uint32_t)lane);
 #pragma unroll
                     for (int s = 0; s < W; ++s) run[s] += write_sublists(e.len[s], e.start(s), run[s]);
                 }

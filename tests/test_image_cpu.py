@@ -112,30 +112,46 @@ def test_compact_layout(db, monkeypatch):
     assert rec["cell"].tolist() == (n_pad - 1 - db.values["branch"][keep].astype(np.int64)).tolist()
 
 
-@pytest.mark.parametrize("kernel,waves", [("team4", 4), ("team8", 8)])
-def test_team_layout(db, kernel, waves, monkeypatch):
+@pytest.mark.parametrize("kernel,waves,table", [("team4", 4, "paired"), ("team4", 4, "plain"), ("team8", 8, "plain")])
+def test_team_layout(db, kernel, waves, table, monkeypatch):
     """Every list as W sublists, one per slice of the branch range, in the list's order; cells local to
-    the slice; one {line, len[W]} entry per code."""
+    the slice; one {line, len[W]} entry per code -- with 4 letters and 16-byte entries twice, in the block
+    of the (k-1)-mer it ends with (slot = its first letter) and in the block of the (k-1)-mer it starts
+    with (slot = 4 + its last letter)."""
     monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
-    plan, table, _, postings = eplacer.build_image(db)
+    if table == "plain":
+        monkeypatch.setenv("EPIK_AMD_TEAM_TABLE", "plain")
+    plan, table_bytes, _, postings = eplacer.build_image(db)
     assert plan.kernel == 1 and plan.layout == 5 and plan.team_waves == waves and plan.team_passes == 1
     rows = plan.slice_rows
     assert rows * waves >= db.num_branches > rows * (waves - 1)
     rows_pad = (rows + 1 + 15) // 16 * 16
     entry_bytes = 16 if waves == 4 else 32
+    paired = table == "paired"
+    assert len(table_bytes) == db.num_keys * entry_bytes * (2 if paired else 1)
+    blocks = db.num_keys // 4
+
+    def entries_of(key):
+        if not paired:
+            return [table_bytes[key * entry_bytes:(key + 1) * entry_bytes]]
+        as_suffix = ((key % blocks) * 8 + key // blocks) * entry_bytes       # a.X in block X, slot a
+        as_prefix = ((key // 4) * 8 + 4 + key % 4) * entry_bytes            # X.b in block X, slot 4 + b
+        return [table_bytes[as_suffix:as_suffix + entry_bytes], table_bytes[as_prefix:as_prefix + entry_bytes]]
+
     post, line = bytearray(), 0
     for key, (b, e) in enumerate(_lists(db)):
-        entry = table[key * entry_bytes:(key + 1) * entry_bytes]
-        got_len = entry[4:4 + 2 * waves].view(np.uint16).tolist()
         v = db.values[b:e]
         region = bytearray()
+        lens = []
         for w in range(waves):
             sub = v[(v["branch"] // rows) == w].copy()
-            assert got_len[w] == len(sub)
+            lens.append(len(sub))
             sub["branch"] -= w * rows
             region += _pad(_chunks(sub, 0, len(sub), rows_pad - 1), 4)
-        if e > b:
-            assert int(entry[:4].view(np.uint32)[0]) == line
+        for entry in entries_of(key):
+            assert entry[4:4 + 2 * waves].view(np.uint16).tolist() == lens
+            if e > b:
+                assert int(entry[:4].view(np.uint32)[0]) == line
         region = _pad(bytes(region), LINE)
         post += region
         line += len(region) // LINE
