@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "team_device.hpp"
@@ -43,7 +44,7 @@ namespace epik_amd {
 // ---------------------------------------------------------------------------------
 // (Workgroups of one wave, 3 KB of LDS each.)
 template <int W>
-__global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t max_kmers)
+__global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
 {
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint64_t null_desc = null_chunk(p);
     constexpr int T = kTilesPerPass;
-    __shared__ uint4 held[T * TeamEntry<W>::kQuads * kWave];  // the entries of a short read's tiles, by lane
+    extern __shared__ __align__(16) uint4 held[];  // [held_passes][T][kQuads][64]: the entries of a short read's tiles, by lane
+    constexpr uint32_t kHeldPerPass = T * TeamEntry<W>::kQuads * kWave;
     unsigned long long chunk_at = 0;  // this wave's piece of the pool: next free descriptor, how many are left
     uint32_t chunk_left = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) tp.front_cursor[2] = p.n_reads;  // (the host sizes the next launch's pool by it)
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
             }
             return exact;
         };
-        const bool one_group = tp.passes == 1 && n_kmers <= (uint64_t)T * stride;  // wave-uniform
+        const bool one_group = tp.passes <= held_passes && n_kmers <= (uint64_t)T * stride;  // wave-uniform
         // ---- chunks per slice -------------------------------------------------------------------------
         if (one_group) {
             uint32_t ch[T], cls[T];
@@ -94,32 +96,41 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
             for (int t = 0; t < T; ++t) ch[t] = tile_char(seq, len, (uint64_t)t * stride);
 #pragma unroll
             for (int t = 0; t < T; ++t) cls[t] = tile_class(ch[t], len, (uint64_t)t * stride, p.char_class);
-            uint32_t acc[W];
-#pragma unroll
-            for (int s = 0; s < W; ++s) acc[s] = 0;
             // the entries wait in LDS for the second half (in registers, unrolled over tiles and slices, they
-            // cost the kernel three quarters of its waves)
-            uint4 raw[T][TeamEntry<W>::kQuads];
+            // cost the kernel three quarters of its waves); the tiles are encoded once for all passes
+            Tile tiles[T];
+            bool exact[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-#pragma unroll
-                for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = make_uint4(0u, 0u, 0u, 0u);
-                const Tile tl = tile_from_class(cls[t], len, (uint64_t)t * stride, n_kmers, k, sigma, stride);
-                if (exact_windows(tl)) TeamEntry<W>::fetch(tp, 0u, tl.key, (uint32_t)t * stride + (uint32_t)lane, raw[t]);
+                tiles[t] = tile_from_class(cls[t], len, (uint64_t)t * stride, n_kmers, k, sigma, stride);
+                exact[t] = exact_windows(tiles[t]);
             }
+            for (uint32_t pass = 0; pass < tp.passes; ++pass) {
+                uint32_t acc[W];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                TeamEntry<W> e;
-                e.unpack(raw[t]);
+                for (int s = 0; s < W; ++s) acc[s] = 0;
+                uint4 raw[T][TeamEntry<W>::kQuads];
 #pragma unroll
-                for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+                for (int t = 0; t < T; ++t) {
 #pragma unroll
-                for (int q = 0; q < TeamEntry<W>::kQuads; ++q) held[(t * TeamEntry<W>::kQuads + q) * kWave + lane] = raw[t][q];
-            }
+                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = make_uint4(0u, 0u, 0u, 0u);
+                    if (exact[t]) TeamEntry<W>::fetch(tp, pass, tiles[t].key, (uint32_t)t * stride + (uint32_t)lane, raw[t]);
+                }
 #pragma unroll
-            for (int s = 0; s < W; ++s) {
-                const uint32_t total = wave_sum_u32(acc[s]);
-                word = ((uint32_t)lane == kFrontHdrWords + (uint32_t)s) ? total : word;
+                for (int t = 0; t < T; ++t) {
+                    TeamEntry<W> e;
+                    e.unpack(raw[t]);
+#pragma unroll
+                    for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+#pragma unroll
+                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q)
+                        held[pass * kHeldPerPass + (t * TeamEntry<W>::kQuads + q) * kWave + lane] = raw[t][q];
+                }
+#pragma unroll
+                for (int s = 0; s < W; ++s) {
+                    const uint32_t total = wave_sum_u32(acc[s]);
+                    word = ((uint32_t)lane == kFrontHdrWords + pass * W + (uint32_t)s) ? total : word;
+                }
             }
         } else {
             for (uint32_t pass = 0; pass < tp.passes; ++pass) {
@@ -217,7 +228,8 @@ __global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t 
                 for (int t = 0; t < T; ++t) {
                     uint4 raw[TeamEntry<W>::kQuads];
 #pragma unroll
-                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[q] = held[(t * TeamEntry<W>::kQuads + q) * kWave + lane];
+                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q)
+                        raw[q] = held[pass * kHeldPerPass + (t * TeamEntry<W>::kQuads + q) * kWave + lane];
                     TeamEntry<W> e;
                     e.unpack(raw);
 #pragma unroll
@@ -558,11 +570,16 @@ uint64_t max_kmers_of(int counts)
 
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream)
 {
-    // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them)
+    // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them).  LDS: the table
+    // entries of a short read's tiles, for every pass -- up to 24 KB per workgroup of one wave; trees of more
+    // passes than that take the two-sweep path.
+    const uint32_t per_pass = (uint32_t)kTilesPerPass * (uint32_t)team_entry_bytes(waves) * 64u;
+    const uint32_t held_passes = std::max(1u, std::min(tp.passes, 24576u / per_pass));
+    const size_t lds = (size_t)held_passes * per_pass;
     if (waves == 4)
-        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(64), 0, stream, tp, max_kmers_of(counts));
+        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(64), lds, stream, tp, max_kmers_of(counts), held_passes);
     else if (waves == 8)
-        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(64), 0, stream, tp, max_kmers_of(counts));
+        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(64), lds, stream, tp, max_kmers_of(counts), held_passes);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
