@@ -627,8 +627,11 @@ static int counts_for(const epik_amd_placer *p, uint64_t longest)
 {
     const uint64_t kmers = longest >= p->params.kmer_size ? longest - p->params.kmer_size + 1 : 0;
     if (kmers >= 32768u) return epik_amd::kCounts32;
-    if (kmers <= 255u && p->geo[epik_amd::kCounts8].resident_waves > p->geo[epik_amd::kCounts16].resident_waves)
-        return epik_amd::kCounts8;
+    // (what counts where the streaming kernel places: ITS workgroups on a CU, with 8- and with 16-bit counts)
+    const auto &g8 = p->geo[epik_amd::kCounts8], &g16 = p->geo[epik_amd::kCounts16];
+    const bool more_waves = p->team && p->team_front && g8.max_blocks != 0 ? g8.stream_blocks > g16.stream_blocks
+                                                                           : g8.resident_waves > g16.resident_waves;
+    if (kmers <= 255u && more_waves) return epik_amd::kCounts8;
     return epik_amd::kCounts16;
 }
 
