@@ -34,8 +34,13 @@ def _oracle_jplace(path, oracle_lib, db, tree, records):
     jplace.write_jplace(path, PlacedCollection(seq_map, placed), "oracle", tree.newick(jplace=True))
 
 
-@pytest.mark.parametrize("devices", ["0", "0,0"])
-def test_epik_py_place_matches_oracle(tmp_path, oracle_lib, devices):
+@pytest.mark.parametrize("devices,kernel", [("0", None), ("0,0", None), ("0", "team4"), ("0,0", "team4x2")])
+def test_epik_py_place_matches_oracle(tmp_path, oracle_lib, devices, kernel, monkeypatch):
+    """kernel: None = what create() chooses for this tree (one wavefront per read); team4 / team4x2 = the driver
+    and the host-buffer entry point over the kernels of large trees (front + streaming + merge; the reads with
+    an N go down the one-kernel path behind them)."""
+    if kernel:
+        monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
     subprocess.run(["make", "-C", os.path.join(ROOT, "epik_amd", "host")], check=True, stdout=subprocess.DEVNULL)
     tree = synth.make_tree(60, seed=11)
     db = synth.make_db(tree.num_nodes, kmer_size=8, seed=12, p_present=0.5)
