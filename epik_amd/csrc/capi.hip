@@ -755,12 +755,15 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         tp.slice_bytes = g.lds_wave_bytes;
         tp.desc_bytes = epik_amd::team_desc_bytes(pp.keep_at_most);
         // (the streaming kernel numbers a read's slices in 32 bits)
-        if (p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32)) {
+        // (no room for the scratch of the three-kernel placement: the one-kernel placement needs none)
+        const bool streamed = p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32) &&
+                              reserve_front(p, n, total_chars, mode != kFinish) == EPIK_AMD_OK;
+        if (!streamed) (void)hipGetLastError();
+        if (streamed) {
             // Placing: front kernel (a wave per read), streaming kernel (a wave per slice of a read), merge
             // kernel (a wave per read), and team_place_kernel for the reads whose descriptors found the pool
             // full.  The halves of a k-mer-space-sharded placement: accumulate = front + streaming (+ the
             // other kernel for the rest), finish = headers + streaming + merge.
-            if (const int rc = reserve_front(p, n, total_chars, mode != kFinish); rc != EPIK_AMD_OK) return rc;
             tp.front_hdr = p->d_front_hdr;
             tp.front_hdr_stride = epik_amd::front_hdr_stride((uint32_t)p->team_waves * p->team_passes);
             tp.front_pool = p->d_front_pool;

@@ -5,7 +5,8 @@ Runs the bench workload through several variants IN ONE PROCESS, interleaved ove
 rounds (devices differ by several percent: never compare across runs).  A variant is a
 comma-separated list of key=value:
     lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
-    layout=compact|packed|paired, kernel=wave|team4|team8, wide=0|1|2, front=0|1 (team placement as one kernel | front + streaming kernel), ablate=<bitmask>, stamps=1   (env read at placer creation)
+    layout=compact|packed|paired, kernel=wave|team4|team8, wide=0|1|2, front=0|1 (team placement as one kernel | front + streaming + merge kernels), grid=<percent of the resident workgroups>,
+    ablate=<bitmask>, stamps=1   (env read at placer creation)
 LEAVES=<n> sets the tree (N = 2n - 1), N_READS the batch.
 Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
 """
