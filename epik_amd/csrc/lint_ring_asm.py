@@ -58,7 +58,20 @@ def lint_loop(name, body, events, problems):
     # asm vector instruction reads it (behind the stage's asm wait); from there to the refill
     # the compiler may reuse it.  The loop is cyclic, so at its top every slot counts as in flight.
     lo, hi = max(0, min(waits[0], loads[0]) - 1), loads[-1] + 15  # -1: the ;;#ASMSTART line
-    inflight = set(ring)
+    for back in range(lo, max(lo - 40, -1), -1):  # ... from the loop's label on (the pipelined ring reads LDS before its first asm)
+        if body[back].startswith(".LBB"):
+            lo = back
+            break
+    # Which slots are in flight where the loop is entered again: those its last trip left in flight behind
+    # its last asm load -- all of them for the plain ring, all but the cell of slot 0 for the pipelined one
+    # (its last stage has already waited for slot 0 and turned its cell into addresses).  One silent walk
+    # from "everything in flight" finds that state; the walk that reports starts from it.
+    inflight = _walk(name, body, lo, loads[-1] + 1, set(ring), None)
+    _walk(name, body, lo, hi, inflight, problems)
+
+
+def _walk(name, body, lo, hi, inflight, problems):
+    inflight = set(inflight)
     in_asm = False
     for n in range(lo, min(hi, len(body) - 1) + 1):
         s = body[n].strip()
@@ -89,8 +102,9 @@ def lint_loop(name, body, events, problems):
         if parts[0].startswith("v_mov_b32") and len(operands) == 2 and not regs_of(operands[1]) \
                 and not operands[1].startswith(("s", "v")):
             continue
-        if touched & inflight:
+        if touched & inflight and problems is not None:
             problems.append(f"{name}: line {n}: compiler code touches an in-flight ring register: {s}")
+    return inflight
 
 
 def lint(path):

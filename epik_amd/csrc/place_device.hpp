@@ -485,48 +485,55 @@ struct WaveLds {
 // ring of kDepth chunk loads in flight and are added into the wave's LDS vectors
 // (place.cpp:349-371).  score_top / count_top: LDS byte addresses of the dummy row (cell 0)
 // in the two vectors; chunks[] has one trip of spare entries behind n_padded.
+//
+// The loads are issued from inline asm (Layout::issue): hipcc must not count them, or it would
+// drain the ring (vmcnt(0)) once per trip of the loop.  A stage waits for its slot with a
+// counted s_waitcnt -- loads retire in issue order --, consumes the slot's two registers inside
+// asm statements only, and refills the slot with the next chunk.  (Letting hipcc read a slot
+// register itself, even behind a "+v" wait, is not safe: it is free to copy it into another
+// register AHEAD of the wait; lint_ring_asm.py checks the generated ISA for that.)
+// Every lane updates the row of its posting: branches are distinct inside a list, and the lanes
+// past the chunk's end all hold the dummy row, whose content nobody reads.  Two consecutive
+// chunks may hit the same row, so a chunk's LDS read-add-write has to be issued before the next
+// chunk's read (LDS executes a wave's operations in order): what CAN go under the round trip of
+// the reads is everything of the next stage that does not touch LDS.
+//
+// The stages are software-pipelined by hand: the wait for the NEXT slot and its two address
+// computations are issued between this stage's LDS reads and the add that needs their data, i.e.
+// under the LDS round trip the wave would otherwise just sit out (round 2: +4 % on the large
+// trees, +1 % on the benchmark).  While stage i waits for slot i+1, slot i has been consumed and
+// not yet refilled: seven slots are in flight and slot i+1 is the oldest, so the wait is
+// vmcnt(kLoads * (kDepth - 2)).
 // ---------------------------------------------------------------------------------
 template <typename Layout, typename CountT, int kDepth = kRing>
 __device__ __forceinline__ void stream_round(const PlaceParams &p, const typename WaveLds<CountT>::u64_t *chunks,
-                                             uint32_t n_padded,
-                                             uint32_t score_top, uint32_t count_top)
+                                                       uint32_t n_padded, uint32_t score_top, uint32_t count_top)
 {
     typedef __attribute__((address_space(3))) float lds_f32;
     typedef __attribute__((address_space(3))) CountT lds_count;
     const int lane = lane_id();
     (void)p;
-    // (3) stream the chunks through a ring of kDepth in-flight loads.  The loads are
-    // issued from inline asm (Layout::issue): hipcc must not count them, or it would
-    // drain the ring (vmcnt(0)) once per trip of the loop.  Stage i of a trip waits
-    // for slot i -- exactly kLoads*(kDepth-1) younger ring loads exist at that
-    // point and loads retire in issue order --, consumes the slot's two registers
-    // inside asm statements only, and refills the slot with the next chunk.
-    // (Letting hipcc read a slot register itself, even behind a "+v" wait, is not
-    // safe: it is free to copy it into another register AHEAD of the wait.)
     uint32_t ring_c[kDepth], ring_s[kDepth];
 #pragma unroll
     for (int i = 0; i < kDepth; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
-    // One stage: (1) asm: wait for the slot, turn its cell into the two LDS addresses;
-    // (2) hipcc: both LDS reads, and meanwhile the next chunk's descriptor words out of
-    // the lanes; (3) asm: the float add, reading the score straight from the slot
-    // register (place.cpp:366); (4) hipcc: count + 1 (:365), both LDS writes;
-    // (5) asm: refill the slot.  Every lane updates the row of its posting: branches
-    // are distinct inside a list, and the lanes past the chunk's end all hold the
-    // dummy row, whose content nobody reads.
-    auto stage = [&](uint32_t &slot_cell, uint32_t &slot_score, auto wait_count, auto &&refill_words,
-                     auto &&refill) {
-        uint32_t score_addr, count_addr;
+    // the two LDS addresses of a slot's posting, behind the wait for its loads
+    auto addresses = [](uint32_t &slot_cell, auto wait_count, uint32_t &score_addr, uint32_t &count_addr, uint32_t s_top,
+                        uint32_t c_top) {
         asm volatile("s_waitcnt vmcnt(%5)\n\t"
                      "v_mad_i32_i24 %0, %2, -4, %3\n\t"
                      "v_mad_i32_i24 %1, %2, %6, %4"
                      : "=&v"(score_addr), "=&v"(count_addr)
-                     : "v"(slot_cell), "s"(score_top), "s"(count_top), "n"(decltype(wait_count)::value),
+                     : "v"(slot_cell), "s"(s_top), "s"(c_top), "n"(decltype(wait_count)::value),
                        "n"(-(int)sizeof(CountT))
                      : "memory");
+    };
+    // one stage: LDS reads of this slot's rows; the refill's descriptor words out of the lanes and the NEXT
+    // slot's wait and addresses meanwhile; add, LDS writes; refill
+    auto stage = [&](uint32_t score_addr, uint32_t count_addr, uint32_t &slot_score, auto &&meanwhile, auto &&refill) {
         lds_f32 *score_cell = (lds_f32 *)(uintptr_t)score_addr;
         lds_count *count_cell = (lds_count *)(uintptr_t)count_addr;
 #ifdef EPIK_AMD_ABLATION
-        const bool skip_acc = (p.ablate & 1u) != 0;
+        const bool skip_acc = (p.ablate & 1u) != 0;  // (timing experiments: no LDS update)
         if (skip_acc) asm volatile("" ::"v"(score_addr), "v"(count_addr));
 #else
         constexpr bool skip_acc = false;
@@ -537,8 +544,8 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
             old_score = *score_cell;
             old_count = (uint32_t)*count_cell;
         }
-        refill_words();
-        __builtin_amdgcn_sched_barrier(0);  // the v_readlanes above overlap the LDS reads' latency
+        meanwhile();
+        __builtin_amdgcn_sched_barrier(0);
         float new_score;
         asm volatile("v_add_f32 %0, %1, %2" : "=v"(new_score) : "v"(old_score), "v"(slot_score) : "memory");
         if (!skip_acc) {
@@ -547,6 +554,8 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
         }
         refill();
     };
+    uint32_t sa, ca;  // addresses of the slot the next stage works on
+    addresses(ring_c[0], std::integral_constant<int, 0>{}, sa, ca, score_top, count_top);
     uint64_t d_next = chunks[lane & (kDepth - 1)];  // descriptors of trip 0, lane i <-> stage i
     for (uint32_t c0 = 0; c0 < n_padded; c0 += kDepth) {
         uint32_t field[Layout::kFields];
@@ -555,19 +564,31 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
 #pragma unroll
         for (int i = 0; i < kDepth; ++i) {
             uint32_t f[Layout::kFields];
+            uint32_t sa_next, ca_next;
             stage(
-                ring_c[i], ring_s[i], std::integral_constant<int, Layout::kLoads *(kDepth - 1)>{},
+                sa, ca, ring_s[i],
                 [&]() {
 #pragma unroll
                     for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
+                    addresses(ring_c[(i + 1) % kDepth], std::integral_constant<int, Layout::kLoads *(kDepth - 2)>{}, sa_next, ca_next, score_top,
+                              count_top);
                 },
                 [&]() { Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]); });
+            sa = sa_next, ca = ca_next;
         }
     }
-    // tail: nothing more to issue; retire the ring (the first stage waits for all of it)
+    // tail: nothing more to issue; retire the ring (slot 0 has been waited for; the rest after one drain)
 #pragma unroll
-    for (int i = 0; i < kDepth; ++i)
-        stage(ring_c[i], ring_s[i], std::integral_constant<int, 0>{}, []() {}, []() {});
+    for (int i = 0; i < kDepth; ++i) {
+        uint32_t sa_next = 0, ca_next = 0;
+        stage(
+            sa, ca, ring_s[i],
+            [&]() {
+                if (i + 1 < kDepth) addresses(ring_c[i + 1], std::integral_constant<int, 0>{}, sa_next, ca_next, score_top, count_top);
+            },
+            []() {});
+        sa = sa_next, ca = ca_next;
+    }
 }
 
 // ---------------------------------------------------------------------------------
