@@ -66,7 +66,15 @@ def lint_loop(name, body, events, problems):
     # its last asm load -- all of them for the plain ring, all but the cell of slot 0 for the pipelined one
     # (its last stage has already waited for slot 0 and turned its cell into addresses).  One silent walk
     # from "everything in flight" finds that state; the walk that reports starts from it.
-    inflight = _walk(name, body, lo, loads[-1] + 1, set(ring), None)
+    end = loads[-1] + 1
+    if body[lo].startswith(".LBB"):  # ... to the branch back to the loop's label
+        label = body[lo].split(":")[0]
+        for n in range(loads[-1], min(loads[-1] + 60, len(body))):
+            t = body[n].strip()
+            if t.startswith(("s_cbranch", "s_branch")) and t.split()[-1] == label:
+                end = n
+                break
+    inflight = _walk(name, body, lo, end, set(ring), None)
     _walk(name, body, lo, hi, inflight, problems)
 
 
