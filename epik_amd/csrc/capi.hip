@@ -44,6 +44,9 @@ int fail_hip(hipError_t e, const char *what)
     } while (0)
 
 constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // gfx950: 160 KiB per CU
+// Reads a wave (a workgroup of the streaming kernel: items per wave) places one after the other when a batch has
+// more reads than the device holds waves: sets the grid (launch()).
+constexpr uint64_t kReadsPerWave = 8, kReadsPerStreamBlock = 48;
 [[maybe_unused]] constexpr size_t kDbgWords = 64 + 4096 * 64;        // diagnostic builds: phase sums + a row of 8 per wave of 4096 workgroups
 
 }  // namespace
@@ -81,7 +84,8 @@ struct epik_amd_placer {
     unsigned long long *h_front_cursor = nullptr; // pinned: the same of the last launch that has finished
     uint64_t longest_read_hint = 0;               // epik_amd_placer_choose_counts
     uint32_t front_blocks = 0;                    // grid of the front kernel: the workgroups a device holds
-    uint64_t grid_percent = 100;                  // diagnostic builds: EPIK_AMD_GRID_PERCENT
+    uint32_t merge_blocks = 0;                    // ... of the merge kernel (four waves each)
+    uint64_t grid_percent = 0;                    // diagnostic builds: EPIK_AMD_GRID_PERCENT (of the resident workgroups; 0: as the product)
     uint64_t num_keys = 0;
     uint64_t num_entries = 0;
     // launch geometry per count width (epik_amd::CountBits)
@@ -468,7 +472,17 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
                                      hipHostMallocDefault));
             p->h_front_cursor[0] = p->h_front_cursor[1] = p->h_front_cursor[2] = 0;
             if (const char *e = std::getenv("EPIK_AMD_TEAM_POOL")) p->front_pool_forced = std::strtoull(e, nullptr, 10);
-            p->front_blocks = (uint32_t)prop.multiProcessorCount * 32u;  // workgroups of one wave: all a CU holds
+            // Grids of the front kernel (workgroups of one wave, 32 resident per CU) and of the merge kernel (four
+            // waves, 5 resident): several times what the device holds at once -- see kReadsPerWave in launch().
+            // (Front: 32 / 64 / 128 per CU = 2.08 / 1.95 / 1.87 ms per million reads; every wave takes the pool
+            // in pieces of its own, so more of them cost pool.)
+            uint32_t front_per_cu = 128, merge_per_cu = 32;
+#ifdef EPIK_AMD_ABLATION
+            if (const char *e = std::getenv("EPIK_AMD_FRONT_PER_CU")) front_per_cu = std::atoi(e) ? (uint32_t)std::atoi(e) : front_per_cu;
+            if (const char *e = std::getenv("EPIK_AMD_MERGE_PER_CU")) merge_per_cu = std::atoi(e) ? (uint32_t)std::atoi(e) : merge_per_cu;
+#endif
+            p->front_blocks = (uint32_t)prop.multiProcessorCount * front_per_cu;
+            p->merge_blocks = (uint32_t)prop.multiProcessorCount * merge_per_cu;
         }
     } else {
         for (int counts = 0; counts < 3; ++counts) {
@@ -732,11 +746,20 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     pp.lds_wave_bytes = g.lds_wave_bytes;
     // the team kernel places one read per workgroup, the others one per wave
     uint64_t blocks = p->team ? n : (n + g.waves_per_block - 1) / g.waves_per_block;
-    if (blocks > g.max_blocks) blocks = g.max_blocks;
+    if (blocks > g.max_blocks) {
+        // More reads than waves the device holds: every wave places several, one after the other.  NOT as few
+        // workgroups as are resident, each striding through the whole batch: the CUs do not progress alike,
+        // and the launch ends with its slowest wave.  With kReadsPerWave reads per wave the dispatcher hands
+        // workgroups to whichever CU has room (configs[1]: resident x 1 / 4 / 16 / 32 / 64 / one read per wave
+        // = 6.97 / 6.75 / 6.55 / 6.55 / 6.67 / 7.97 ms of the diagnostic build; a workgroup's start costs its
+        // share of clearing the LDS).
+        const uint64_t spread = (n + g.waves_per_block * kReadsPerWave - 1) / (g.waves_per_block * kReadsPerWave);
+        blocks = p->team ? g.max_blocks : std::max<uint64_t>(g.max_blocks, spread);
 #ifdef EPIK_AMD_ABLATION
-    // (timing experiments: fewer resident workgroups -- does a launch scale with them?)
-    blocks = std::max<uint64_t>(1, blocks * p->grid_percent / 100u);
+        // (timing experiments: a given multiple of the resident workgroups)
+        if (p->grid_percent) blocks = std::max<uint64_t>(1, g.max_blocks * p->grid_percent / 100u);
 #endif
+    }
     p->last_blocks = (uint32_t)blocks;
     p->last_streamed = false;
     p->last_geo = (uint32_t)p->counts;
@@ -772,7 +795,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.slow_list = p->d_slow_list;
             tp.slice_rows_out = p->d_slice_rows;
             tp.slice_sums_out = p->d_slice_sums;
-            const uint64_t front_blocks = std::min<uint64_t>(n, (uint64_t)p->front_blocks);  // (front, merge: a read per wave)
+            const uint64_t front_blocks = std::min<uint64_t>(n, (uint64_t)p->front_blocks);  // (a read per wave)
             if (mode == kFinish) {
                 HIP_TRY(epik_amd::launch_team_headers(tp, p->team_waves, p->counts, stream));
             } else {
@@ -780,15 +803,21 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
                 HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
             }
             const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
-            uint64_t stream_blocks = std::min<uint64_t>(n * parts, g.stream_blocks);
+            uint64_t stream_blocks = n * parts;
+            if (stream_blocks > g.stream_blocks) {  // as for `blocks` above (N = 9 999: resident x 1 / 4 / 16 / 32 / 64 = 20.2 / 19.9 / 19.4 / 19.4 / 19.6 ms)
+                stream_blocks = std::max<uint64_t>(g.stream_blocks, (n + kReadsPerStreamBlock - 1) / kReadsPerStreamBlock * parts);
 #ifdef EPIK_AMD_ABLATION
-            stream_blocks = std::max<uint64_t>(parts, stream_blocks * p->grid_percent / 100u / parts * parts);
+                if (p->grid_percent) stream_blocks = std::max<uint64_t>(parts, g.stream_blocks * p->grid_percent / 100u / parts * parts);
 #endif
+            }
             p->last_blocks = (uint32_t)stream_blocks;
             p->last_streamed = true;
             HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)stream_blocks),
                                                  g.stream_lds_bytes, stream));
-            if (mode != kAccumulate) HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)front_blocks), stream));
+            if (mode != kAccumulate) {
+                const uint64_t merge_blocks = std::min<uint64_t>((n + 3u) / 4u, (uint64_t)p->merge_blocks);
+                HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)merge_blocks), stream));
+            }
             if (mode != kFinish) {
                 tp.read_list = p->d_slow_list;
                 tp.read_list_count = p->d_front_cursor + 1;

@@ -472,6 +472,7 @@ struct WaveLds {
     __device__ __forceinline__ void clear(uint32_t n_pad) const
     {
         typedef __attribute__((address_space(3))) v4u u32x4_t;
+        // (a scalar loop over whole trips of 64 stores, unrolled four times, was slower: N = 9 999, +0.8 %)
         const uint32_t lane = __lane_id();
         auto *s16 = reinterpret_cast<u32x4_t *>(score);
         for (uint32_t i = lane; i < n_pad / 4u; i += 64u) s16[i] = v4u{0u, 0u, 0u, 0u};
@@ -731,6 +732,9 @@ struct TeamPartial {
 // works on one slice of the branches: correction, the slice's own top rows and its share of
 // sum_scores go to the merge area in LDS (ctx.cand / ctx.partial) and the function returns after
 // clearing the slice; team_merge() then does the part from "10^score of every row" on.
+#ifndef EPIK_AMD_TAU_STOP
+#define EPIK_AMD_TAU_STOP 8
+#endif
 template <typename Layout, typename CountT, typename Ctx>
 __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restrict__ kp, WaveLds<CountT> lds,
                                                     uint64_t read, uint64_t n_kmers, Ctx ctx)
@@ -912,15 +916,21 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         // edge is a candidate), found bit by bit from the top: one comparison and a ballot per bit, the rest
         // scalar.  Scores of one read lie close together, so the search usually starts below the bits they
         // share with the largest one.  (Seven rounds of wave maximum + knock-out took three times as long.)
+        // The search stops kTauStop bits above the end: what it has then is a lower bound of that value, within
+        // 2^kTauStop units in the last place (a hundredth in a score of a few hundred), and any tau that at
+        // least n_sel edges reach serves -- a lower one only lets the few edges in between into the candidates,
+        // which the ranking below drops again.  A step is a chain of compare, scalar count, scalar select: a
+        // hundred cycles of latency that nothing else fills.
+        constexpr int kTauStop = EPIK_AMD_TAU_STOP;
         const uint32_t top = wave_max_u32(lane_best);  // != 0: touched != 0
         uint32_t prefix = 0;
         int bit = 31;
-        {
-            constexpr int kShared = 20;  // try: everything above the low 20 bits as in `top`
-            const uint32_t trial = top & ~((1u << kShared) - 1u);
-            if (trial != 0 && (uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial, bit = kShared - 1;
+#pragma unroll
+        for (int shared = 20; shared <= 24; shared += 4) {  // try: everything above the low 20 (24) bits as in `top`
+            const uint32_t trial = top & ~((1u << shared) - 1u);
+            if (bit == 31 && trial != 0 && (uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial, bit = shared - 1;
         }
-        for (; bit >= 0; --bit) {
+        for (; bit >= kTauStop; --bit) {
             const uint32_t trial = prefix | (1u << bit);
             if ((uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial;
         }

@@ -129,10 +129,39 @@ struct MergeParams {
     uint32_t *n_rows, *kmer_counts;
 };
 
+// What the merge of a read reads when its slots and slices fit the lanes of a wave (S * keep_at_most <= 64): a
+// slot per lane, a slice's partial sum per lane.  team_merge_kernel asks for the next read's while it works on
+// this one's.
+struct MergeInputs {
+    v4u mine;
+    uint32_t touched, relative;
+    float ref_score;
+    double sum;
+};
 template <typename CandPtr, typename PartialPtr>
-__device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand, uint32_t cand_stride,
-                                                     PartialPtr partials, uint32_t n_slices, uint64_t read,
-                                                     uint64_t n_kmers)
+__device__ __forceinline__ MergeInputs load_merge_inputs(CandPtr cand, uint32_t cand_stride, PartialPtr partials,
+                                                         uint32_t n_slices, uint32_t keep)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    MergeInputs in;
+    in.mine = v4u{0u, 0u, 0u, 0u};
+    in.touched = in.relative = 0u;
+    in.ref_score = 0.0f;
+    in.sum = 0.0;
+    if (lane < n_slices * keep) in.mine = cand[(lane / keep) * cand_stride + lane % keep];
+    if (lane < n_slices) {
+        in.touched = partials[lane].touched;
+        in.relative = partials[lane].relative;
+        in.ref_score = partials[lane].ref_score;
+        in.sum = partials[lane].sum;
+    }
+    return in;
+}
+
+// kPreloaded: `in` holds the read's inputs (the caller made sure they fit the lanes)
+template <bool kPreloaded, typename CandPtr, typename PartialPtr>
+__device__ __forceinline__ void team_merge_body(MergeParams p, CandPtr cand, uint32_t cand_stride, PartialPtr partials,
+                                                uint32_t n_slices, uint64_t read, uint64_t n_kmers, const MergeInputs &in)
 {
     const int lane = lane_id();
     const uint32_t keep = p.keep_at_most;
@@ -145,8 +174,10 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand
     uint32_t my_touched = 0, my_relative = 0;
     float my_ref = 0.0f;
     double my_sum = 0.0;
-    const bool sums_in_lanes = n_slices <= (uint32_t)kWave;  // wave-uniform; else looped over below
-    if (sums_in_lanes && (uint32_t)lane < n_slices) {
+    const bool sums_in_lanes = kPreloaded || n_slices <= (uint32_t)kWave;  // wave-uniform; else looped over below
+    if constexpr (kPreloaded) {
+        my_touched = in.touched, my_relative = in.relative, my_ref = in.ref_score, my_sum = in.sum;
+    } else if (sums_in_lanes && (uint32_t)lane < n_slices) {
         my_touched = partials[lane].touched;
         my_relative = partials[lane].relative;
         my_ref = partials[lane].ref_score;
@@ -160,7 +191,7 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand
     uint32_t n_sel;
     float best_score;
     // Up to 64 slots (4 or 8 slices of the default 7 rows): one slot per lane, everything in registers.
-    const bool in_lanes = M <= (uint32_t)kWave;  // wave-uniform
+    const bool in_lanes = kPreloaded || M <= (uint32_t)kWave;  // wave-uniform
     v4u mine = v4u{0u, 0u, 0u, 0u};             // in_lanes: this lane's slot, .w = its rank
     int best_lane = 0;
     if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
@@ -175,7 +206,10 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand
         }
     } else if (in_lanes) {
         n_sel = keep < touched ? keep : touched;  // :137
-        if ((uint32_t)lane < M) mine = cand[((uint32_t)lane / keep) * cand_stride + (uint32_t)lane % keep];
+        if constexpr (kPreloaded)
+            mine = in.mine;
+        else if ((uint32_t)lane < M)
+            mine = cand[((uint32_t)lane / keep) * cand_stride + (uint32_t)lane % keep];
         const uint64_t key = mine.x ? (((uint64_t)mine.x << 32) | (uint64_t)(~mine.y)) : 0ull;
         uint32_t rank = 0;
         for (uint32_t j = 0; j < M; ++j) rank += readlane_u64(key, (int)j) > key ? 1u : 0u;
@@ -292,6 +326,13 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand
         }
     }
     if (lane == 0) p.n_rows[read] = (uint32_t)__popcll(kept_ranks);
+}
+template <typename CandPtr, typename PartialPtr>
+__device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand, uint32_t cand_stride,
+                                                     PartialPtr partials, uint32_t n_slices, uint64_t read,
+                                                     uint64_t n_kmers)
+{
+    team_merge_body<false>(p, cand, cand_stride, partials, n_slices, read, n_kmers, MergeInputs{});
 }
 
 

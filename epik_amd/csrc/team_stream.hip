@@ -42,9 +42,13 @@ namespace epik_amd {
 // a time: one atomic add per read on a single counter costs more than everything else here (measured: 8 ns
 // each, device-wide).
 // ---------------------------------------------------------------------------------
-// (Workgroups of one wave, 3 KB of LDS each.)
+// (Workgroups of one wave, 3 KB of LDS each.  With 4 slices per pass the kernel is held to the 64 registers of
+// eight waves per SIMD -- it needed 65.)
+#ifndef EPIK_AMD_FRONT_OCC
+#define EPIK_AMD_FRONT_OCC 8
+#endif
 template <int W>
-__global__ __launch_bounds__(64) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
+__global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
 {
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
@@ -531,14 +535,47 @@ __global__ __launch_bounds__(256) void team_merge_kernel(TeamParams tp, uint32_t
     mp.kmer_counts = p.kmer_counts;
     v4u *rows_out = static_cast<v4u *>(tp.slice_rows_out);  // (more than 64 slots: team_merge keeps the ranks in them)
     TeamPartial *sums_out = static_cast<TeamPartial *>(tp.slice_sums_out);
-    for (uint64_t read = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); read < p.n_reads; read += n_waves) {
-        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
-        const uint32_t flags = hdr[1], len = hdr[2];
-        if (flags & kFrontSlow) continue;  // team_place_kernel's
+    const uint64_t first = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    auto settled = [&](uint64_t read, uint32_t flags) {  // reads without rows to merge
+        if (flags & kFrontSlow) return true;  // team_place_kernel's
         if (flags & (kFrontNoRows | kFrontTooNarrow)) {
             if (lane == 0) p.n_rows[read] = (flags & kFrontNoRows) ? 0u : kCountsTooNarrow;
-            continue;
+            return true;
         }
+        return false;
+    };
+    if (n_slices * p.keep_at_most <= (uint32_t)kWave) {
+        // A slot per lane.  A read is a chain of three memory round trips (header, slots and sums, rows out) around
+        // a few hundred instructions: the wave asks for the next read's header, slots and sums before it works on
+        // this one's.  (Slots and sums of a read that has none to merge are whatever the buffers hold: not used.)
+        struct Fetched {
+            uint32_t flags, len;
+            MergeInputs in;
+        };
+        auto fetch = [&](uint64_t read) {
+            const uint32_t *hdr = reinterpret_cast<const uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
+            Fetched f;
+            f.flags = hdr[1], f.len = hdr[2];
+            f.in = load_merge_inputs(rows_out + read * n_slices * p.keep_at_most, p.keep_at_most, sums_out + read * n_slices,
+                                     n_slices, p.keep_at_most);
+            return f;
+        };
+        if (first >= p.n_reads) return;
+        Fetched cur = fetch(first);
+        for (uint64_t read = first; read < p.n_reads; read += n_waves) {
+            const uint64_t next_read = read + n_waves < p.n_reads ? read + n_waves : read;  // (the last one: once more, unused)
+            const Fetched next = fetch(next_read);
+            if (!settled(read, cur.flags))
+                team_merge_body<true>(mp, rows_out, p.keep_at_most, sums_out, n_slices, read, (uint64_t)cur.len - p.kmer_size + 1u,
+                                      cur.in);
+            cur = next;
+        }
+        return;
+    }
+    for (uint64_t read = first; read < p.n_reads; read += n_waves) {
+        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
+        const uint32_t flags = hdr[1], len = hdr[2];
+        if (settled(read, flags)) continue;
         team_merge(mp, rows_out + read * n_slices * p.keep_at_most, p.keep_at_most, sums_out + read * n_slices, n_slices,
                    read, (uint64_t)len - p.kmer_size + 1u);
     }
@@ -568,14 +605,23 @@ uint64_t max_kmers_of(int counts)
 
 }  // namespace
 
+namespace {
+// LDS of the front kernel: the table entries of a short read's tiles, for every pass -- up to 24 KB per
+// workgroup of one wave; trees of more passes than that take the two-sweep path.
+uint32_t front_held_passes(int waves, uint32_t passes, size_t *lds)
+{
+    const uint32_t per_pass = (uint32_t)kTilesPerPass * (uint32_t)team_entry_bytes(waves) * 64u;
+    const uint32_t held_passes = std::max(1u, std::min(passes, 24576u / per_pass));
+    *lds = (size_t)held_passes * per_pass;
+    return held_passes;
+}
+}  // namespace
+
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream)
 {
-    // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them).  LDS: the table
-    // entries of a short read's tiles, for every pass -- up to 24 KB per workgroup of one wave; trees of more
-    // passes than that take the two-sweep path.
-    const uint32_t per_pass = (uint32_t)kTilesPerPass * (uint32_t)team_entry_bytes(waves) * 64u;
-    const uint32_t held_passes = std::max(1u, std::min(tp.passes, 24576u / per_pass));
-    const size_t lds = (size_t)held_passes * per_pass;
+    // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them)
+    size_t lds = 0;
+    const uint32_t held_passes = front_held_passes(waves, tp.passes, &lds);
     if (waves == 4)
         hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(64), lds, stream, tp, max_kmers_of(counts), held_passes);
     else if (waves == 8)

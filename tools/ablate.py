@@ -50,7 +50,9 @@ def main():
         if "kernel" in kv:
             os.environ["EPIK_AMD_KERNEL"] = kv["kernel"]
         os.environ["EPIK_AMD_TEAM_FRONT"] = kv.get("front", "1")
-        os.environ["EPIK_AMD_GRID_PERCENT"] = kv.get("grid", "100")
+        os.environ["EPIK_AMD_GRID_PERCENT"] = kv.get("grid", "0")
+        os.environ["EPIK_AMD_FRONT_PER_CU"] = kv.get("fb", "0")  # workgroups per CU of the front / merge kernel (0: as queried)
+        os.environ["EPIK_AMD_MERGE_PER_CU"] = kv.get("mb", "0")
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))
         desc = capi.PlacerDesc(
             abi_version=capi.ABI_VERSION, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
