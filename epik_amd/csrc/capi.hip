@@ -46,7 +46,17 @@ int fail_hip(hipError_t e, const char *what)
 constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // gfx950: 160 KiB per CU
 // Reads a wave (a workgroup of the streaming kernel: items per wave) places one after the other when a batch has
 // more reads than the device holds waves: sets the grid (launch()).
-constexpr uint64_t kReadsPerWave = 8, kReadsPerStreamBlock = 48;
+constexpr uint64_t kGridRounds = 24, kMinGridRounds = 8, kMinReadsPerWave = 2, kMinReadsPerStreamBlock = 16;
+// ... the grid for `units` work items (reads per wave, reads per workgroup) of a kernel of which `resident`
+// workgroups fit the device, `min_per_block` items a workgroup at least: whole rounds of the resident workgroups,
+// and the resident ones alone, striding, where that makes fewer than kMinGridRounds (what the last workgroups
+// leave idle is up to a round)
+inline uint64_t spread_grid(uint64_t units, uint64_t resident, uint64_t min_per_block)
+{
+    if (units <= resident) return units;
+    const uint64_t rounds = std::min<uint64_t>(kGridRounds, units / (resident * min_per_block));
+    return rounds >= kMinGridRounds ? resident * rounds : resident;
+}
 [[maybe_unused]] constexpr size_t kDbgWords = 64 + 4096 * 64;        // diagnostic builds: phase sums + a row of 8 per wave of 4096 workgroups
 
 }  // namespace
@@ -661,6 +671,15 @@ struct shard_buffers {
 enum launch_mode { kPlace = epik_amd::kTeamModePlace, kAccumulate = epik_amd::kTeamModeAccumulate,
                    kFinish = epik_amd::kTeamModeFinish };
 
+// Grid of the front kernel (workgroups of one wave, a read at a time): up to p->front_blocks, four times what the
+// device holds -- but a wave takes the pool in pieces of kFrontPoolChunk descriptors, a few dozen reads' worth: with
+// fewer reads per wave than that the descriptors of a small batch would lie spread over a pool many times their size.
+uint64_t front_grid(const epik_amd_placer *p, uint64_t n)
+{
+    const uint64_t resident = (uint64_t)p->front_blocks / 4u;
+    return std::min<uint64_t>(n, std::max<uint64_t>(resident, std::min<uint64_t>(p->front_blocks, n / 32u)));
+}
+
 // Scratch of the front kernel for a launch of n reads (`total_chars`: their characters when the caller knows,
 // else 0).  The pool is sized from what the image says a k-mer's descriptors take and from what earlier
 // launches asked for; a read that finds it full is placed by team_place_kernel, so the estimate only
@@ -699,7 +718,7 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, b
         const double per_kmer = (double)p->plan.team_chunks / (double)std::max<uint64_t>(p->plan.present_codes, 1);
         const uint64_t chars = total_chars ? total_chars : n * (p->longest_read_hint ? p->longest_read_hint : 160u);
         // ... and what the waves of the front kernel leave unused of the pieces they take the pool in
-        const uint64_t front_waves = std::min<uint64_t>(n, (uint64_t)p->front_blocks);
+        const uint64_t front_waves = front_grid(p, n);
         double est = (double)chars * per_kmer * 1.1 + (double)n * slices * epik_amd::kTeamRing +
                      (double)front_waves * epik_amd::kFrontPoolChunk;
         // what the last finished launch asked for per read, if that is more
@@ -749,12 +768,12 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     if (blocks > g.max_blocks) {
         // More reads than waves the device holds: every wave places several, one after the other.  NOT as few
         // workgroups as are resident, each striding through the whole batch: the CUs do not progress alike,
-        // and the launch ends with its slowest wave.  With kReadsPerWave reads per wave the dispatcher hands
-        // workgroups to whichever CU has room (configs[1]: resident x 1 / 4 / 16 / 32 / 64 / one read per wave
-        // = 6.97 / 6.75 / 6.55 / 6.55 / 6.67 / 7.97 ms of the diagnostic build; a workgroup's start costs its
-        // share of clearing the LDS).
-        const uint64_t spread = (n + g.waves_per_block * kReadsPerWave - 1) / (g.waves_per_block * kReadsPerWave);
-        blocks = p->team ? g.max_blocks : std::max<uint64_t>(g.max_blocks, spread);
+        // and the launch ends with its slowest wave.  A grid of kGridRounds times the resident workgroups lets
+        // the dispatcher hand the next workgroup to whichever CU has room, and what the last ones leave idle is
+        // a 24th of the launch (configs[1]: resident x 1 / 4 / 16 / 32 / 64 / one read per wave = 6.97 / 6.75 /
+        // 6.55 / 6.55 / 6.67 / 7.97 ms of the diagnostic build; a workgroup's start costs its share of clearing
+        // the LDS, hence a minimum of reads per wave for the small batches).
+        blocks = p->team ? g.max_blocks : spread_grid(blocks, g.max_blocks, kMinReadsPerWave);
 #ifdef EPIK_AMD_ABLATION
         // (timing experiments: a given multiple of the resident workgroups)
         if (p->grid_percent) blocks = std::max<uint64_t>(1, g.max_blocks * p->grid_percent / 100u);
@@ -795,7 +814,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.slow_list = p->d_slow_list;
             tp.slice_rows_out = p->d_slice_rows;
             tp.slice_sums_out = p->d_slice_sums;
-            const uint64_t front_blocks = std::min<uint64_t>(n, (uint64_t)p->front_blocks);  // (a read per wave)
+            const uint64_t front_blocks = front_grid(p, n);
             if (mode == kFinish) {
                 HIP_TRY(epik_amd::launch_team_headers(tp, p->team_waves, p->counts, stream));
             } else {
@@ -804,8 +823,9 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             }
             const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
             uint64_t stream_blocks = n * parts;
+            if (stream_blocks > g.stream_blocks && mode != kPlace) stream_blocks = g.stream_blocks;  // (bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s against 15.1 spread)
             if (stream_blocks > g.stream_blocks) {  // as for `blocks` above (N = 9 999: resident x 1 / 4 / 16 / 32 / 64 = 20.2 / 19.9 / 19.4 / 19.4 / 19.6 ms)
-                stream_blocks = std::max<uint64_t>(g.stream_blocks, (n + kReadsPerStreamBlock - 1) / kReadsPerStreamBlock * parts);
+                stream_blocks = spread_grid(n, g.stream_blocks / parts, kMinReadsPerStreamBlock) * parts;
 #ifdef EPIK_AMD_ABLATION
                 if (p->grid_percent) stream_blocks = std::max<uint64_t>(parts, g.stream_blocks * p->grid_percent / 100u / parts * parts);
 #endif

@@ -177,10 +177,10 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     for (int c = 0; c < 3; ++c) plan.wave_resident[c] = wave_fits ? wave_kernel_resident_waves(plan.n_pad, c) : 0;
 
     // ---- kernel: one wavefront per read while enough of them fit a CU, else a workgroup per read ----
-    // (measured, r02: with the team placement as front + streaming + merge kernels it wins where fewer than 6
-    // waves of the other fit a CU with 16-bit counts, N >~ 4 500: 58 against 54 M reads/s at N = 4 999,
-    // 61 against 66 at N = 3 999)
-    bool team = !wave_fits || plan.wave_resident[kCounts16] < 6;
+    // (measured, r02: with the team placement as front + streaming + merge kernels it wins where fewer than 8
+    // waves of the other fit a CU with 16-bit counts, N >~ 3 100: 86 against 82 M reads/s at N = 3 499, 86
+    // against 71 at N = 3 999; 89 against 92 at N = 2 999)
+    bool team = !wave_fits || plan.wave_resident[kCounts16] < 8;
     int forced_waves = 0;
     uint32_t forced_passes = 0;
     if (forced_kernel && forced_kernel[0]) {
