@@ -21,7 +21,7 @@ def main():
             reads.append(cur)
             cur = []
         cur.append((code, cycles))
-    reads = reads[50:-5]  # steady state
+    reads = reads[min(50, len(reads) // 5):len(reads) - min(5, len(reads) // 10)]  # steady state (a workgroup of the product's grid places some fifty reads)
     total, count = collections.Counter(), collections.Counter()
     for r in reads:
         for code, cycles in r:
