@@ -93,6 +93,7 @@ struct epik_amd_placer {
     unsigned long long *d_front_cursor = nullptr; // [0] descriptors asked for, [1] reads on the slow list, [2] reads of the launch
     unsigned long long *h_front_cursor = nullptr; // pinned: the same of the last launch that has finished
     uint64_t longest_read_hint = 0;               // epik_amd_placer_choose_counts
+    uint32_t max_blocks_cap = 0;                  // tests: EPIK_AMD_MAX_BLOCKS
     uint32_t front_blocks = 0;                    // grid of the front kernel: the workgroups a device holds
     uint32_t merge_blocks = 0;                    // ... of the merge kernel (four waves each)
     uint64_t grid_percent = 0;                    // diagnostic builds: EPIK_AMD_GRID_PERCENT (of the resident workgroups; 0: as the product)
@@ -536,6 +537,9 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
             CREATE_TRY(epik_amd::set_finish_reads_lds_limit(counts, g.lds_block_bytes));
         }
     }
+    // EPIK_AMD_MAX_BLOCKS=<n> (tests): launch as if the device held only so many workgroups -- small batches then
+    // take the grids of the large ones
+    if (const char *e = std::getenv("EPIK_AMD_MAX_BLOCKS")) p->max_blocks_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     // EPIK_AMD_WIDE_COUNTS=0|1|2: 16-, 32-, 8-bit counts whatever the reads (tests, experiments)
     if (const char *w = std::getenv("EPIK_AMD_WIDE_COUNTS")) {
         p->counts = w[0] == '1' ? epik_amd::kCounts32 : w[0] == '2' ? epik_amd::kCounts8 : epik_amd::kCounts16;
@@ -765,7 +769,8 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     pp.lds_wave_bytes = g.lds_wave_bytes;
     // the team kernel places one read per workgroup, the others one per wave
     uint64_t blocks = p->team ? n : (n + g.waves_per_block - 1) / g.waves_per_block;
-    if (blocks > g.max_blocks) {
+    const uint64_t resident = p->max_blocks_cap ? std::min<uint64_t>(g.max_blocks, p->max_blocks_cap) : g.max_blocks;
+    if (blocks > resident) {
         // More reads than waves the device holds: every wave places several, one after the other.  NOT as few
         // workgroups as are resident, each striding through the whole batch: the CUs do not progress alike,
         // and the launch ends with its slowest wave.  A grid of kGridRounds times the resident workgroups lets
@@ -773,10 +778,14 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         // a 24th of the launch (configs[1]: resident x 1 / 4 / 16 / 32 / 64 / one read per wave = 6.97 / 6.75 /
         // 6.55 / 6.55 / 6.67 / 7.97 ms of the diagnostic build; a workgroup's start costs its share of clearing
         // the LDS, hence a minimum of reads per wave for the small batches).
-        blocks = p->team ? g.max_blocks : spread_grid(blocks, g.max_blocks, kMinReadsPerWave);
+        // (Tried instead: the resident grid, its waves taking the reads four at a time from a device-wide counter,
+        // the question for the next four asked just before a read streams.  N = 1 303 / 1 999: +1.5 / +3 % over
+        // this grid; configs[1]: -1.5 % (two more registers in a kernel held to 96, spilled); two reads at a time
+        // or one: the counter itself is the limit, 13 ns per question.  Not kept.)
+        blocks = p->team ? resident : spread_grid(blocks, resident, kMinReadsPerWave);
 #ifdef EPIK_AMD_ABLATION
         // (timing experiments: a given multiple of the resident workgroups)
-        if (p->grid_percent) blocks = std::max<uint64_t>(1, g.max_blocks * p->grid_percent / 100u);
+        if (p->grid_percent) blocks = std::max<uint64_t>(1, resident * p->grid_percent / 100u);
 #endif
     }
     p->last_blocks = (uint32_t)blocks;
@@ -823,11 +832,12 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             }
             const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
             uint64_t stream_blocks = n * parts;
-            if (stream_blocks > g.stream_blocks && mode != kPlace) stream_blocks = g.stream_blocks;  // (bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s against 15.1 spread)
-            if (stream_blocks > g.stream_blocks) {  // as for `blocks` above (N = 9 999: resident x 1 / 4 / 16 / 32 / 64 = 20.2 / 19.9 / 19.4 / 19.4 / 19.6 ms)
-                stream_blocks = spread_grid(n, g.stream_blocks / parts, kMinReadsPerStreamBlock) * parts;
+            const uint64_t stream_resident = p->max_blocks_cap ? std::min<uint64_t>(g.stream_blocks, (uint64_t)p->max_blocks_cap * parts) : g.stream_blocks;
+            if (stream_blocks > stream_resident && mode != kPlace) stream_blocks = stream_resident;  // (bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s against 15.1 spread)
+            if (stream_blocks > stream_resident) {  // as for `blocks` above (N = 9 999: resident x 1 / 4 / 16 / 32 / 64 = 20.2 / 19.9 / 19.4 / 19.4 / 19.6 ms)
+                stream_blocks = spread_grid(n, stream_resident / parts, kMinReadsPerStreamBlock) * parts;
 #ifdef EPIK_AMD_ABLATION
-                if (p->grid_percent) stream_blocks = std::max<uint64_t>(parts, g.stream_blocks * p->grid_percent / 100u / parts * parts);
+                if (p->grid_percent) stream_blocks = std::max<uint64_t>(parts, stream_resident * p->grid_percent / 100u / parts * parts);
 #endif
             }
             p->last_blocks = (uint32_t)stream_blocks;

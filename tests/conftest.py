@@ -35,9 +35,14 @@ def select_kernel(monkeypatch, name):
     (paired, filtered, packed, compact), or teamW[xP] -- the team placement as front kernel +
     streaming kernel (team_stream.hip) --, teamW[xP]-classic -- team_place_kernel alone --, or
     teamW[xP]-smallpool -- a descriptor pool so small that some reads of a batch fall to
-    team_place_kernel behind the streaming kernel."""
-    for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT"):
+    team_place_kernel behind the streaming kernel.  Any of them with -fewblocks: a device that holds two
+    workgroups (EPIK_AMD_MAX_BLOCKS), so that the waves of a test-sized batch place several reads one after
+    the other on the grids of a million-read batch (capi.hip: spread_grid)."""
+    for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT", "EPIK_AMD_MAX_BLOCKS"):
         monkeypatch.delenv(var, raising=False)
+    if name.endswith("-fewblocks"):
+        name = name[:-len("-fewblocks")]
+        monkeypatch.setenv("EPIK_AMD_MAX_BLOCKS", "2")
     if name.startswith("team"):
         kernel, _, variant = name.partition("-")
         monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)

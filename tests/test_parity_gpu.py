@@ -16,7 +16,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact", "team4", "team8", "team4x3",
-                                      "team4-classic", "team4x3-classic", "team4-smallpool", "team8x2-smallpool"])
+                                      "team4-classic", "team4x3-classic", "team4-smallpool", "team8x2-smallpool",
+                                      "paired-fewblocks", "team4-fewblocks", "team8x2-fewblocks", "team4-classic-fewblocks"])
 def db_layout(request, monkeypatch):
     """Every parity test runs on every HBM layout of the database (line-aligned lists behind a
     direct-index table -- keyed by k-mer, or by the overlap of consecutive k-mers for DNA, or behind
