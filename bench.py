@@ -349,7 +349,9 @@ def main():
 
     if rank == 0:
         info = placer.launch_info()
-        n_rows_host = d_nrows.cpu().numpy()
+        n_rows_host = d_nrows.cpu().numpy().view(np.uint32).astype(np.int64)
+        if (n_rows_host > keep).any():
+            raise SystemExit("a read came back marked EPIK_AMD_ROWS_COUNTS_TOO_NARROW: the bench chose too narrow counts")
         result = {
             "metric": "reads placed/sec",
             "value": (1 if kmer_shard else world) * n * args.steps / elapsed,

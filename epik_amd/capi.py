@@ -38,6 +38,10 @@ EXPORTS = (
     "epik_amd_placer_create_sharded",
     "epik_amd_placer_accumulate_device",
     "epik_amd_placer_finish_device",
+    "epik_amd_placer_partial_info",
+    "epik_amd_placer_accumulate_lists_device",
+    "epik_amd_placer_finish_lists_device",
+    "epik_amd_placer_last_path",
     "epik_amd_placer_set_wide_counts",
     "epik_amd_placer_choose_counts",
     "epik_amd_placer_launch_info",
@@ -86,6 +90,25 @@ class Plan(ctypes.Structure):
     ]
 
 
+class PartialInfo(ctypes.Structure):
+    """`epik_amd_partial_info`."""
+
+    _fields_ = [
+        ("lists", ctypes.c_uint32),
+        ("slices", ctypes.c_uint32),
+        ("slice_rows", ctypes.c_uint32),
+        ("entry_bytes", ctypes.c_uint32),
+        ("num_branches", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+        ("postings_per_kmer", ctypes.c_double),
+    ]
+
+
+MAX_SHARDS = 16
+#: count of a partial list that found no room in d_entries
+LIST_OVERFLOW = 0xFFFFFFFF
+PATH_WAVE, PATH_TEAM_ONE_KERNEL, PATH_TEAM_STREAMED = 0, 1, 2
+
 #: n_rows of a read with more k-mers than the counts of a device-pointer launch hold
 ROWS_COUNTS_TOO_NARROW = 0xFFFFFFFF
 
@@ -123,6 +146,15 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_placer_accumulate_device.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, vp]
     lib.epik_amd_placer_finish_device.restype = i32
     lib.epik_amd_placer_finish_device.argtypes = [vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.epik_amd_placer_partial_info.restype = i32
+    lib.epik_amd_placer_partial_info.argtypes = [vp, ctypes.POINTER(PartialInfo)]
+    lib.epik_amd_placer_accumulate_lists_device.restype = i32
+    lib.epik_amd_placer_accumulate_lists_device.argtypes = [vp, vp, vp, u64, ctypes.c_uint32, vp, u64, vp, vp, vp, vp, vp, vp]
+    lib.epik_amd_placer_finish_lists_device.restype = i32
+    lib.epik_amd_placer_finish_lists_device.argtypes = [vp, vp, u64, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                        vp, vp, vp, vp, vp, vp]
+    lib.epik_amd_placer_last_path.restype = i32
+    lib.epik_amd_placer_last_path.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.epik_amd_placer_plan.restype = i32
     lib.epik_amd_placer_plan.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32, u64,
                                          ctypes.POINTER(Plan)]

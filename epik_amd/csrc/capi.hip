@@ -65,7 +65,7 @@ struct epik_amd_placer {
     int device = 0;
     epik_amd::DbLayout layout = epik_amd::DbLayout::kCompact32;
     int counts = epik_amd::kCounts16;  // width of the per-branch counts the next device launch uses
-    bool counts_forced = false;        // set by the caller / the environment: place() does not choose
+    bool counts_forced = false;        // set by set_wide_counts / the environment: place() chooses only to WIDEN
     bool timing = false;
     void *d_table = nullptr;       // offsets (compact) or {len, line} entries (packed)
     uint64_t *d_filter = nullptr;  // presence words of the filtered layout
@@ -109,6 +109,10 @@ struct epik_amd_placer {
         // team_stream_kernel (team placement as front + streaming + merge kernels): workgroups of 4 waves
         uint32_t stream_lds_bytes = 0, stream_blocks = 0;
     } geo[3];
+    uint32_t *d_sparse_cap = nullptr;             // partial lists: room per (read, slice), front kernel -> scan kernel
+    size_t sparse_cap_items = 0;
+    uint64_t front_failed_reads = 0;              // != 0: the scratch of the three-kernel placement could not be had for a
+                                                  // launch of that many reads (not tried again for as many or more)
     uint32_t last_blocks = 0;
     bool last_streamed = false;  // the last launch went through team_stream_kernel
     uint32_t last_geo = 0;
@@ -210,6 +214,7 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_slice_sums);
     (void)hipFree(p->d_front_pool);
     (void)hipFree(p->d_front_cursor);
+    (void)hipFree(p->d_sparse_cap);
     if (p->h_front_cursor) (void)hipHostFree(p->h_front_cursor);
     if (p->ev_start) (void)hipEventDestroy(p->ev_start);
     if (p->ev_stop) (void)hipEventDestroy(p->ev_stop);
@@ -649,6 +654,12 @@ int epik_amd_placer_build_image(const epik_amd_placer_desc *d, uint32_t shard_in
     }
 }
 
+// k-mers a read may have with counts of that width (the top bit of 16- and 32-bit counts is a flag)
+static uint64_t max_kmers_of_counts(int counts)
+{
+    return counts == epik_amd::kCounts8 ? 255u : counts == epik_amd::kCounts16 ? 32767u : 0x7fffffffull;
+}
+
 // The narrowest counts that hold the k-mers of a read of `longest` characters, 8 bits only when
 // that keeps more waves on a CU than 16.
 static int counts_for(const epik_amd_placer *p, uint64_t longest)
@@ -671,9 +682,19 @@ struct shard_buffers {
     const int32_t *amb_slot = nullptr;
     uint32_t *amb_order = nullptr;
     float *amb_avg = nullptr;
+    // ... or its partial lists (accumulate writes entries / index / part_total; finish reads `sources`)
+    uint8_t *entries = nullptr;
+    uint64_t entries_cap = 0;
+    uint2 *index = nullptr;
+    unsigned long long *part_total = nullptr;
+    uint32_t parts = 0;
+    const epik_amd::SparseSources *sources = nullptr;
 };
 enum launch_mode { kPlace = epik_amd::kTeamModePlace, kAccumulate = epik_amd::kTeamModeAccumulate,
-                   kFinish = epik_amd::kTeamModeFinish };
+                   kFinish = epik_amd::kTeamModeFinish, kAccumulateLists = epik_amd::kTeamModeAccumulateLists,
+                   kFinishLists = epik_amd::kTeamModeFinishLists };
+inline bool is_finish(launch_mode m) { return m == kFinish || m == kFinishLists; }
+inline bool is_accumulate(launch_mode m) { return m == kAccumulate || m == kAccumulateLists; }
 
 // Grid of the front kernel (workgroups of one wave, a read at a time): up to p->front_blocks, four times what the
 // device holds -- but a wave takes the pool in pieces of kFrontPoolChunk descriptors, a few dozen reads' worth: with
@@ -688,9 +709,15 @@ uint64_t front_grid(const epik_amd_placer *p, uint64_t n)
 // else 0).  The pool is sized from what the image says a k-mer's descriptors take and from what earlier
 // launches asked for; a read that finds it full is placed by team_place_kernel, so the estimate only
 // decides speed.  Grown, never shrunk; growing frees the old buffer (which waits for the device).
-static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, bool with_pool)
+static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, bool with_pool, bool lists)
 {
     const uint32_t slices = (uint32_t)p->team_waves * p->team_passes;
+    if (lists && (size_t)n * slices > p->sparse_cap_items) {
+        (void)hipFree(p->d_sparse_cap);
+        p->d_sparse_cap = nullptr, p->sparse_cap_items = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_sparse_cap), (size_t)n * slices * sizeof(uint32_t)));
+        p->sparse_cap_items = (size_t)n * slices;
+    }
     const size_t hdr_bytes = (size_t)n * epik_amd::front_hdr_stride(slices);
     if (hdr_bytes > p->front_hdr_bytes) {
         (void)hipFree(p->d_front_hdr);
@@ -752,9 +779,12 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
                   uint64_t total_chars = 0)
 {
     if (n == 0) return EPIK_AMD_OK;
+    const bool lists = mode == kAccumulateLists || mode == kFinishLists;
     epik_amd::PlaceParams pp = p->params;
     pp.partial_scores = shard.scores;  // non-null in the placement kernels: accumulate only
     pp.partial_counts = shard.counts;
+    // (the dense partial counts are uint16: a read of more k-mers is marked, not wrapped, whatever the LDS counts hold)
+    pp.max_kmers_cap = (mode == kAccumulate || mode == kFinish) ? 65535u : 0u;
     pp.amb_slot = shard.amb_slot;
     pp.amb_order = shard.amb_order;
     pp.amb_avg = shard.amb_avg;
@@ -766,6 +796,9 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     pp.kmer_counts = static_cast<uint32_t *>(d_counts);
     const auto &g = p->geo[p->counts];
     if (g.max_blocks == 0) return fail(EPIK_AMD_ERR_UNSUPPORTED, "no kernel of this count width for this tree size");
+    if (lists && !(p->team && p->team_front))
+        return fail(EPIK_AMD_ERR_UNSUPPORTED, "partial lists need the front / streaming / merge kernels of a large tree "
+                                              "(epik_amd_placer_partial_info says so: use the dense calls)");
     pp.lds_wave_bytes = g.lds_wave_bytes;
     // the team kernel places one read per workgroup, the others one per wave
     uint64_t blocks = p->team ? n : (n + g.waves_per_block - 1) / g.waves_per_block;
@@ -791,7 +824,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     p->last_blocks = (uint32_t)blocks;
     p->last_streamed = false;
     p->last_geo = (uint32_t)p->counts;
-    const bool timed = p->timing && mode != kFinish;
+    const bool timed = p->timing && !is_finish(mode);
     if (timed) HIP_TRY(hipEventRecord(p->ev_start, stream));
     if (p->team) {
         epik_amd::TeamParams tp{};
@@ -806,15 +839,23 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         tp.slice_bytes = g.lds_wave_bytes;
         tp.desc_bytes = epik_amd::team_desc_bytes(pp.keep_at_most);
         // (the streaming kernel numbers a read's slices in 32 bits)
-        // (no room for the scratch of the three-kernel placement: the one-kernel placement needs none)
-        const bool streamed = p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32) &&
-                              reserve_front(p, n, total_chars, mode != kFinish) == EPIK_AMD_OK;
-        if (!streamed) (void)hipGetLastError();
+        // No room for the scratch of the three-kernel placement: the one-kernel placement needs none.  Remembered
+        // on the handle -- a launch of as many reads or more does not try again (every attempt is a hipFree and a
+        // hipMalloc, i.e. a wait for the device) -- and told by epik_amd_placer_last_path().
+        bool streamed = p->team_front && n * ((uint64_t)p->team_waves * p->team_passes) < (1ull << 32) &&
+                        !(p->front_failed_reads && n >= p->front_failed_reads);
+        if (streamed && reserve_front(p, n, total_chars, !is_finish(mode), mode == kAccumulateLists) != EPIK_AMD_OK) {
+            (void)hipGetLastError();
+            p->front_failed_reads = n;
+            streamed = false;
+        }
+        if (lists && !streamed)
+            return fail(EPIK_AMD_ERR_HIP, "partial lists: no device memory for the scratch of a launch of this size");
         if (streamed) {
             // Placing: front kernel (a wave per read), streaming kernel (a wave per slice of a read), merge
             // kernel (a wave per read), and team_place_kernel for the reads whose descriptors found the pool
-            // full.  The halves of a k-mer-space-sharded placement: accumulate = front + streaming (+ the
-            // other kernel for the rest), finish = headers + streaming + merge.
+            // full.  The halves of a k-mer-space-sharded placement: accumulate = front (+ scan: partial lists) +
+            // streaming (+ the other kernel for the rest), finish = headers + streaming + merge.
             tp.front_hdr = p->d_front_hdr;
             tp.front_hdr_stride = epik_amd::front_hdr_stride((uint32_t)p->team_waves * p->team_passes);
             tp.front_pool = p->d_front_pool;
@@ -823,17 +864,30 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.slow_list = p->d_slow_list;
             tp.slice_rows_out = p->d_slice_rows;
             tp.slice_sums_out = p->d_slice_sums;
+            if (mode == kAccumulateLists) {
+                tp.sparse_cap = p->d_sparse_cap;
+                tp.sparse_index = shard.index;
+                tp.sparse_entries = shard.entries;
+                tp.sparse_entries_cap = shard.entries_cap;
+                tp.sparse_part_total = shard.part_total;
+                tp.sparse_parts = shard.parts;
+                tp.sparse_part_reads = (uint32_t)((n + shard.parts - 1) / shard.parts);
+            }
             const uint64_t front_blocks = front_grid(p, n);
-            if (mode == kFinish) {
+            if (is_finish(mode)) {
                 HIP_TRY(epik_amd::launch_team_headers(tp, p->team_waves, p->counts, stream));
             } else {
                 HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
-                HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, dim3((unsigned)front_blocks), stream));
+                HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, mode == kAccumulateLists,
+                                                    dim3((unsigned)front_blocks), stream));
+                if (mode == kAccumulateLists) HIP_TRY(epik_amd::launch_team_sparse_scan(tp, p->team_waves, stream));
             }
             const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
             uint64_t stream_blocks = n * parts;
             const uint64_t stream_resident = p->max_blocks_cap ? std::min<uint64_t>(g.stream_blocks, (uint64_t)p->max_blocks_cap * parts) : g.stream_blocks;
-            if (stream_blocks > stream_resident && mode != kPlace) stream_blocks = stream_resident;  // (bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s against 15.1 spread)
+            // (the dense halves are bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s on the
+            // resident grid against 15.1 spread)
+            if (stream_blocks > stream_resident && (mode == kAccumulate || mode == kFinish)) stream_blocks = stream_resident;
             if (stream_blocks > stream_resident) {  // as for `blocks` above (N = 9 999: resident x 1 / 4 / 16 / 32 / 64 = 20.2 / 19.9 / 19.4 / 19.4 / 19.6 ms)
                 stream_blocks = spread_grid(n, stream_resident / parts, kMinReadsPerStreamBlock) * parts;
 #ifdef EPIK_AMD_ABLATION
@@ -843,12 +897,12 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             p->last_blocks = (uint32_t)stream_blocks;
             p->last_streamed = true;
             HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)stream_blocks),
-                                                 g.stream_lds_bytes, stream));
-            if (mode != kAccumulate) {
+                                                 g.stream_lds_bytes, stream, shard.sources));
+            if (!is_accumulate(mode)) {
                 const uint64_t merge_blocks = std::min<uint64_t>((n + 3u) / 4u, (uint64_t)p->merge_blocks);
                 HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)merge_blocks), stream));
             }
-            if (mode != kFinish) {
+            if (!is_finish(mode)) {
                 tp.read_list = p->d_slow_list;
                 tp.read_list_count = p->d_front_cursor + 1;
                 HIP_TRY(epik_amd::launch_team(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)blocks),
@@ -915,6 +969,82 @@ int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets,
                   static_cast<hipStream_t>(stream), shard);
 }
 
+int epik_amd_placer_partial_info(const epik_amd_placer *p, epik_amd_partial_info *out)
+{
+    if (!p || !out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *out = epik_amd_partial_info{};
+    out->num_branches = p->params.num_branches;
+    out->lists = p->team && p->team_front ? 1u : 0u;
+    out->slices = p->team ? (uint32_t)p->team_waves * p->team_passes : 1u;
+    out->slice_rows = p->team ? p->team_slice_rows : p->params.num_branches;
+    out->entry_bytes = epik_amd::sparse_entry_bytes(p->counts);
+    out->postings_per_kmer = (double)p->plan.kept_entries / (double)std::max<uint64_t>(p->num_keys, 1);
+    return EPIK_AMD_OK;
+}
+
+int epik_amd_placer_accumulate_lists_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
+                                            uint64_t n, uint32_t n_parts, void *d_entries, uint64_t entries_cap,
+                                            void *d_index, void *d_part_entries, const void *d_amb_slot,
+                                            void *d_amb_order, void *d_amb_avg, void *stream)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (n_parts == 0 || n_parts > EPIK_AMD_MAX_SHARDS) return fail(EPIK_AMD_ERR_INVALID, "n_parts must be in [1, EPIK_AMD_MAX_SHARDS]");
+    if (!d_part_entries) return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_part_entries, 0, n_parts * sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+        return EPIK_AMD_OK;
+    }
+    if (!d_seqs || !d_seq_offsets || !d_index || (!d_entries && entries_cap)) return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    if (entries_cap >= (1ull << 32)) return fail(EPIK_AMD_ERR_INVALID, "entries_cap must be below 2^32 (offsets inside a part are 32-bit)");
+    if (d_amb_slot && (!d_amb_order || !d_amb_avg))
+        return fail(EPIK_AMD_ERR_INVALID, "d_amb_slot without d_amb_order / d_amb_avg");
+    shard_buffers shard;
+    shard.entries = static_cast<uint8_t *>(d_entries);
+    shard.entries_cap = entries_cap;
+    shard.index = static_cast<uint2 *>(d_index);
+    shard.part_total = static_cast<unsigned long long *>(d_part_entries);
+    shard.parts = n_parts;
+    shard.amb_slot = static_cast<const int32_t *>(d_amb_slot);
+    shard.amb_order = static_cast<uint32_t *>(d_amb_order);
+    shard.amb_avg = static_cast<float *>(d_amb_avg);
+    return launch(p, kAccumulateLists, d_seqs, d_seq_offsets, n, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream),
+                  shard);
+}
+
+int epik_amd_placer_finish_lists_device(epik_amd_placer *p, const void *d_seq_offsets, uint64_t n, uint32_t n_shards,
+                                        const void *const *d_entries, const void *const *d_index,
+                                        const void *d_amb_slot, const void *d_amb_avg, void *d_rows, void *d_n_rows,
+                                        void *d_kmer_counts, void *stream)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    if (n == 0) return EPIK_AMD_OK;
+    if (n_shards == 0 || n_shards > EPIK_AMD_MAX_SHARDS) return fail(EPIK_AMD_ERR_INVALID, "n_shards must be in [1, EPIK_AMD_MAX_SHARDS]");
+    if (!d_seq_offsets || !d_entries || !d_index || !d_rows || !d_n_rows) return fail(EPIK_AMD_ERR_INVALID, "null device buffer");
+    if (d_amb_slot && !d_amb_avg) return fail(EPIK_AMD_ERR_INVALID, "d_amb_slot without d_amb_avg");
+    epik_amd::SparseSources src{};
+    src.n_shards = n_shards;
+    for (uint32_t g = 0; g < n_shards; ++g) {
+        if (!d_index[g]) return fail(EPIK_AMD_ERR_INVALID, "null index of a shard");
+        src.entries[g] = static_cast<const uint8_t *>(d_entries[g]);  // (may be null when the shard sent no entry)
+        src.index[g] = static_cast<const uint2 *>(d_index[g]);
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    shard_buffers shard;
+    shard.sources = &src;
+    shard.amb_slot = static_cast<const int32_t *>(d_amb_slot);
+    shard.amb_avg = const_cast<float *>(static_cast<const float *>(d_amb_avg));
+    return launch(p, kFinishLists, nullptr, d_seq_offsets, n, d_rows, d_n_rows, d_kmer_counts,
+                  static_cast<hipStream_t>(stream), shard);
+}
+
+int epik_amd_placer_last_path(const epik_amd_placer *p, uint32_t *path)
+{
+    if (!p || !path) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *path = !p->team ? EPIK_AMD_PATH_WAVE : p->last_streamed ? EPIK_AMD_PATH_TEAM_STREAMED : EPIK_AMD_PATH_TEAM_ONE_KERNEL;
+    return EPIK_AMD_OK;
+}
+
 int epik_amd_placer_place_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
                                  uint64_t n, void *d_rows, void *d_n_rows, void *d_kmer_counts,
                                  void *stream)
@@ -973,7 +1103,18 @@ static int place_impl(epik_amd_placer *p, const char *seqs, const uint64_t *seq_
     // The narrowest counts that hold the longest read's k-mers: 16 bits normally, 32 for a read of
     // 32768 k-mers or more, 8 (reads of up to 255 k-mers) when that puts more waves on a CU.
     const int saved_counts = p->counts;
-    if (!p->counts_forced) p->counts = counts_for(p, longest);
+    {
+        // (a width forced by the caller or the environment is kept unless it cannot hold the longest read's
+        // k-mers: a read must never come back as EPIK_AMD_ROWS_COUNTS_TOO_NARROW from THIS entry point, whose
+        // consumers take n_rows as a row count)
+        const int wanted = counts_for(p, longest);
+        const uint64_t kmers = longest >= p->params.kmer_size ? longest - p->params.kmer_size + 1 : 0;
+        if (!p->counts_forced) {
+            p->counts = wanted;
+        } else if (kmers > max_kmers_of_counts(p->counts)) {
+            p->counts = kmers > max_kmers_of_counts(epik_amd::kCounts16) ? epik_amd::kCounts32 : epik_amd::kCounts16;
+        }
+    }
     struct restore_counts {
         epik_amd_placer *p;
         int v;
@@ -1157,8 +1298,8 @@ int epik_amd_placer_set_wide_counts(epik_amd_placer *p, int enabled)
 int epik_amd_placer_choose_counts(epik_amd_placer *p, uint64_t longest_read)
 {
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    // (for the device-pointer entry points only: epik_amd_placer_place() keeps choosing from its batch)
     p->counts = counts_for(p, longest_read);
-    p->counts_forced = true;
     p->longest_read_hint = longest_read;
     return EPIK_AMD_OK;
 }

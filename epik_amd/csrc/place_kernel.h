@@ -47,6 +47,8 @@ struct PlaceParams {
     double keep_factor;
     float threshold;
     float log_threshold;
+    uint32_t max_kmers_cap;          // != 0: a read with more k-mers than this is not placed whatever the LDS counts hold
+                                     // (the uint16 counts of the dense partial vectors: 65535)
     uint32_t n_pad;                  // LDS rows per wave: num_branches + the dummy row, rounded up to 64
     uint32_t lds_wave_bytes;         // LDS bytes per wave (scores + counts + chunk descriptors)
     uint32_t ablate;                 // timing experiments only (-DEPIK_AMD_ABLATION builds)
@@ -92,6 +94,30 @@ struct TeamParams {
     // {ord(score), branch, k-mer count, -} (empty slots 0) and [n_reads][S] partial sums (TeamPartial)
     void *slice_rows_out;
     void *slice_sums_out;
+    // The partial LISTS of a k-mer-space shard (include/epik_amd.h, "sparse partials"): instead of a dense
+    // [num_branches] vector per read, the rows a read touched in each slice, compacted.  The front kernel leaves
+    // sparse_cap[read][S] = how many entries the list of (read, slice) may take (the postings of the slice's
+    // sublists, at most the slice's rows); team_sparse_scan_kernel turns them into sparse_index[read][S].x =
+    // first entry of the list inside the read's PART (parts = the n_parts equal runs of sparse_part_reads reads
+    // that go to one finisher each) and sparse_part_total[part]; the streaming kernel (the other kernel for the
+    // reads left to it) writes the entries and sparse_index[..].y = how many.
+    uint32_t *sparse_cap;
+    uint2 *sparse_index;
+    uint8_t *sparse_entries;
+    uint64_t sparse_entries_cap;          // entries
+    unsigned long long *sparse_part_total;  // [n_parts]
+    uint32_t sparse_parts, sparse_part_reads;
+};
+// An entry of a partial list: {f32 sum, u32 row | count << 16} with 8- and 16-bit counts, {f32 sum, u32 row,
+// u32 count, 0} with 32-bit counts (reads of 32768 k-mers or more); row = branch - first branch of the slice.
+constexpr uint32_t sparse_entry_bytes(int counts) { return counts == kCounts32 ? 16u : 8u; }
+constexpr uint32_t kSparseOverflow = 0xffffffffu;  // sparse_index[..].y of a list that did not fit sparse_entries
+constexpr int kMaxShards = 16;                     // EPIK_AMD_MAX_SHARDS
+// what finish reads: the lists of its reads as every shard sent them (entries = start of the part's segment)
+struct SparseSources {
+    const uint8_t *entries[kMaxShards];
+    const uint2 *index[kMaxShards];
+    uint32_t n_shards;
 };
 // header flags
 constexpr uint32_t kFrontAmbiguous = 1u;  // the read has an ambiguous k-mer (place.cpp:306-313)
@@ -105,16 +131,18 @@ constexpr uint32_t front_hdr_stride(uint32_t slices) { return ((kFrontHdrWords +
 // a wave of the front kernel takes the pool this many descriptors at a time (one atomic add each) and hands
 // them to its reads itself; a read that needs more takes exactly what it needs
 constexpr uint32_t kFrontPoolChunk = 4096;
-enum : int { kTeamModePlace = 0, kTeamModeAccumulate = 1, kTeamModeFinish = 2 };
+enum : int { kTeamModePlace = 0, kTeamModeAccumulate = 1, kTeamModeFinish = 2, kTeamModeAccumulateLists = 3,
+             kTeamModeFinishLists = 4 };
 hipError_t launch_team(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
                        hipStream_t stream);
 hipError_t set_team_lds_limit(int waves, int counts, size_t lds_bytes);
 hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
 // team_stream.hip: the front kernel (any grid of 256-thread workgroups, one read per wave) and the
 // streaming kernel (one workgroup per read, grid = resident workgroups, LDS as the team kernel's)
-hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream);
+hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, bool lists, dim3 grid, hipStream_t stream);
 hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
-                              hipStream_t stream);
+                              hipStream_t stream, const SparseSources *sources = nullptr);
+hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, hipStream_t stream);
 hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipStream_t stream);
 hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream);
 constexpr size_t kTeamPartialBytes = 24;  // sizeof(TeamPartial) (place_device.hpp)

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
         // place.cpp:322 underflows for len < k; we report "no placement" -- also for a read whose
         // k-mers could overflow this kernel's count type (the host then uses the wide kernel)
         // (n_rows = kCountsTooNarrow tells the caller, who chose the count width, which case it was)
-        if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers) {
+        if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers || (p.max_kmers_cap && len - k + 1 > p.max_kmers_cap)) {
             if (p.partial_scores) {  // accumulate-only launch: an all-zero partial vector
                 for (uint32_t i = lane; i < p.num_branches; i += kWave) {
                     p.partial_scores[read * p.num_branches + i] = 0.0f;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 5) void finish_reads_kernel(PlaceParams p)
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
     for (uint64_t read = wave_global; read < p.n_reads; read += total_waves) {
         const uint64_t len = p.seq_offsets[read + 1] - p.seq_offsets[read];
-        if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers) {
+        if (len < k || len - k + 1 > WaveLds<CountT>::kMaxKmers || (p.max_kmers_cap && len - k + 1 > p.max_kmers_cap)) {
             if (lane == 0) p.n_rows[read] = len < k ? 0u : kCountsTooNarrow;
             continue;
         }

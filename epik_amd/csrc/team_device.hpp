@@ -336,6 +336,178 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand
 }
 
 
+
+// ---------------------------------------------------------------------------------
+// Partial LISTS of a k-mer-space shard (include/epik_amd.h): what accumulate leaves per (read, slice) instead of
+// a dense vector -- the rows that received a k-mer, as {f32 sum, u32 row | count << 16} (32-bit counts:
+// {f32 sum, u32 row, u32 count, 0}), row = branch - first branch of the slice, in any order (a row is there once).
+// ---------------------------------------------------------------------------------
+template <typename CountT>
+struct PartialEntry {
+    static constexpr bool kWide = sizeof(CountT) == 4;
+    static constexpr uint32_t kBytes = kWide ? 16u : 8u;
+    typedef std::conditional_t<kWide, v4u, v2u> raw_t;
+    __device__ static __forceinline__ raw_t make(uint32_t score_bits, uint32_t row, uint32_t count)
+    {
+        if constexpr (kWide)
+            return v4u{score_bits, row, count, 0u};
+        else
+            return v2u{score_bits, row | (count << 16)};
+    }
+    __device__ static __forceinline__ uint32_t row(const raw_t &e)
+    {
+        if constexpr (kWide)
+            return e.y;
+        else
+            return e.y & 0xffffu;
+    }
+    __device__ static __forceinline__ uint32_t count(const raw_t &e)
+    {
+        if constexpr (kWide)
+            return e.z;
+        else
+            return e.y >> 16;
+    }
+};
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The rows of the wave's slice that received a k-mer go to `out` (room for `cap` entries; never more are
+// written), and every row is reset for the wave's next read (place.cpp:335-342).  Returns how many rows had
+// received one (wave-uniform); the caller makes sure cap covers them (the front kernel's bound: the postings
+// of the slice's sublists, at most the slice's rows).  Four consecutive rows per lane and trip.
+template <typename CountT>
+__device__ __forceinline__ uint32_t emit_partial_list(WaveLds<CountT> lds, uint32_t rows_pad, uint32_t rows,
+                                                      uint8_t *__restrict__ out, uint32_t cap)
+{
+    typedef WaveLds<CountT> Lds_t;
+    typedef PartialEntry<CountT> Entry;
+    typedef __attribute__((address_space(3))) v4u u32x4_t;
+    const uint32_t lane = (uint32_t)lane_id();
+    auto *dst = reinterpret_cast<typename Entry::raw_t *>(out);
+    uint32_t n = 0;
+    for (uint32_t base = 0; base < rows_pad; base += 4u * (uint32_t)kWave) {
+        const uint32_t i0 = base + 4u * lane;
+        const bool mine = i0 < rows_pad;  // rows_pad is a multiple of 16: the lane's four rows are inside or outside together
+        float raw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t words[Lds_t::kCountWords];
+#pragma unroll
+        for (int q = 0; q < Lds_t::kCountWords; ++q) words[q] = 0u;
+        if (mine) lds.load4_packed(i0, raw, words);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t c;
+            if constexpr (sizeof(CountT) == 1)
+                c = (words[0] >> (8 * u)) & 0xffu;
+            else if constexpr (sizeof(CountT) == 2)
+                c = (words[u >> 1] >> (16 * (u & 1))) & (0xffffu & ~Lds_t::kSeen);
+            else
+                c = words[u] & ~Lds_t::kSeen;
+            const bool hit = c != 0u && i0 + (uint32_t)u < rows;  // (the dummy row and the padding lie behind `rows`)
+            const uint64_t m = __ballot(hit);
+            if (m) {
+                const uint32_t slot = n + lanes_below(m);
+                if (hit && slot < cap) dst[slot] = Entry::make(__float_as_uint(raw[u]), i0 + (uint32_t)u, c);
+                n += (uint32_t)__popcll(m);
+            }
+        }
+        if (mine) {
+            *reinterpret_cast<u32x4_t *>(lds.score + i0) = v4u{0u, 0u, 0u, 0u};
+            if constexpr (sizeof(CountT) == 1) {
+                *reinterpret_cast<typename Lds_t::u32_t *>(lds.count + i0) = 0u;
+            } else {
+                typename Lds_t::vcw zero;
+#pragma unroll
+                for (int q = 0; q < Lds_t::kCountWords; ++q) zero[q] = 0u;
+                *reinterpret_cast<typename Lds_t::count_words_t *>(lds.count + i0) = zero;
+            }
+        }
+    }
+    return n;
+}
+
+// The other direction (finish): the lists every shard sent for this (read, slice), in shard order, added into
+// the wave's rows -- the same float32 order as a dense sum over the shards in rank order, 0 + x being x
+// (place.cpp:349-371 split over the shards' lists).  `item` = read * slices + slice, the read numbered inside
+// the finisher's batch.  A trip is up to four chunks of 64 entries of ONE list: its rows are distinct, so the
+// four LDS read-add-writes go out together (one round trip per trip, not per chunk); lists of different shards
+// may name the same row and stay in order.  The next trip's entries are asked for before this one's are added.
+template <typename CountT>
+__device__ __forceinline__ void merge_partial_lists(const SparseSources &src, WaveLds<CountT> lds, uint64_t item,
+                                                    uint32_t rows_pad)
+{
+    typedef PartialEntry<CountT> Entry;
+    typedef typename Entry::raw_t raw_t;
+    constexpr int kTrip = 4;  // chunks of 64 entries
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t n_shards = src.n_shards;
+    // lane g: where shard g's list lies and how long it is
+    uint32_t my_first = 0, my_count = 0;
+    if (lane < n_shards) {
+        const uint2 ix = src.index[lane][item];
+        my_first = ix.x;
+        my_count = ix.y == kSparseOverflow ? 0u : ix.y;  // (the caller has checked: see epik_amd.h)
+    }
+    struct Trip {
+        raw_t e[kTrip];
+    };
+    const uint32_t dummy = rows_pad - 1u;
+    // the walk over (shard, first entry of the trip), scalar
+    uint32_t g = 0, at = 0, cnt = 0;
+    const uint8_t *base = nullptr;
+    auto settle = [&]() {  // on the next trip that exists; false at the end
+        while (g < n_shards) {
+            cnt = (uint32_t)__builtin_amdgcn_readlane(my_count, (int)g);
+            if (at < cnt) {
+                base = src.entries[g] + (uint64_t)(uint32_t)__builtin_amdgcn_readlane(my_first, (int)g) * Entry::kBytes;
+                return true;
+            }
+            ++g, at = 0;
+        }
+        return false;
+    };
+    auto load_trip = [&]() {
+        Trip t;
+        const raw_t *list = reinterpret_cast<const raw_t *>(base);
+#pragma unroll
+        for (int c = 0; c < kTrip; ++c) {
+            t.e[c] = Entry::make(0u, dummy, 0u);  // lanes behind the list's end: +0 on the dummy row
+            const uint32_t i = at + (uint32_t)c * (uint32_t)kWave + lane;
+            if (i < cnt) t.e[c] = list[i];
+        }
+        at += (uint32_t)kTrip * (uint32_t)kWave;
+        return t;
+    };
+    auto add_trip = [&](const Trip &t) {
+        float old_s[kTrip];
+        uint32_t old_c[kTrip], row[kTrip];
+#pragma unroll
+        for (int c = 0; c < kTrip; ++c) {
+            row[c] = Entry::row(t.e[c]);
+            old_s[c] = lds.score[row[c]];
+            old_c[c] = (uint32_t)lds.count[row[c]];
+        }
+#pragma unroll
+        for (int c = 0; c < kTrip; ++c) {
+            lds.score[row[c]] = __fadd_rn(old_s[c], __uint_as_float(t.e[c].x));
+            lds.count[row[c]] = (CountT)(old_c[c] + Entry::count(t.e[c]));
+        }
+    };
+    if (!settle()) return;
+    Trip cur = load_trip();
+    for (;;) {
+        const bool more = settle();
+        Trip next;
+        if (more) next = load_trip();
+        add_trip(cur);
+        if (!more) break;
+        cur = next;
+    }
+}
+
 }  // namespace
 }  // namespace epik_amd
 #endif

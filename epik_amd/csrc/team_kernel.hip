@@ -35,7 +35,8 @@
 
 namespace epik_amd {
 
-enum : int { kTeamPlace = kTeamModePlace, kTeamAccumulate = kTeamModeAccumulate, kTeamFinish = kTeamModeFinish };
+enum : int { kTeamPlace = kTeamModePlace, kTeamAccumulate = kTeamModeAccumulate, kTeamFinish = kTeamModeFinish,
+             kTeamAccumulateLists = kTeamModeAccumulateLists };  // (lists: the reads the front kernel left to this kernel)
 
 template <int W, typename CountT, int kMode>
 __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(TeamParams tp)
@@ -69,6 +70,14 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                                                               (rows_pad - 1u) * (uint32_t)sizeof(CountT));
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // = &tp.base
     for (uint32_t i = lane; i < rows_pad; i += kWave) lds.store(i, 0u, 0u);
+    uint64_t part_first = 0;  // partial lists out: where every part's entries begin (lane r: part r), as in team_stream_kernel
+    if constexpr (kMode == kTeamAccumulateLists) {
+        const uint64_t mine = (uint32_t)lane < tp.sparse_parts ? (uint64_t)tp.sparse_part_total[lane] : 0ull;
+        for (uint32_t r = 0; r < tp.sparse_parts; ++r) {
+            const uint64_t t = readlane_u64(mine, (int)r);
+            if ((uint32_t)lane > r) part_first += t;
+        }
+    }
     // (no list entry is ever read before it was written; should that ever break, an entry is at least a chunk
     // of zero bytes at a valid address and not what the LDS happened to hold)
     for (uint32_t i = lane; i < tp.desc_bytes / 8u; i += kWave) lds.desc[i] = null_chunk(p);
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
         next_read = tp.read_list ? tp.read_list[blockIdx.x] : (uint64_t)blockIdx.x;
         bounds[0] = p.seq_offsets[next_read], bounds[1] = p.seq_offsets[next_read + 1];
     }
+    uint32_t placed_here = 0;  // reads this workgroup has really placed (the skipped ones below meet at no barrier)
     for (uint64_t at = blockIdx.x; at < n_todo; at += gridDim.x) {
         const uint64_t read = readlane_u64(next_read, 0);
         const uint64_t seq_begin = readlane_u64(bounds[0], 0);
@@ -115,8 +125,10 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
         // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than
         // this launch's counts hold is marked (the caller chose the count width).  Uniform over the
         // workgroup: nobody is left waiting at a barrier.
-        if (len < k || len - k + 1 > Lds::kMaxKmers) {
-            if (kMode == kTeamAccumulate) {  // an all-zero partial vector
+        if (len < k || len - k + 1 > Lds::kMaxKmers || (p.max_kmers_cap && len - k + 1 > p.max_kmers_cap)) {
+            if (kMode == kTeamAccumulateLists) {
+                // (its lists are empty: the front kernel made no room, the scan kernel wrote "0 entries")
+            } else if (kMode == kTeamAccumulate) {  // an all-zero partial vector
                 for (uint32_t i = threadIdx.x; i < p.num_branches; i += W * kWave) {
                     p.partial_scores[read * p.num_branches + i] = 0.0f;
                     p.partial_counts[read * p.num_branches + i] = 0u;
@@ -127,9 +139,11 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
             continue;
         }
         const uint64_t n_kmers = len - k + 1;  // :322
-        // which of the two flags this read uses: the workgroup's reads alternate (NOT read & 1: with an even
-        // grid every read of a workgroup has the same parity, and the clear below would race with the next read)
-        const uint32_t parity = (uint32_t)((at - blockIdx.x) / gridDim.x) & 1u;
+        // which of the two flags this read uses: the reads the workgroup PLACES alternate (NOT read & 1: with an
+        // even grid every read of a workgroup has the same parity; and not the iteration index either: a read
+        // skipped above executes no barrier, so the reads before and after it would share a flag and wave 0's
+        // clear of the first could land on the second's set)
+        const uint32_t parity = placed_here++ & 1u;
         bool any_amb = false;  // the same in every wave of the workgroup
 
         for (uint32_t pass = 0; pass < tp.passes; ++pass) {
@@ -304,11 +318,23 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                 }
                 // ---- ambiguous k-mers (place.cpp:306-313, 373-415), after all exact ones ----------
                 if (any_amb) {
-                    const int64_t amb_slot = (kMode == kTeamAccumulate && p.amb_slot) ? (int64_t)p.amb_slot[read] : -1;
+                    const int64_t amb_slot = ((kMode == kTeamAccumulate || kMode == kTeamAccumulateLists) && p.amb_slot) ? (int64_t)p.amb_slot[read] : -1;
                     place_ambiguous<TeamChunks, CountT>(kp, lds, seq, len, n_kmers, amb_slot, ctx);
                 }
             }
-            if (kMode == kTeamAccumulate) {
+            if constexpr (kMode == kTeamAccumulateLists) {
+                // k-mer-space shard, partial lists: the rows that received a k-mer, where the scan kernel made room
+                const uint64_t slice_at = read * n_slices + pass * W + wave;
+                const uint2 ix = tp.sparse_index[slice_at];
+                const uint32_t room = tp.sparse_cap[slice_at];
+                const uint32_t part = (uint32_t)(read / tp.sparse_part_reads);
+                const uint64_t first = readlane_u64(part_first, (int)part) + ix.x;
+                const bool fits = first + room <= tp.sparse_entries_cap;
+                const uint32_t n_out = emit_partial_list<CountT>(lds, rows_pad, ctx.rows_,
+                                                                 tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
+                                                                 fits ? room : 0u);
+                if (lane == 0) tp.sparse_index[slice_at].y = fits ? n_out : kSparseOverflow;
+            } else if (kMode == kTeamAccumulate) {
                 // k-mer-space shard: the slice's raw sums and counts leave for HBM (see place_kernel.hip)
                 for (uint32_t i = lane; i < rows_pad; i += kWave) {
                     const uint2 cv = lds.load(i);
@@ -328,10 +354,10 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
             // top-k candidates), and the tile waves of the next pass / read write into every list as soon as
             // THEY have met: nobody may start that before everybody is through here.  Placing, the barrier
             // in front of the merge below does it after the last pass.
-            if (kMode == kTeamAccumulate || pass + 1 < tp.passes) __syncthreads();
+            if (kMode == kTeamAccumulate || kMode == kTeamAccumulateLists || pass + 1 < tp.passes) __syncthreads();
         }
         TEAM_STAMP(6)  // slice epilogue
-        if (kMode != kTeamAccumulate) {
+        if (kMode != kTeamAccumulate && kMode != kTeamAccumulateLists) {
             __syncthreads();  // every slice's rows and sums are in LDS
             if (wave == W - 1) {
                 MergeParams mp;
@@ -382,7 +408,8 @@ hipError_t team_dispatch(int waves, int counts, int mode, F &&f)
 #define EPIK_TEAM_CASE(W, C, M) \
     if (waves == W && counts == C && mode == M) \
         return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M>();
-#define EPIK_TEAM_MODES(W, C) EPIK_TEAM_CASE(W, C, kTeamPlace) EPIK_TEAM_CASE(W, C, kTeamAccumulate) EPIK_TEAM_CASE(W, C, kTeamFinish)
+#define EPIK_TEAM_MODES(W, C) EPIK_TEAM_CASE(W, C, kTeamPlace) EPIK_TEAM_CASE(W, C, kTeamAccumulate) EPIK_TEAM_CASE(W, C, kTeamFinish) \
+    EPIK_TEAM_CASE(W, C, kTeamAccumulateLists)
 #define EPIK_TEAM_COUNTS(W) EPIK_TEAM_MODES(W, kCounts8) EPIK_TEAM_MODES(W, kCounts16) EPIK_TEAM_MODES(W, kCounts32)
     EPIK_TEAM_COUNTS(4)
     EPIK_TEAM_COUNTS(8)
@@ -406,7 +433,7 @@ hipError_t launch_team(const TeamParams &tp, int waves, int counts, int mode, di
 hipError_t set_team_lds_limit(int waves, int counts, size_t /*lds_bytes*/)  // (always the whole CU: see place_kernel.hip)
 {
     hipError_t err = hipSuccess;
-    for (int mode = 0; mode < 3 && err == hipSuccess; ++mode)
+    for (int mode = 0; mode < 4 && err == hipSuccess; ++mode)
         err = team_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_place_kernel<W, C, M>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);

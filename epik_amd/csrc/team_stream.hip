@@ -47,7 +47,10 @@ namespace epik_amd {
 #ifndef EPIK_AMD_FRONT_OCC
 #define EPIK_AMD_FRONT_OCC 8
 #endif
-template <int W>
+// kLists (the first half of a k-mer-space-sharded placement that leaves partial LISTS): the front end also says
+// how many entries the list of every (read, slice) may take -- the postings of the slice's sublists, at most
+// the slice's rows -- into tp.sparse_cap; team_sparse_scan_kernel lays the lists out from that.
+template <int W, bool kLists>
 __global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
 {
     const PlaceParams &p = tp.base;
@@ -75,6 +78,8 @@ __global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_fron
         if (len < k || len - k + 1 > max_kmers) {  // no placement / counts too narrow: the consumer reports it
             word = lane == 1 ? (len < k ? kFrontNoRows : kFrontTooNarrow) : lane == 2 ? (uint32_t)len : 0u;
             if ((uint32_t)lane < kFrontHdrWords + n_slices) hdr[lane] = word;
+            if constexpr (kLists)
+                if ((uint32_t)lane < n_slices) tp.sparse_cap[read * n_slices + (uint32_t)lane] = 0u;
             continue;
         }
         const uint64_t n_kmers = len - k + 1;  // :322
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_fron
             return exact;
         };
         const bool one_group = tp.passes <= held_passes && n_kmers <= (uint64_t)T * stride;  // wave-uniform
+        uint32_t postings = 0;  // kLists, lane 3 + s: the postings of slice s's sublists
         // ---- chunks per slice -------------------------------------------------------------------------
         if (one_group) {
             uint32_t ch[T], cls[T];
@@ -120,12 +126,18 @@ __global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_fron
                     for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = make_uint4(0u, 0u, 0u, 0u);
                     if (exact[t]) TeamEntry<W>::fetch(tp, pass, tiles[t].key, (uint32_t)t * stride + (uint32_t)lane, raw[t]);
                 }
+                uint32_t plen[W];
+#pragma unroll
+                for (int s = 0; s < W; ++s) plen[s] = 0;
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     TeamEntry<W> e;
                     e.unpack(raw[t]);
 #pragma unroll
-                    for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+                    for (int s = 0; s < W; ++s) {
+                        acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+                        if constexpr (kLists) plen[s] += e.len[s];
+                    }
 #pragma unroll
                     for (int q = 0; q < TeamEntry<W>::kQuads; ++q)
                         held[pass * kHeldPerPass + (t * TeamEntry<W>::kQuads + q) * kWave + lane] = raw[t][q];
@@ -134,26 +146,41 @@ __global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_fron
                 for (int s = 0; s < W; ++s) {
                     const uint32_t total = wave_sum_u32(acc[s]);
                     word = ((uint32_t)lane == kFrontHdrWords + pass * W + (uint32_t)s) ? total : word;
+                    if constexpr (kLists) {
+                        const uint32_t all = wave_sum_u32(plen[s]);
+                        postings = ((uint32_t)lane == kFrontHdrWords + pass * W + (uint32_t)s) ? all : postings;
+                    }
                 }
             }
         } else {
             for (uint32_t pass = 0; pass < tp.passes; ++pass) {
-                uint32_t acc[W];
+                uint32_t acc[W], plen[W];
 #pragma unroll
-                for (int s = 0; s < W; ++s) acc[s] = 0;
+                for (int s = 0; s < W; ++s) acc[s] = plen[s] = 0;
                 for (uint64_t tile_pos = 0; tile_pos < n_kmers; tile_pos += stride) {
                     const Tile tl = encode_tile(seq, len, tile_pos, n_kmers, k, sigma, stride, p.char_class);
                     if (exact_windows(tl)) {
                         TeamEntry<W> e;
                         e.load(tp, pass, tl.key, (uint32_t)tile_pos + (uint32_t)lane);
 #pragma unroll
-                        for (int s = 0; s < W; ++s) acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+                        for (int s = 0; s < W; ++s) {
+                            acc[s] += (e.len[s] + (uint32_t)kWave - 1u) >> 6;
+                            // (saturating: a very long read's sublists may name more postings than 32 bits hold;
+                            // the bound below is the slice's rows then)
+                            if constexpr (kLists) plen[s] = plen[s] + e.len[s] < plen[s] ? 0xffffffffu : plen[s] + e.len[s];
+                        }
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < W; ++s) {
                     const uint32_t total = wave_sum_u32(acc[s]);
                     word = ((uint32_t)lane == kFrontHdrWords + pass * W + (uint32_t)s) ? total : word;
+                    if constexpr (kLists) {
+                        // (lane sums below 2^32 / 64 add up without wrapping; anything larger is "all rows")
+                        const bool huge = __ballot(plen[s] >= (1u << 25)) != 0;
+                        const uint32_t all = huge ? 0xffffffffu : wave_sum_u32(plen[s]);
+                        postings = ((uint32_t)lane == kFrontHdrWords + pass * W + (uint32_t)s) ? all : postings;
+                    }
                 }
             }
         }
@@ -185,6 +212,18 @@ __global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_fron
         if (!fits) {
             flags |= kFrontSlow;
             if (lane == 0) tp.slow_list[atomicAdd(tp.front_cursor + 1, 1ull)] = read;
+        }
+        if constexpr (kLists) {
+            // Room for the list of (read, slice): a posting touches one row, and the slice has only so many.  A
+            // read whose ambiguous k-mers are ADDED by this shard (no slot: one shard only, epik_amd.h) may touch
+            // any row.
+            if (is_count) {
+                const uint32_t slice = (uint32_t)lane - kFrontHdrWords;
+                const uint32_t first = slice * tp.slice_rows;
+                const uint32_t rows = first >= p.num_branches ? 0u : min(tp.slice_rows, p.num_branches - first);
+                const bool adds_amb = any_amb && !(p.amb_slot && p.amb_slot[read] >= 0);
+                tp.sparse_cap[read * n_slices + slice] = adds_amb ? rows : min(postings, rows);
+            }
         }
         word = lane == 0 ? (uint32_t)(off >> 3) : lane == 1 ? flags : lane == 2 ? (uint32_t)len : word;
         if ((uint32_t)lane < kFrontHdrWords + n_slices) hdr[lane] = word;
@@ -300,8 +339,11 @@ __device__ __forceinline__ void slice_epilogue(const TeamParams *__restrict__ kt
 // kMode: kTeamModePlace; kTeamModeAccumulate / kTeamModeFinish = the two halves of a k-mer-space-sharded
 // placement (include/epik_amd.h): stream only, the slice's raw sums and counts to HBM / the totals back from
 // HBM, slice epilogue (the headers then come from team_header_kernel: there is no front end).
+// kTeamModeAccumulateLists / kTeamModeFinishLists: the same halves with partial LISTS in place of the dense
+// vectors -- the rows a slice really touched, compacted (emit_partial_list), and the shards' lists of a slice
+// added back in shard order (merge_partial_lists; `src` says where they lie).
 template <int W, typename CountT, int kMode>
-__global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp)
+__global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp, SparseSources src)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef WaveLds<CountT> Lds;
@@ -325,6 +367,15 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                                                               (rows_pad - 1u) * (uint32_t)sizeof(CountT));
     const PlaceParams *kp = (const PlaceParams *)__builtin_amdgcn_kernarg_segment_ptr();  // = &tp.base
     for (uint32_t i = lane; i < rows_pad; i += kWave) lds.store(i, 0u, 0u);
+    // partial lists out: where every part's entries begin (lane r: part r), from the scan kernel's totals
+    uint64_t part_first = 0;
+    if constexpr (kMode == kTeamModeAccumulateLists) {
+        uint64_t mine = (uint32_t)lane < tp.sparse_parts ? (uint64_t)tp.sparse_part_total[lane] : 0ull;
+        for (uint32_t r = 0; r < tp.sparse_parts; ++r) {  // (a handful of parts: a serial sum of uniform values)
+            const uint64_t t = readlane_u64(mine, (int)r);
+            if ((uint32_t)lane > r) part_first += t;
+        }
+    }
 
     const uint32_t k = p.kmer_size;
     const uint32_t keep = p.keep_at_most;
@@ -368,7 +419,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     auto first_round = [&](uint32_t word) {
         const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
         uint64_t d = null_desc;
-        if (kMode != kTeamModeFinish && !(flags & (kFrontSlow | kFrontNoRows | kFrontTooNarrow))) {
+        if (kMode != kTeamModeFinish && kMode != kTeamModeFinishLists && !(flags & (kFrontSlow | kFrontNoRows | kFrontTooNarrow))) {
             uint32_t my_padded;
             const uint64_t *list = slice_list(word, (int)(kFrontHdrWords + wave), my_padded);
             const uint32_t n_first = my_padded < cap ? my_padded : cap;
@@ -440,6 +491,19 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                     }
                     lds.store(i, __float_as_uint(sc), c);
                 }
+            } else if constexpr (kMode == kTeamModeFinishLists) {
+                // ... the same from the shards' partial lists, in shard order; then the ambiguous record
+                merge_partial_lists<CountT>(src, lds, slice_at, rows_pad);
+                const int64_t slot = p.amb_slot ? (int64_t)p.amb_slot[read] : -1;
+                if (slot >= 0) {
+                    for (uint32_t i = lane; i < ctx.rows_; i += kWave) {
+                        const float avg = p.amb_avg[(uint64_t)slot * p.num_branches + ctx.base_ + i];
+                        if (avg > 0.0f) {
+                            const uint2 cv = lds.load(i);
+                            lds.store(i, __float_as_uint(__fadd_rn(__uint_as_float(cv.x), avg)), cv.y + 1u);
+                        }
+                    }
+                }
             } else {
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
             uint32_t my_padded;
@@ -472,6 +536,19 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 }
                 continue;
             }
+            if constexpr (kMode == kTeamModeAccumulateLists) {
+                // ... as a list of the rows that received a k-mer, where the scan kernel made room for it
+                const uint2 ix = tp.sparse_index[slice_at];
+                const uint32_t room = tp.sparse_cap[slice_at];
+                const uint32_t part = (uint32_t)(read / tp.sparse_part_reads);
+                const uint64_t first = readlane_u64(part_first, (int)part) + ix.x;
+                const bool fits = first + room <= tp.sparse_entries_cap;
+                const uint32_t n_out = emit_partial_list<CountT>(lds, rows_pad, ctx.rows_,
+                                                                 tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
+                                                                 fits ? room : 0u);
+                if (lane == 0) tp.sparse_index[slice_at].y = fits ? n_out : kSparseOverflow;
+                continue;
+            }
             // ---- correction, the slice's best rows and share of sum_scores (to HBM: team_merge_kernel),
             //      reset of the rows
             if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
@@ -497,6 +574,46 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             STREAM_STAMP(3)  // slice epilogue
         }
     }
+}
+
+// Partial lists: room for every (read, slice) list of a part, one after the other in read order, from the front
+// kernel's bounds.  One workgroup per part (a part = the reads of one finisher); 4 096 items per trip.
+__global__ __launch_bounds__(1024) void team_sparse_scan_kernel(TeamParams tp, uint32_t n_slices)
+{
+    __shared__ unsigned long long wave_total[16];
+    __shared__ unsigned long long carry_s;
+    const PlaceParams &p = tp.base;
+    const uint32_t lane = (uint32_t)lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t r0 = (uint64_t)blockIdx.x * tp.sparse_part_reads;
+    const uint64_t r1 = r0 + tp.sparse_part_reads < p.n_reads ? r0 + tp.sparse_part_reads : p.n_reads;
+    const uint64_t items = r1 > r0 ? (r1 - r0) * n_slices : 0;
+    const uint32_t *__restrict__ room = tp.sparse_cap + r0 * n_slices;
+    uint2 *__restrict__ index = tp.sparse_index + r0 * n_slices;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t t0 = 0; t0 < items; t0 += 4096u) {
+        const uint64_t i0 = t0 + 4ull * threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + (uint64_t)u < items ? room[i0 + (uint64_t)u] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];  // (a list has at most the slice's rows: no wrap)
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_total[w];
+        unsigned long long at = before + (incl - mine);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // (offsets inside a part are 32-bit: the host keeps a part's entries below 2^32, see capi.hip)
+            if (i0 + (uint64_t)u < items) index[i0 + (uint64_t)u] = make_uint2((uint32_t)at, 0u);
+            at += v[u];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = at;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tp.sparse_part_total[blockIdx.x] = carry_s;
 }
 
 // The headers of a batch whose descriptors nobody needs (finish): length and the two "no placement" flags.
@@ -589,7 +706,8 @@ hipError_t stream_dispatch(int waves, int counts, int mode, F &&f)
 #define EPIK_STREAM_CASE(W, C, M) \
     if (waves == W && counts == C && mode == M) \
         return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M>();
-#define EPIK_STREAM_MODES(W, C) EPIK_STREAM_CASE(W, C, kTeamModePlace) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate) EPIK_STREAM_CASE(W, C, kTeamModeFinish)
+#define EPIK_STREAM_MODES(W, C) EPIK_STREAM_CASE(W, C, kTeamModePlace) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate) EPIK_STREAM_CASE(W, C, kTeamModeFinish) \
+    EPIK_STREAM_CASE(W, C, kTeamModeAccumulateLists) EPIK_STREAM_CASE(W, C, kTeamModeFinishLists)
     EPIK_STREAM_MODES(4, kCounts8) EPIK_STREAM_MODES(4, kCounts16) EPIK_STREAM_MODES(4, kCounts32)
     EPIK_STREAM_MODES(8, kCounts8) EPIK_STREAM_MODES(8, kCounts16) EPIK_STREAM_MODES(8, kCounts32)
 #undef EPIK_STREAM_MODES
@@ -617,32 +735,47 @@ uint32_t front_held_passes(int waves, uint32_t passes, size_t *lds)
 }
 }  // namespace
 
-hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, dim3 grid, hipStream_t stream)
+hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, bool lists, dim3 grid, hipStream_t stream)
 {
     // reads with more k-mers than the consumer's counts hold get no descriptors (it marks them)
     size_t lds = 0;
     const uint32_t held_passes = front_held_passes(waves, tp.passes, &lds);
-    if (waves == 4)
-        hipLaunchKernelGGL((team_front_kernel<4>), grid, dim3(64), lds, stream, tp, max_kmers_of(counts), held_passes);
+    uint64_t max_kmers = max_kmers_of(counts);
+    if (tp.base.max_kmers_cap) max_kmers = std::min<uint64_t>(max_kmers, tp.base.max_kmers_cap);
+    if (waves == 4 && !lists)
+        hipLaunchKernelGGL((team_front_kernel<4, false>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
+    else if (waves == 4)
+        hipLaunchKernelGGL((team_front_kernel<4, true>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
+    else if (waves == 8 && !lists)
+        hipLaunchKernelGGL((team_front_kernel<8, false>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
     else if (waves == 8)
-        hipLaunchKernelGGL((team_front_kernel<8>), grid, dim3(64), lds, stream, tp, max_kmers_of(counts), held_passes);
+        hipLaunchKernelGGL((team_front_kernel<8, true>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, hipStream_t stream)
+{
+    hipLaunchKernelGGL(team_sparse_scan_kernel, dim3(tp.sparse_parts), dim3(1024), 0, stream, tp, (uint32_t)waves * tp.passes);
     return hipGetLastError();
 }
 
 hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipStream_t stream)
 {
     const dim3 grid((unsigned)((tp.base.n_reads + 255) / 256));
-    hipLaunchKernelGGL(team_header_kernel, grid, dim3(256), 0, stream, tp, (uint32_t)waves * tp.passes, max_kmers_of(counts));
+    uint64_t max_kmers = max_kmers_of(counts);
+    if (tp.base.max_kmers_cap) max_kmers = std::min<uint64_t>(max_kmers, tp.base.max_kmers_cap);
+    hipLaunchKernelGGL(team_header_kernel, grid, dim3(256), 0, stream, tp, (uint32_t)waves * tp.passes, max_kmers);
     return hipGetLastError();
 }
 
 hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
-                              hipStream_t stream)
+                              hipStream_t stream, const SparseSources *sources)
 {
+    const SparseSources src = sources ? *sources : SparseSources{};
     return stream_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
-        hipLaunchKernelGGL((team_stream_kernel<W, C, M>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp);
+        hipLaunchKernelGGL((team_stream_kernel<W, C, M>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp, src);
         return hipGetLastError();
     });
 }
@@ -656,7 +789,7 @@ hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStre
 hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whole CU: see place_kernel.hip)
 {
     hipError_t err = hipSuccess;
-    for (int mode = 0; mode < 3 && err == hipSuccess; ++mode)
+    for (int mode = 0; mode < 5 && err == hipSuccess; ++mode)
         err = stream_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);

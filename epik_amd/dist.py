@@ -251,3 +251,249 @@ def kmer_sharded_gpu_fns(placer, seqs: np.ndarray, seq_offsets: np.ndarray, devi
         return rows, n_rows, kmer_counts
 
     return accumulate, finish
+
+
+# ---------------------------------------------------------------------------------------------------
+# K-mer-space shard with partial LISTS (include/epik_amd.h, "partial LISTS"): a shard's lists reach a
+# small part of a large tree per read, so what crosses is, per read and slice of the branch range, only
+# the rows that received a k-mer -- kilobytes per read where the dense vectors are 6 bytes per branch --
+# and the exchange of batch b runs under the accumulate of batch b + 1.
+#
+# An ENGINE is the two kernel halves behind a small protocol (`ListsGpuEngine` below: the HIP placer;
+# tests/dist_worker_kmer.py has a numpy one for the gloo tests on CPU):
+#     slices, entry_bytes                          geometry of the lists, the same on every rank
+#     compute_stream, comm_stream                  torch streams, or None (no device)
+#     begin(seqs, seq_offsets) -> batch            uploads a batch every rank holds in full
+#     accumulate(batch, n_parts, amb_slot, amb_rows, min_entries=0) -> Partials   (asynchronous)
+#     finish(batch, begin, end, entries, index, amb_slot, amb_avg) -> (rows, n_rows, kmer_counts)
+#         entries / index: one tensor per shard, in shard order -- the part's entries as that shard
+#         wrote them and its [end - begin (padded), slices, 2] index
+# ---------------------------------------------------------------------------------------------------
+class Partials:
+    """What one accumulate leaves: `entries` (uint8, the parts one after the other), `index` (int32
+    [per * n_parts, slices, 2] = {first entry inside the part, entries}), `part_entries` (int64 [n_parts],
+    how many entries each part takes in `entries`), the ambiguous records (or None), the capacity of
+    `entries` in entries, and the event after which all of it is there (None: already)."""
+
+    def __init__(self, entries, index, part_entries, amb_order, amb_avg, cap, done=None):
+        self.entries, self.index, self.part_entries = entries, index, part_entries
+        self.amb_order, self.amb_avg, self.cap, self.done = amb_order, amb_avg, cap, done
+
+
+class ListsGpuEngine:
+    """The accumulate_lists / finish_lists halves of a `Placer` created with shard_index / shard_count
+    (a large tree: `placer.partial_info()["lists"]`).  `host_staging`: the exchange runs on host
+    tensors (a gloo group) -- the lists are copied out after accumulate and back in for finish."""
+
+    def __init__(self, placer, device, host_staging: bool = False, overlap: bool = True):
+        import torch
+        info = placer.partial_info()
+        if not info["lists"]:
+            raise ValueError("this placer's kernels leave dense partial vectors (a small tree): use place_kmer_sharded")
+        self.placer, self.device, self.host_staging = placer, device, host_staging
+        self.slices, self.num_branches, self.keep = info["slices"], info["num_branches"], placer.keep_at_most
+        self.entry_bytes = info["entry_bytes"]
+        self.postings_per_kmer = info["postings_per_kmer"]
+        self.kmer_size = placer.kmer_size
+        self.compute_stream = torch.cuda.current_stream(device)
+        self.comm_stream = torch.cuda.Stream(device) if (overlap and not host_staging) else None
+        self.margin = 1.3  # room in `entries` over the estimate; grows when a batch overflowed
+
+    def begin(self, seqs: np.ndarray, seq_offsets: np.ndarray):
+        import torch
+        seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = len(seq_offsets) - 1
+        lengths = np.diff(seq_offsets.astype(np.int64)) if n else np.zeros(0, np.int64)
+        batch = {"n": n, "offsets": seq_offsets,
+                 "d_seqs": torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.uint8)).to(self.device),
+                 "d_offs": torch.from_numpy(seq_offsets.view(np.int64)).to(self.device),
+                 "longest": int(lengths.max()) if n else 0,
+                 "kmers": int(np.maximum(lengths - (self.kmer_size - 1), 0).sum())}
+        return batch
+
+    def accumulate(self, batch, n_parts: int, amb_slot, amb_rows: int, min_entries: int = 0):
+        import torch
+        n, S, dev = batch["n"], self.slices, self.device
+        per = -(-n // n_parts) if n else 0
+        self.placer.choose_counts(batch["longest"])  # the count width (and with it the entry format) of this batch
+        self.entry_bytes = self.placer.partial_info()["entry_bytes"]
+        cap = max(int(batch["kmers"] * self.postings_per_kmer * self.margin) + 4096, int(min_entries))
+        cap = min(cap, (1 << 32) - 1)
+        with torch.cuda.stream(self.compute_stream):
+            entries = torch.empty(cap * self.entry_bytes, dtype=torch.uint8, device=dev)
+            index = torch.zeros((per * n_parts, S, 2), dtype=torch.int32, device=dev)
+            part_entries = torch.zeros(n_parts, dtype=torch.int64, device=dev)
+            d_slot = order = avg = None
+            if amb_rows:
+                d_slot = torch.from_numpy(np.ascontiguousarray(amb_slot, dtype=np.int32)).to(dev)
+                order = torch.full((amb_rows, self.num_branches), -1, dtype=torch.int32, device=dev)  # AMB_NONE
+                avg = torch.zeros((amb_rows, self.num_branches), dtype=torch.float32, device=dev)
+            self.placer.accumulate_lists_device(
+                batch["d_seqs"].data_ptr(), batch["d_offs"].data_ptr(), n, n_parts, entries.data_ptr(), cap,
+                index.data_ptr(), part_entries.data_ptr(), self.compute_stream.cuda_stream,
+                d_amb_slot=d_slot.data_ptr() if amb_rows else 0, d_amb_order=order.data_ptr() if amb_rows else 0,
+                d_amb_avg=avg.data_ptr() if amb_rows else 0)
+            done = self.compute_stream.record_event()
+        batch["_keep"] = (d_slot,)  # (alive until the kernels have run)
+        return Partials(entries, index, part_entries, order, avg, cap, done)
+
+    def finish(self, batch, begin: int, end: int, entries, index, amb_slot, amb_avg):
+        import torch
+        from . import capi
+        m, keep, dev = end - begin, self.keep, self.device
+        rows = np.zeros((m, keep), dtype=capi.PLACEMENT)
+        n_rows = np.zeros(m, dtype=np.uint32)
+        kmer_counts = np.zeros((m, keep), dtype=np.uint32)
+        if m == 0:
+            return rows, n_rows, kmer_counts
+        with torch.cuda.stream(self.compute_stream):
+            entries = [e.to(dev) for e in entries]
+            index = [x.to(dev).contiguous() for x in index]
+            d_slot = d_avg = None
+            if amb_avg is not None and amb_slot is not None:
+                d_slot = torch.from_numpy(np.ascontiguousarray(amb_slot, dtype=np.int32)).to(dev)
+                d_avg = amb_avg.to(dev).contiguous()
+            d_rows = torch.zeros(m * keep * 2, dtype=torch.float64, device=dev)  # 16 B per row
+            d_n_rows = torch.zeros(m, dtype=torch.int32, device=dev)
+            d_kc = torch.zeros(m * keep, dtype=torch.int32, device=dev)
+            self.placer.finish_lists_device(
+                batch["d_offs"].data_ptr() + 8 * begin, m, [e.data_ptr() if e.numel() else 0 for e in entries],
+                [x.data_ptr() for x in index], d_rows.data_ptr(), d_n_rows.data_ptr(), d_kc.data_ptr(),
+                self.compute_stream.cuda_stream, d_amb_slot=d_slot.data_ptr() if d_slot is not None else 0,
+                d_amb_avg=d_avg.data_ptr() if d_avg is not None else 0)
+            self.compute_stream.synchronize()
+            rows[:] = d_rows.cpu().numpy().view(capi.PLACEMENT).reshape(m, keep)
+            n_rows[:] = d_n_rows.cpu().numpy().view(np.uint32)
+            kmer_counts[:] = d_kc.cpu().numpy().view(np.uint32).reshape(m, keep)
+        return rows, n_rows, kmer_counts
+
+
+def _exchange_lists(engine, parts: Partials, n_reads: int, dist, rank: int, world: int):
+    """One exchange step: every rank sends each peer the part of that peer's reads -- its entries (as
+    many as the part takes: all-to-all with split sizes, known after a gather of the part sizes) and its
+    index (equal splits) -- one link per peer.  Returns (entries[g], index[g]) in shard order for the
+    reads this rank owns, and the total this rank's parts took (for the overflow check)."""
+    import torch
+    eb, S = engine.entry_bytes, engine.slices
+    per = -(-n_reads // world) if n_reads else 0
+    staged = getattr(engine, "host_staging", False)
+    sizes_mine = parts.part_entries.cpu() if staged else parts.part_entries
+    sizes = torch.empty(world * world, dtype=torch.int64, device=sizes_mine.device)
+    dist.all_gather_into_tensor(sizes, sizes_mine.contiguous())
+    sizes = sizes.cpu().view(world, world)            # [g][r]: entries shard g holds for the reads of rank r
+    mine_total = int(sizes[rank].sum())
+    if mine_total > parts.cap:                        # the caller repeats the accumulate with more room
+        return None, None, mine_total
+    send_split = [int(x) * eb for x in sizes[rank]]
+    recv_split = [int(sizes[g][rank]) * eb for g in range(world)]
+    send = parts.entries[:mine_total * eb]
+    send_index = parts.index
+    if staged:
+        send, send_index = send.cpu(), send_index.cpu()
+    recv = torch.empty(sum(recv_split), dtype=torch.uint8, device=send.device)
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_split, input_split_sizes=send_split)
+    recv_index = torch.empty_like(send_index)
+    # (the index crosses as bytes: the collectives of some backends do not take every integer type)
+    dist.all_to_all_single(recv_index.view(torch.uint8).view(-1), send_index.contiguous().view(torch.uint8).view(-1))
+    entries, at = [], 0
+    for g in range(world):
+        entries.append(recv[at:at + recv_split[g]])
+        at += recv_split[g]
+    index = [recv_index.view(world, per, S, 2)[g] for g in range(world)]
+    return entries, index, mine_total
+
+
+def place_kmer_sharded_lists(engine, batches, dist, char_class=None, gather_to: int | None = 0):
+    """K-mer-space-sharded placement of a sequence of batches, each held in full by every rank, with
+    partial lists and the exchange of a batch overlapped with the accumulate of the next one.
+
+    batches: iterable of (seqs uint8, seq_offsets uint64); char_class: the 256-entry class table (None: no
+    read holds an ambiguous character, no slots are made).  Yields, per batch and in order, what
+    `place_sharded` returns: the rank's own rows (gather_to None), or everything on `gather_to`.
+    """
+    import contextlib
+    import torch
+    rank, _, world = env_rank_world()
+    if dist is None:
+        rank, world = 0, 1
+    comm = getattr(engine, "comm_stream", None)
+    compute = getattr(engine, "compute_stream", None)
+
+    def start(seqs, offs):
+        n = len(offs) - 1
+        slot, per_owner = (None, 0)
+        if char_class is not None:
+            slot, per_owner = amb_slots(seqs, offs, char_class, world)
+            if per_owner == 0:
+                slot = None
+        batch = engine.begin(seqs, offs)
+        parts = engine.accumulate(batch, world, slot, per_owner * world)
+        return {"n": n, "batch": batch, "parts": parts, "slot": slot, "per_owner": per_owner}
+
+    def complete(job):
+        n, batch, parts = job["n"], job["batch"], job["parts"]
+        begin, end = owner_bounds(n, rank, world)
+        slot, per_owner = job["slot"], job["per_owner"]
+        my_slot = my_avg = None
+        if dist is None:
+            if parts.done is not None:
+                parts.done.synchronize()
+            total = int(parts.part_entries.sum())
+            while total > parts.cap:   # more room, once more (the estimate learns)
+                engine.margin *= 1.5
+                parts = engine.accumulate(batch, world, slot, per_owner * world, min_entries=total)
+                if parts.done is not None:
+                    parts.done.synchronize()
+                total = int(parts.part_entries.sum())
+            entries, index = [parts.entries[:total * engine.entry_bytes]], [parts.index]
+            if per_owner:
+                my_slot, my_avg = slot, parts.amb_avg
+            return engine.finish(batch, 0, n, entries, index, my_slot, my_avg)
+        while True:
+            ctx = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
+            with ctx:
+                if parts.done is not None:
+                    if comm is not None:
+                        comm.wait_event(parts.done)   # the exchange waits for THIS batch's accumulate only
+                    else:
+                        parts.done.synchronize()
+                entries, index, total = _exchange_lists(engine, parts, n, dist, rank, world)
+                # every rank repeats together: one that overflowed tells the others
+                flag = torch.tensor([1 if entries is None else 0], dtype=torch.int32,
+                                    device=parts.part_entries.device if not getattr(engine, "host_staging", False) else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                again = bool(flag.cpu().item())
+                if not again and per_owner:
+                    def cross(x):
+                        x = x.cpu() if getattr(engine, "host_staging", False) else x
+                        sent = x.contiguous().view(torch.uint8)
+                        got = torch.empty_like(sent)
+                        dist.all_to_all_single(got.view(-1), sent.view(-1))
+                        return got.view(x.dtype).view(world, x.shape[0] // world, -1)
+                    my_avg = combine_amb(cross(parts.amb_order), cross(parts.amb_avg))
+                    my_slot = slot[begin:end].copy()
+                    my_slot[my_slot >= 0] -= rank * per_owner
+                done = comm.record_event() if comm is not None else None
+            if not again:
+                break
+            engine.margin *= 1.5
+            parts = engine.accumulate(batch, world, slot, per_owner * world, min_entries=total or 0)
+        if done is not None and compute is not None:
+            compute.wait_event(done)
+        mine = engine.finish(batch, begin, end, entries, [x[:max(end - begin, 0)] for x in index], my_slot, my_avg)
+        if gather_to is None:
+            return mine
+        gathered = [None] * world if rank == gather_to else None
+        dist.gather_object(mine, gathered, dst=gather_to)
+        if rank != gather_to:
+            return None
+        return tuple(np.concatenate([p[i] for p in gathered], axis=0) for i in range(3))
+
+    pending = None
+    for seqs, offs in batches:
+        job = start(seqs, offs)          # batch b + 1 accumulates ...
+        if pending is not None:
+            yield complete(pending)      # ... while batch b crosses and finishes
+        pending = job
+    if pending is not None:
+        yield complete(pending)

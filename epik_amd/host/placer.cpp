@@ -108,6 +108,12 @@ std::vector<placed_collection> placer::place_batches(const std::vector<const std
         for (size_t u = 0; u < out[b].placed_seqs.size(); ++u) {
             const size_t i = first_unique[b] + u;
             auto& placements = out[b].placed_seqs[u].placements;
+            // (n_rows is a row count here: epik_amd_placer_place widens the counts by itself, so the
+            // EPIK_AMD_ROWS_COUNTS_TOO_NARROW mark of the device entry points must never arrive)
+            if (n_rows[i] > _keep_at_most)
+                throw std::runtime_error("GPU placer: read " + std::to_string(i) + " came back with " +
+                                         std::to_string(n_rows[i]) + " rows (keep_at_most " +
+                                         std::to_string(_keep_at_most) + ")");
             placements.reserve(n_rows[i]);
             for (uint32_t r = 0; r < n_rows[i]; ++r) {
                 const auto& row = rows[i * _keep_at_most + r];

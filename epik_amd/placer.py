@@ -233,6 +233,42 @@ class Placer:
             self._handle, d_seq_offsets, int(n), d_scores, d_counts, d_amb_slot or None, d_amb_avg or None,
             d_rows, d_n_rows, d_kmer_counts or None, stream or None))
 
+    def partial_info(self) -> dict:
+        """Geometry of the partial lists of this handle (`epik_amd_placer_partial_info`)."""
+        info = capi.PartialInfo()
+        capi.check(self._lib.epik_amd_placer_partial_info(self._handle, ctypes.byref(info)))
+        return {"lists": bool(info.lists), "slices": int(info.slices), "slice_rows": int(info.slice_rows),
+                "entry_bytes": int(info.entry_bytes), "num_branches": int(info.num_branches),
+                "postings_per_kmer": float(info.postings_per_kmer)}
+
+    def accumulate_lists_device(self, d_seqs: int, d_seq_offsets: int, n: int, n_parts: int, d_entries: int,
+                                entries_cap: int, d_index: int, d_part_entries: int, stream: int = 0,
+                                d_amb_slot: int = 0, d_amb_order: int = 0, d_amb_avg: int = 0) -> None:
+        """First half of a k-mer-space-sharded placement with partial LISTS: per read and slice of the branch
+        range only the rows this shard's lists touched (`epik_amd_placer_accumulate_lists_device`)."""
+        capi.check(self._lib.epik_amd_placer_accumulate_lists_device(
+            self._handle, d_seqs, d_seq_offsets, int(n), int(n_parts), d_entries or None, int(entries_cap), d_index,
+            d_part_entries, d_amb_slot or None, d_amb_order or None, d_amb_avg or None, stream or None))
+
+    def finish_lists_device(self, d_seq_offsets: int, n: int, d_entries, d_index, d_rows: int, d_n_rows: int,
+                            d_kmer_counts: int = 0, stream: int = 0, d_amb_slot: int = 0, d_amb_avg: int = 0) -> None:
+        """Second half: the shards' lists of the n reads (d_entries[g], d_index[g]: device addresses, one per
+        shard, in shard order) added in that order, then correction, top-k and like-weight-ratio
+        (`epik_amd_placer_finish_lists_device`)."""
+        g = len(d_entries)
+        assert len(d_index) == g
+        entries = (ctypes.c_void_p * g)(*[int(x) or None for x in d_entries])
+        index = (ctypes.c_void_p * g)(*[int(x) or None for x in d_index])
+        capi.check(self._lib.epik_amd_placer_finish_lists_device(
+            self._handle, d_seq_offsets, int(n), g, entries, index, d_amb_slot or None, d_amb_avg or None,
+            d_rows, d_n_rows, d_kmer_counts or None, stream or None))
+
+    def last_path(self) -> int:
+        """Which kernels the last launch ran: capi.PATH_WAVE / PATH_TEAM_ONE_KERNEL / PATH_TEAM_STREAMED."""
+        out = ctypes.c_uint32(0)
+        capi.check(self._lib.epik_amd_placer_last_path(self._handle, ctypes.byref(out)))
+        return int(out.value)
+
     def choose_counts(self, longest_read: int) -> None:
         """Width of the per-branch counts for the device entry points, chosen as `place_packed`
         chooses it from the batch (`epik_amd_placer_choose_counts`)."""
@@ -275,6 +311,10 @@ class Placer:
             offsets[1:] = np.cumsum([len(b) for b in bufs], dtype=np.uint64)
         data = np.frombuffer(b"".join(bufs), dtype=np.uint8) if bufs else np.zeros(0, np.uint8)
         rows, n_rows, counts = self.place_packed(data, offsets)
+        if len(n_rows) and int(n_rows.max()) > self.keep_at_most:
+            # (never from place_packed, which widens the counts by itself: a row count, not the
+            # EPIK_AMD_ROWS_COUNTS_TOO_NARROW mark of the device entry points)
+            raise RuntimeError(f"a read came back with {int(n_rows.max())} rows (keep_at_most {self.keep_at_most})")
         placed = []
         for i, seq in enumerate(unique):
             pl = []

@@ -193,7 +193,9 @@ int epik_amd_placer_choose_counts(epik_amd_placer *p, uint64_t longest_read);
  *
  *   accumulate_device : per read, the raw float32 score sums and the k-mer counts of this shard's
  *                       lists, d_scores float32 / d_counts uint16 = [n][num_branches]
- *                       (place.cpp:349-371 without 418-422); reads of up to 65535 k-mers;
+ *                       (place.cpp:349-371 without 418-422); reads of up to 65535 k-mers (a longer one
+ *                       leaves an all-zero vector and finish marks it EPIK_AMD_ROWS_COUNTS_TOO_NARROW:
+ *                       the partial lists below have no such limit);
  *   (caller)          : adds d_scores and d_counts over the shards -- one all-to-all + a sum in rank
  *                       order, each GPU keeping the totals of its own reads (epik_amd/dist.py);
  *   finish_device     : correction, top-k, like-weight-ratio and filter on the totals
@@ -222,6 +224,62 @@ int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets,
                                   const void *d_scores, const void *d_counts, const void *d_amb_slot,
                                   const void *d_amb_avg, void *d_rows, void *d_n_rows, void *d_kmer_counts,
                                   void *stream);
+
+/*
+ * The same two halves with partial LISTS instead of dense vectors (large trees: the handles whose
+ * epik_amd_placer_partial_info() says lists == 1).  A shard's lists reach a small part of a large tree per read
+ * (N = 9 999, 8 shards: ~5 % of the branches), so accumulate leaves, per read and SLICE of the branch range
+ * (slices * slice_rows >= num_branches; the same on every shard: the geometry depends on the tree alone), only the
+ * rows that received a k-mer:
+ *
+ *   entry  {f32 sum, u32 row | count << 16}      8 bytes (counts of 8 or 16 bits: reads of up to 32767 k-mers)
+ *          {f32 sum, u32 row, u32 count, u32 0}  16 bytes (32-bit counts, chosen for longer reads)
+ *          row = branch - slice * slice_rows; any order inside a list, every row at most once;
+ *   index  [n][slices] {u32 first, u32 count}: the list of (read, slice) = entries first .. first + count - 1 of
+ *          the read's PART.
+ *
+ * The n reads form n_parts equal runs of ceil(n / n_parts) reads -- part r is what finisher r needs, and its
+ * entries lie together: d_part_entries[r] (uint64) says how many entries part r takes in d_entries, the parts one
+ * after the other from the start (lists are laid out before they are filled, from an upper bound -- the postings
+ * of the slice's sublists --: a part is that bound added up, a few percent more than the entries its index names).
+ * If the parts together exceed entries_cap the lists that found no room are marked count == 0xffffffff and the
+ * call must be repeated with a larger buffer (read d_part_entries after the stream has finished; it is always
+ * complete).  entries_cap < 2^32.
+ *
+ * finish_lists takes, for its n reads (one part), what each of the n_shards shards left for them: d_entries[g] =
+ * the start of the part's entries as shard g wrote them, d_index[g] = the part's [n][slices] index of shard g
+ * (HOST arrays of device pointers), and adds the lists of a slice into LDS in shard order -- the float32 sums
+ * are those of the dense exchange's rank-order sum (0 + x is x) -- then finishes as finish_device does.  All
+ * shards and the finisher must run with the same count width (epik_amd_placer_choose_counts with the batch's
+ * longest read on each).  The ambiguous records cross as with the dense calls.
+ */
+#define EPIK_AMD_MAX_SHARDS 16
+typedef struct {
+    uint32_t lists;        /* 1: accumulate_lists / finish_lists are available on this handle */
+    uint32_t slices;       /* lists per read */
+    uint32_t slice_rows;   /* branches per slice */
+    uint32_t entry_bytes;  /* 8 or 16, for the count width chosen last */
+    uint32_t num_branches;
+    uint32_t reserved;
+    double postings_per_kmer; /* mean postings of this shard's lists per k-mer code (to size d_entries:
+                                 reads * k-mers per read * this, and some margin) */
+} epik_amd_partial_info;
+int epik_amd_placer_partial_info(const epik_amd_placer *p, epik_amd_partial_info *out);
+int epik_amd_placer_accumulate_lists_device(epik_amd_placer *p, const void *d_seqs, const void *d_seq_offsets,
+                                            uint64_t n, uint32_t n_parts, void *d_entries, uint64_t entries_cap,
+                                            void *d_index, void *d_part_entries, const void *d_amb_slot,
+                                            void *d_amb_order, void *d_amb_avg, void *stream);
+int epik_amd_placer_finish_lists_device(epik_amd_placer *p, const void *d_seq_offsets, uint64_t n, uint32_t n_shards,
+                                        const void *const *d_entries, const void *const *d_index,
+                                        const void *d_amb_slot, const void *d_amb_avg, void *d_rows, void *d_n_rows,
+                                        void *d_kmer_counts, void *stream);
+
+/* Which kernels the last launch of this handle ran (reports; a large-tree handle falls back from the three-kernel
+ * placement to the one-kernel one when the device has no room for the scratch of a launch). */
+#define EPIK_AMD_PATH_WAVE 0u            /* place_reads_kernel: one wavefront per read */
+#define EPIK_AMD_PATH_TEAM_ONE_KERNEL 1u /* team_place_kernel: one workgroup per read */
+#define EPIK_AMD_PATH_TEAM_STREAMED 2u   /* team_front_kernel + team_stream_kernel + team_merge_kernel (+ the other for the rest) */
+int epik_amd_placer_last_path(const epik_amd_placer *p, uint32_t *path);
 
 /* Launch geometry actually used (for reports): waves per workgroup (one read per wave with the
  * one-wavefront kernel, one slice of a read per wave on large trees), workgroups of the last launch,

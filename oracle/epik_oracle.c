@@ -504,8 +504,9 @@ int orc_place_batched(const orc_db *db, const char *seqs, const uint64_t *seq_of
         uint64_t n_unique = 0;
         for (uint64_t i = 0; i < m; ++i)
             if (first[i] == i) unique[n_unique++] = i;
+        int batch_failed = 0; /* a read whose scratch could not grow: the whole call fails, as orc_place_batch */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic) num_threads(num_threads)
+#pragma omp parallel for schedule(dynamic) num_threads(num_threads) reduction(| : batch_failed)
 #endif
         for (int64_t u = 0; u < (int64_t)n_unique; ++u) {
 #ifdef _OPENMP
@@ -517,6 +518,11 @@ int orc_place_batched(const orc_db *db, const char *seqs, const uint64_t *seq_of
             const int r = orc_place_read(db, s, seqs + seq_offsets[i], (size_t)(seq_offsets[i + 1] - seq_offsets[i]),
                                          rows + i * keep, counts ? counts + i * keep : NULL);
             n_rows[i] = r > 0 ? (uint32_t)r : 0;
+            if (r < 0) batch_failed |= 1;
+        }
+        if (batch_failed) {
+            failed = 1;
+            break;
         }
         for (uint64_t i = 0; i < m; ++i) { /* the headers of a duplicate share the placement (jplace "nm") */
             if (first[i] == i) continue;

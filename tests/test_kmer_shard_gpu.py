@@ -131,3 +131,201 @@ def test_two_ranks_on_the_one_gpu(gpu_available, oracle_lib, worker, db_layout):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "ok: world=2" in out.stdout
+
+
+# ---- partial LISTS (include/epik_amd.h): the same halves, only the touched rows per (read, slice) ----------
+def _lists_or_skip(pl, db_layout):
+    info = pl.partial_info()
+    if not info["lists"]:
+        assert not db_layout.startswith("team") or "classic" in db_layout, db_layout
+        pytest.skip("dense partial vectors only on this kernel (small tree / one-kernel placement)")
+    return info
+
+
+def _accumulate_lists(pl, d_seqs, d_offs, n, n_parts, slot, per, cap=None, longest=0):
+    """One accumulate_lists call into fresh torch buffers; returns (entries, index, part_entries, order, avg)."""
+    import torch
+    dev = d_seqs.device
+    pl.choose_counts(longest)
+    info = pl.partial_info()
+    S, eb, N = info["slices"], info["entry_bytes"], info["num_branches"]
+    per_part = -(-n // n_parts)
+    cap = int(cap if cap is not None else n * 4 * N // 3 + 1024)
+    entries = torch.full((max(cap, 1) * eb,), 0xAB, dtype=torch.uint8, device=dev)
+    index = torch.zeros((per_part * n_parts, S, 2), dtype=torch.int32, device=dev)
+    part_entries = torch.zeros(n_parts, dtype=torch.int64, device=dev)
+    d_slot = order = avg = None
+    if per:
+        d_slot = torch.from_numpy(np.ascontiguousarray(slot, dtype=np.int32)).to(dev)
+        order = torch.full((per, N), -1, dtype=torch.int32, device=dev)
+        avg = torch.zeros((per, N), dtype=torch.float32, device=dev)
+    pl.accumulate_lists_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, n_parts, entries.data_ptr(), cap, index.data_ptr(),
+                               part_entries.data_ptr(), 0, d_amb_slot=d_slot.data_ptr() if per else 0,
+                               d_amb_order=order.data_ptr() if per else 0, d_amb_avg=avg.data_ptr() if per else 0)
+    torch.cuda.synchronize()
+    return entries, index, part_entries.cpu().numpy(), order, avg
+
+
+def _finish_lists(pl, d_offs, begin, end, entries, index, slot, avg):
+    import torch
+    from epik_amd import capi
+    m, keep, dev = end - begin, pl.keep_at_most, d_offs.device
+    d_rows = torch.zeros(m * keep * 2, dtype=torch.float64, device=dev)
+    d_n = torch.zeros(m, dtype=torch.int32, device=dev)
+    d_kc = torch.zeros(m * keep, dtype=torch.int32, device=dev)
+    d_slot = torch.from_numpy(np.ascontiguousarray(slot, dtype=np.int32)).to(dev) if slot is not None else None
+    pl.finish_lists_device(d_offs.data_ptr() + 8 * begin, m, [e.data_ptr() for e in entries], [x.data_ptr() for x in index],
+                           d_rows.data_ptr(), d_n.data_ptr(), d_kc.data_ptr(), 0,
+                           d_amb_slot=d_slot.data_ptr() if d_slot is not None else 0,
+                           d_amb_avg=avg.data_ptr() if avg is not None else 0)
+    torch.cuda.synchronize()
+    return (d_rows.cpu().numpy().view(capi.PLACEMENT).reshape(m, keep), d_n.cpu().numpy().view(np.uint32),
+            d_kc.cpu().numpy().view(np.uint32).reshape(m, keep))
+
+
+def _check_lists(entries, index, part_entries, info, n, n_parts):
+    """What the header promises about a shard's lists: every list inside its part, rows below slice_rows and at
+    most once per list, no list marked as overflowed."""
+    eb, S = info["entry_bytes"], info["slices"]
+    idx = index.cpu().numpy().view(np.uint32).reshape(-1, S, 2)
+    raw = entries.cpu().numpy()
+    per = -(-n // n_parts)
+    part_first = np.concatenate([[0], np.cumsum(part_entries)])
+    assert (idx[:n, :, 1] != 0xFFFFFFFF).all()
+    for r in range(0, n, max(1, n // 97)):
+        part = r // per
+        for s in range(S):
+            first, count = int(idx[r, s, 0]), int(idx[r, s, 1])
+            assert first + count <= int(part_entries[part])
+            lo = (int(part_first[part]) + first) * eb
+            words = raw[lo:lo + count * eb].view(np.uint32).reshape(count, eb // 4)
+            rows = words[:, 1] & 0xFFFF if eb == 8 else words[:, 1]
+            cnts = words[:, 1] >> 16 if eb == 8 else words[:, 2]
+            assert (rows < info["slice_rows"]).all() and len(np.unique(rows)) == count and (cnts > 0).all()
+
+
+def test_lists_one_shard_is_the_one_pass_kernel(gpu_available, db_layout):
+    assert gpu_available
+    import torch
+    from epik_amd.placer import Placer
+    db, (data, offs) = _case()
+    dev = torch.device("cuda", 0)
+    n = len(offs) - 1
+    slot, per = edist.amb_slots(data, offs, alphabet.char_class_table(db.states), 1)
+    with Placer.from_synth(db) as pl:
+        info = _lists_or_skip(pl, db_layout)
+        ref = pl.place_packed(data, offs)
+        d_seqs = torch.from_numpy(data).to(dev)
+        d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+        longest = int(np.diff(offs.astype(np.int64)).max())
+        # without slots (the shard adds its ambiguous k-mers itself) and with them; one part and three
+        for use_slots, n_parts in ((False, 1), (True, 1), (True, 3)):
+            e, ix, pe, order, avg = _accumulate_lists(pl, d_seqs, d_offs, n, n_parts, slot, per if use_slots else 0, longest=longest)
+            _check_lists(e, ix, pe, info, n, n_parts)
+            part_first = np.concatenate([[0], np.cumsum(pe)])
+            per_part = -(-n // n_parts)
+            got = []
+            for r in range(n_parts):
+                b, en = min(n, r * per_part), min(n, (r + 1) * per_part)
+                if en == b:
+                    continue
+                got.append(_finish_lists(pl, d_offs, b, en, [e[int(part_first[r]) * info["entry_bytes"]:]],
+                                         [ix[r * per_part:]], slot[b:en] if use_slots else None, avg))
+            got = tuple(np.concatenate([g[i] for g in got]) for i in range(3))
+            assert_rows_match(*got, *ref, lwr_tol=0.0)
+
+
+def test_lists_overflow_is_reported_not_written(gpu_available, db_layout):
+    """A buffer too small for the parts: the lists that find no room are marked, nothing is written past
+    the buffer, and d_part_entries still says what the parts need."""
+    assert gpu_available
+    import torch
+    from epik_amd.placer import Placer
+    db, (data, offs) = _case()
+    dev = torch.device("cuda", 0)
+    n = len(offs) - 1
+    with Placer.from_synth(db) as pl:
+        info = _lists_or_skip(pl, db_layout)
+        d_seqs = torch.from_numpy(data).to(dev)
+        d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+        longest = int(np.diff(offs.astype(np.int64)).max())
+        _, _, need, _, _ = _accumulate_lists(pl, d_seqs, d_offs, n, 2, None, 0, longest=longest)
+        cap = int(need.sum()) // 3
+        e, ix, pe, _, _ = _accumulate_lists(pl, d_seqs, d_offs, n, 2, None, 0, cap=cap, longest=longest)
+        assert np.array_equal(pe, need)
+        counts = ix.cpu().numpy().view(np.uint32)[:n, :, 1]
+        assert (counts == 0xFFFFFFFF).any() and (counts != 0xFFFFFFFF).any()
+        assert (e.cpu().numpy()[cap * info["entry_bytes"]:] == 0xAB).all()
+
+
+def _emulated_shards_lists(db, data, offs, shards, n_parts):
+    """`shards` placers on the one device leave partial lists for `n_parts` finishers; every part is finished
+    from the shards' lists in shard order, the ambiguous records combined as place_kmer_sharded_lists does."""
+    import torch
+    from epik_amd.placer import Placer
+    n = len(offs) - 1
+    dev = torch.device("cuda", 0)
+    slot, per = edist.amb_slots(data, offs, alphabet.char_class_table(db.states), 1)
+    placers = [Placer.from_synth(db, shard_index=g, shard_count=shards) for g in range(shards)]
+    try:
+        info = placers[0].partial_info()
+        if not info["lists"]:
+            pytest.skip("dense partial vectors only on this kernel")
+        # (the geometry of the lists depends on the tree alone: the same on every shard)
+        assert all((p.partial_info()["slices"], p.partial_info()["slice_rows"]) == (info["slices"], info["slice_rows"]) for p in placers)
+        d_seqs = torch.from_numpy(data).to(dev)
+        d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+        longest = int(np.diff(offs.astype(np.int64)).max())
+        parts = [_accumulate_lists(p, d_seqs, d_offs, n, n_parts, slot, per, longest=longest) for p in placers]
+        info = placers[0].partial_info()  # (the entry format follows the count width chosen for this batch)
+        for e, ix, pe, _, _ in parts:
+            _check_lists(e, ix, pe, info, n, n_parts)
+        avg = edist.combine_amb(torch.stack([p[3] for p in parts]), torch.stack([p[4] for p in parts])) if per else None
+        per_part, eb = -(-n // n_parts), info["entry_bytes"]
+        got = []
+        for r in range(n_parts):
+            b, en = min(n, r * per_part), min(n, (r + 1) * per_part)
+            if en == b:
+                continue
+            entries = [e[int(np.concatenate([[0], np.cumsum(pe)])[r]) * eb:] for e, _, pe, _, _ in parts]
+            index = [ix[r * per_part:] for _, ix, _, _, _ in parts]
+            got.append(_finish_lists(placers[r % shards], d_offs, b, en, entries, index, slot[b:en] if per else None, avg))
+        return tuple(np.concatenate([g[i] for g in got]) for i in range(3))
+    finally:
+        for p in placers:
+            p.close()
+
+
+@pytest.mark.parametrize("shards,n_parts", [(2, 2), (3, 1), (3, 3)])
+def test_lists_emulated_shards_match_the_oracle_and_the_dense_exchange(gpu_available, oracle_lib, shards, n_parts, db_layout):
+    """The lists are the dense vectors without their zeros: finish adds them in shard order, so the rows are
+    bit for bit those of the dense exchange's rank-order sum."""
+    assert gpu_available
+    if not db_layout.startswith("team") or "classic" in db_layout:
+        pytest.skip("dense partial vectors only on this kernel")
+    db, (data, offs) = _case()
+    got = _emulated_shards_lists(db, data, offs, shards, n_parts)
+    _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
+    assert_rows_match(*got, *_emulated_shards(db, data, offs, shards), lwr_tol=0.0)
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_n9999_lists_emulated_shards(gpu_available, oracle_lib, shards, db_layout):
+    """BASELINE configs[4] with partial lists, a read of more than 32767 k-mers among them (32-bit counts,
+    16-byte entries: the dense vectors' uint16 counts could not hold it)."""
+    assert gpu_available
+    if not db_layout.startswith("team") or "classic" in db_layout:
+        pytest.skip("dense partial vectors only on this kernel")
+    tree = synth.make_tree(5000, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=8, seed=47, p_present=0.6, lognormal=(3.5, 1.7))
+    rng = np.random.default_rng(50)
+    reads = mixed_reads(rng, 300, db.kmer_size, max_len=151)
+    reads += ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(500)] + ["ACGTN" * 70]
+    data, offs = synth.pack_reads(reads)
+    got = _emulated_shards_lists(db, data, offs, shards, shards)
+    _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
+    if shards == 2 and db_layout == "team4":
+        reads = reads[:40] + ["".join(rng.choice(list("ACGT"), size=40_000))]
+        data, offs = synth.pack_reads(reads)
+        got = _emulated_shards_lists(db, data, offs, shards, shards)
+        _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
