@@ -34,6 +34,7 @@ Rank 0 prints ONE JSON line.  Extra objects (rank 0, N=1 where they cost time):
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import re
@@ -197,14 +198,21 @@ def image_bytes(plan) -> int:
     return int(plan.table_bytes + plan.filter_bytes + plan.posting_bytes)
 
 
-def kernel_name(plan, placing: bool = True) -> str:
-    """What the HIP events around a launch time: one kernel, or -- placing on a large tree -- the three
-    kernels of the team placement back to back on the stream (epik_amd/csrc/team_stream.hip)."""
-    if plan.kernel != 1:
-        return "place_reads_kernel"
-    if placing and os.environ.get("EPIK_AMD_TEAM_FRONT", "1") != "0" and plan.team_waves * plan.team_passes <= 61:
-        return f"team_front_kernel<{plan.team_waves}> + team_stream_kernel<{plan.team_waves}> + team_merge_kernel"
-    return f"team_place_kernel<{plan.team_waves}>"
+def kernel_name(plan, pl, placing: bool = True) -> str:
+    """What the HIP events around a launch time, as the handle says it ran (`epik_amd_placer_last_path`, not
+    what the plan would have liked): one kernel, or -- on a large tree -- the kernels of the team placement
+    back to back on the stream (epik_amd/csrc/team_stream.hip)."""
+    from epik_amd import capi
+    path = pl.last_path()
+    if path == capi.PATH_WAVE:
+        return "place_reads_kernel" if placing else "place_reads_kernel (accumulate) + finish_reads_kernel"
+    w = plan.team_waves
+    if path == capi.PATH_TEAM_STREAMED:
+        if placing:
+            return f"team_front_kernel<{w}> + team_stream_kernel<{w}> + team_merge_kernel"
+        return (f"accumulate: team_front_kernel<{w}> + team_sparse_scan_kernel + team_stream_kernel<{w}>; "
+                f"finish: team_header_kernel + team_stream_kernel<{w}> + team_merge_kernel")
+    return f"team_place_kernel<{w}>"
 
 
 def main():
@@ -279,11 +287,115 @@ def main():
 
     step = make_step(placer)
 
+    drain = None
+    shard_info = None
     if kmer_shard:
         N = placer.num_branches
         per = -(-n // world)
         begin, end = edist.owner_bounds(n, rank, world)
+        pinfo = placer.partial_info()
+        shard_info = {"partials": "lists" if pinfo["lists"] else "dense"}
+    if kmer_shard and pinfo["lists"]:
+        # ---- partial lists (large trees): per read and slice only the rows this shard's lists touched ------
+        S, eb = pinfo["slices"], pinfo["entry_bytes"]
+        comm = torch.cuda.Stream(dev) if (dist is not None and not rehearsal) else None
+
+        def alloc(cap):
+            return {"entries": torch.empty(max(cap, 1) * eb, dtype=torch.uint8, device=dev), "cap": cap,
+                    "index": torch.zeros((per * world, S, 2), dtype=torch.int32, device=dev),
+                    "part_entries": torch.zeros(world, dtype=torch.int64, device=dev), "done": None}
+
+        def accumulate(buf):
+            placer.accumulate_lists_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, world, buf["entries"].data_ptr(),
+                                           buf["cap"], buf["index"].data_ptr(), buf["part_entries"].data_ptr(),
+                                           stream.cuda_stream)
+            buf["done"] = stream.record_event()
+
+        # one untimed pass says how much room the parts take (the same batch every step)
+        probe = alloc(int(n * max(args.read_length - args.kmer_size + 1, 1) * pinfo["postings_per_kmer"] * 2) + 65536)
+        accumulate(probe)
+        torch.cuda.synchronize()
+        need = int(probe["part_entries"].sum().item())
+        if need > probe["cap"]:
+            raise SystemExit(f"the sizing pass of the partial lists overflowed ({need} > {probe['cap']} entries)")
+        del probe
+        bufs = [alloc(need + 1024) for _ in range(2 if dist is not None else 1)]
+        shard_info.update({"entry_bytes": eb, "slices": S, "entries_per_read": need / n,
+                           "partial_bytes_per_read": (need * eb + S * 8 * n) / n,
+                           "dense_bytes_per_read": 6 * N})
+        own = {"entries": [None] * world, "index": [None] * world}
+
+        def exchange(buf):
+            """all-to-all of the parts (split sizes from a gather of the part sizes) and of their index, on the
+            communication stream behind THIS batch's accumulate only (epik_amd.dist._exchange_lists)."""
+            ctx = torch.cuda.stream(comm) if comm is not None else contextlib.nullcontext()
+            with ctx:
+                if comm is not None:
+                    comm.wait_event(buf["done"])
+                else:
+                    buf["done"].synchronize()
+                staged = rehearsal
+                mine = buf["part_entries"].cpu() if staged else buf["part_entries"]
+                sizes = torch.empty(world * world, dtype=torch.int64, device=mine.device)
+                dist.all_gather_into_tensor(sizes, mine)
+                sizes = sizes.cpu().view(world, world)
+                total = int(sizes[rank].sum())
+                send_split = [int(x) * eb for x in sizes[rank]]
+                recv_split = [int(sizes[g][rank]) * eb for g in range(world)]
+                send, send_index = buf["entries"][:total * eb], buf["index"]
+                if staged:
+                    send, send_index = send.cpu(), send_index.cpu()
+                recv = torch.empty(sum(recv_split), dtype=torch.uint8, device=send.device)
+                dist.all_to_all_single(recv, send, output_split_sizes=recv_split, input_split_sizes=send_split)
+                recv_index = torch.empty_like(send_index)
+                dist.all_to_all_single(recv_index.view(torch.uint8).view(-1), send_index.view(torch.uint8).view(-1))
+                if staged:
+                    recv, recv_index = recv.to(dev), recv_index.to(dev)
+                at = 0
+                for g in range(world):
+                    own["entries"][g] = recv[at:at + recv_split[g]]
+                    own["index"][g] = recv_index.view(world, per, S, 2)[g]
+                    at += recv_split[g]
+                own["keep"] = (recv, recv_index)
+                return comm.record_event() if comm is not None else None
+
+        def finish_lists():
+            if end > begin:
+                placer.finish_lists_device(d_offs.data_ptr() + 8 * begin, end - begin,
+                                           [e.data_ptr() if e.numel() else 0 for e in own["entries"]],
+                                           [x.data_ptr() for x in own["index"]], d_rows.data_ptr(), d_nrows.data_ptr(),
+                                           0, stream.cuda_stream)
+
+        if dist is None:
+            def step():  # noqa: F811
+                accumulate(bufs[0])
+                own["entries"][0], own["index"][0] = bufs[0]["entries"], bufs[0]["index"]
+                finish_lists()
+        else:
+            state = {"i": 0, "pending": None}
+
+            def complete(buf):
+                arrived = exchange(buf)
+                if arrived is not None:
+                    stream.wait_event(arrived)
+                finish_lists()
+
+            def step():  # noqa: F811
+                # batch i accumulates while batch i - 1 crosses and finishes (double-buffered)
+                buf = bufs[state["i"] & 1]
+                state["i"] += 1
+                accumulate(buf)
+                if state["pending"] is not None:
+                    complete(state["pending"])
+                state["pending"] = buf
+
+            def drain():  # noqa: F811
+                if state["pending"] is not None:
+                    complete(state["pending"])
+                    state["pending"] = None
+    elif kmer_shard:
         part = [torch.zeros((per * world, N), dtype=t, device=dev) for t in (torch.float32, torch.int16)]
+        shard_info.update({"partial_bytes_per_read": 6 * N, "dense_bytes_per_read": 6 * N})
 
         def exchange(x):  # one link per peer; the rows cross as bytes (epik_amd.dist.place_kmer_sharded)
             sent = x.view(torch.uint8)
@@ -312,9 +424,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed_steps(step_fn, steps, warmup):
+    def timed_steps(step_fn, steps, warmup, drain_fn=None):
         for _ in range(warmup):
             step_fn()
+        if drain_fn is not None:
+            drain_fn()
         torch.cuda.synchronize()
         barrier()
         starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
@@ -326,13 +440,15 @@ def main():
             starts[i].record(stream)
             step_fn()
             stops[i].record(stream)
+        if drain_fn is not None:  # (a pipelined step leaves its last batch to be finished: inside the timed region)
+            drain_fn()
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         return elapsed, float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
 
     # ---- timed region: exactly K steps, HIP events around every launch ------------------
-    elapsed, kernel_ms = timed_steps(step, args.steps, args.warmup)
+    elapsed, kernel_ms = timed_steps(step, args.steps, args.warmup, drain)
     elapsed = edist.max_over_ranks(elapsed, dist, device=None if rehearsal else dev)
 
     def roofline_of(pl, pl_plan, ms, workload_name):
@@ -344,7 +460,7 @@ def main():
         return {"bound": "hbm+mall" if working_set <= 2 * MALL_BYTES else "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(workload_name), "working_set_bytes": working_set, "mall_bytes": MALL_BYTES,
-                "kernel": kernel_name(pl_plan, not kmer_shard), "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel": kernel_name(pl_plan, pl, not kmer_shard), "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_read": alg_bytes / n}
 
     if rank == 0:
@@ -366,10 +482,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "reads_per_step_per_gpu": n,
-                       "parallelism": (f"k-mer space sharded over {world} GPU(s), one all-to-all + sum per step"
+                       "parallelism": (f"k-mer space sharded over {world} GPU(s), one exchange step per batch "
+                                       f"({shard_info['partials']} partials), overlapped with the next batch's accumulate"
                                        if kmer_shard else
                                        f"reads sharded over {world} GPU(s), DB replicated, no collective"),
-                       "launch": info, "mean_rows_per_read": float(n_rows_host.mean())},
+                       "launch": info, "mean_rows_per_read": float(n_rows_host.mean()),
+                       **({"kmer_shard": shard_info} if shard_info else {})},
             "roofline": roofline_of(placer, plan, kernel_ms, workload),
         }
     placer.close()

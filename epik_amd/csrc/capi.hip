@@ -110,6 +110,7 @@ struct epik_amd_placer {
         uint32_t stream_lds_bytes = 0, stream_blocks = 0;
     } geo[3];
     uint32_t *d_sparse_cap = nullptr;             // partial lists: room per (read, slice), front kernel -> scan kernel
+    unsigned long long *d_scan_tiles = nullptr;   // ... and the scan's tile sums
     size_t sparse_cap_items = 0;
     uint64_t front_failed_reads = 0;              // != 0: the scratch of the three-kernel placement could not be had for a
                                                   // launch of that many reads (not tried again for as many or more)
@@ -215,6 +216,7 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_front_pool);
     (void)hipFree(p->d_front_cursor);
     (void)hipFree(p->d_sparse_cap);
+    (void)hipFree(p->d_scan_tiles);
     if (p->h_front_cursor) (void)hipHostFree(p->h_front_cursor);
     if (p->ev_start) (void)hipEventDestroy(p->ev_start);
     if (p->ev_stop) (void)hipEventDestroy(p->ev_stop);
@@ -714,8 +716,12 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, b
     const uint32_t slices = (uint32_t)p->team_waves * p->team_passes;
     if (lists && (size_t)n * slices > p->sparse_cap_items) {
         (void)hipFree(p->d_sparse_cap);
-        p->d_sparse_cap = nullptr, p->sparse_cap_items = 0;
+        (void)hipFree(p->d_scan_tiles);
+        p->d_sparse_cap = nullptr, p->d_scan_tiles = nullptr, p->sparse_cap_items = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_sparse_cap), (size_t)n * slices * sizeof(uint32_t)));
+        // (the scan's tile sums: at most a tile per part more than the reads alone make)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_scan_tiles),
+                          (size_t)(epik_amd::sparse_scan_tiles(n, slices) + EPIK_AMD_MAX_SHARDS) * sizeof(unsigned long long)));
         p->sparse_cap_items = (size_t)n * slices;
     }
     const size_t hdr_bytes = (size_t)n * epik_amd::front_hdr_stride(slices);
@@ -880,7 +886,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
                 HIP_TRY(hipMemsetAsync(p->d_front_cursor, 0, 2 * sizeof(unsigned long long), stream));
                 HIP_TRY(epik_amd::launch_team_front(tp, p->team_waves, p->counts, mode == kAccumulateLists,
                                                     dim3((unsigned)front_blocks), stream));
-                if (mode == kAccumulateLists) HIP_TRY(epik_amd::launch_team_sparse_scan(tp, p->team_waves, stream));
+                if (mode == kAccumulateLists) HIP_TRY(epik_amd::launch_team_sparse_scan(tp, p->team_waves, p->d_scan_tiles, stream));
             }
             const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
             uint64_t stream_blocks = n * parts;

@@ -506,9 +506,35 @@ struct WaveLds {
 // not yet refilled: seven slots are in flight and slot i+1 is the oldest, so the wait is
 // vmcnt(kLoads * (kDepth - 2)).
 // ---------------------------------------------------------------------------------
-template <typename Layout, typename CountT, int kDepth = kRing>
+// The postings of a round's first kDepth chunks when they were fetched ahead (team_stream_kernel: the descriptors
+// of a wave's next read are there a read ahead, so its first trip to memory can lie under the epilogue of the read in
+// front): plain loads into plain registers -- the compiler counts them, and nothing of the ring is in flight
+// while they are.  cell[i] / score[i]: what the ring's slot i would hold for chunk i.
+template <int kDepth>
+struct Preloaded {
+    uint32_t cell[kDepth], score[kDepth];
+};
+// (`d`: the chunk's descriptor, address | count << 48, the same in all lanes)
+template <typename Layout>
+__device__ __forceinline__ void preload_chunk(uint64_t d, uint32_t &cell, uint32_t &score)
+{
+    static_assert(Layout::kChunkBytes == 64u * 6u, "the packed chunk format: f32 score[cnt], u16 cell[cnt]");
+    typedef __attribute__((address_space(1))) const uint32_t global_u32;
+    typedef __attribute__((address_space(1))) const uint16_t global_u16;
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint64_t addr = d & 0xffffffffffffull;
+    const uint32_t cnt = (uint32_t)(d >> 48);
+    cell = score = 0;  // lanes past the end: cell 0, the dummy row
+    if (lane < cnt) {
+        score = ((global_u32 *)(uintptr_t)addr)[lane];
+        cell = ((global_u16 *)(uintptr_t)(addr + 4u * cnt))[lane];
+    }
+}
+
+template <typename Layout, typename CountT, int kDepth = kRing, bool kPreloaded = false>
 __device__ __forceinline__ void stream_round(const PlaceParams &p, const typename WaveLds<CountT>::u64_t *chunks,
-                                                       uint32_t n_padded, uint32_t score_top, uint32_t count_top)
+                                                       uint32_t n_padded, uint32_t score_top, uint32_t count_top,
+                                                       const Preloaded<kDepth> *pre = nullptr)
 {
     typedef __attribute__((address_space(3))) float lds_f32;
     typedef __attribute__((address_space(3))) CountT lds_count;
@@ -516,7 +542,12 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
     (void)p;
     uint32_t ring_c[kDepth], ring_s[kDepth];
 #pragma unroll
-    for (int i = 0; i < kDepth; ++i) ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
+    for (int i = 0; i < kDepth; ++i) {
+        if constexpr (kPreloaded)
+            ring_c[i] = pre->cell[i], ring_s[i] = pre->score[i];  // the round's first chunks are here already
+        else
+            ring_c[i] = ring_s[i] = 0;  // cell 0: the dummy row
+    }
     // the two LDS addresses of a slot's posting, behind the wait for its loads
     auto addresses = [](uint32_t &slot_cell, auto wait_count, uint32_t &score_addr, uint32_t &count_addr, uint32_t s_top,
                         uint32_t c_top) {
@@ -557,8 +588,10 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
     };
     uint32_t sa, ca;  // addresses of the slot the next stage works on
     addresses(ring_c[0], std::integral_constant<int, 0>{}, sa, ca, score_top, count_top);
-    uint64_t d_next = chunks[lane & (kDepth - 1)];  // descriptors of trip 0, lane i <-> stage i
-    for (uint32_t c0 = 0; c0 < n_padded; c0 += kDepth) {
+    // (preloaded: the ring starts out holding chunks 0 .. kDepth-1, and the first trip fetches the next kDepth)
+    constexpr uint32_t kFirst = kPreloaded ? (uint32_t)kDepth : 0u;
+    uint64_t d_next = chunks[kFirst + (lane & (kDepth - 1))];  // descriptors of the first trip, lane i <-> stage i
+    for (uint32_t c0 = kFirst; c0 < n_padded; c0 += kDepth) {
         uint32_t field[Layout::kFields];
         Layout::prepare(d_next, field);
         d_next = chunks[c0 + kDepth + (lane & (kDepth - 1))];  // next trip (spare entries behind the end)

@@ -142,7 +142,9 @@ hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_p
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, bool lists, dim3 grid, hipStream_t stream);
 hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
                               hipStream_t stream, const SparseSources *sources = nullptr);
-hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, hipStream_t stream);
+// (tile_sums: scratch of sparse_scan_tiles(reads per part, slices) * parts 64-bit words)
+uint64_t sparse_scan_tiles(uint64_t part_reads, uint32_t slices);
+hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, unsigned long long *tile_sums, hipStream_t stream);
 hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipStream_t stream);
 hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream);
 constexpr size_t kTeamPartialBytes = 24;  // sizeof(TeamPartial) (place_device.hpp)

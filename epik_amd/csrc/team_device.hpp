@@ -381,8 +381,9 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 // of the slice's sublists, at most the slice's rows).  Four consecutive rows per lane and trip.
 template <typename CountT>
 __device__ __forceinline__ uint32_t emit_partial_list(WaveLds<CountT> lds, uint32_t rows_pad, uint32_t rows,
-                                                      uint8_t *__restrict__ out, uint32_t cap)
+                                                      uint8_t *__restrict__ out, uint32_t cap, uint32_t ablate = 0)
 {
+    (void)ablate;
     typedef WaveLds<CountT> Lds_t;
     typedef PartialEntry<CountT> Entry;
     typedef __attribute__((address_space(3))) v4u u32x4_t;
@@ -410,6 +411,9 @@ __device__ __forceinline__ uint32_t emit_partial_list(WaveLds<CountT> lds, uint3
             const uint64_t m = __ballot(hit);
             if (m) {
                 const uint32_t slot = n + lanes_below(m);
+#ifdef EPIK_AMD_ABLATION
+                if (ablate & 128u) cap = 0;  // (timing experiments: no entry leaves)
+#endif
                 if (hit && slot < cap) dst[slot] = Entry::make(__float_as_uint(raw[u]), i0 + (uint32_t)u, c);
                 n += (uint32_t)__popcll(m);
             }
@@ -429,49 +433,82 @@ __device__ __forceinline__ uint32_t emit_partial_list(WaveLds<CountT> lds, uint3
     return n;
 }
 
-// The other direction (finish): the lists every shard sent for this (read, slice), in shard order, added into
+// The other direction (finish): the lists every shard sent for a (read, slice) item, in shard order, added into
 // the wave's rows -- the same float32 order as a dense sum over the shards in rank order, 0 + x being x
 // (place.cpp:349-371 split over the shards' lists).  `item` = read * slices + slice, the read numbered inside
 // the finisher's batch.  A trip is up to four chunks of 64 entries of ONE list: its rows are distinct, so the
 // four LDS read-add-writes go out together (one round trip per trip, not per chunk); lists of different shards
-// may name the same row and stay in order.  The next trip's entries are asked for before this one's are added.
+// may name the same row and stay in order.  The next trip's entries are asked for before this one's are added,
+// and the walk comes in three steps so that the caller can put an item's two dependent trips to memory (index,
+// then entries) under the work on the item in front of it: request() asks for the item's index entries (lane g:
+// shard g's), start() for its first trip, run() does the rest.
+// where the shards' lists lie, one shard per lane (loaded from the argument block once per kernel: indexed by
+// the lane there, every request would begin with a trip to memory for the pointer itself)
+struct ListSources {
+    uint64_t entries = 0, index = 0;  // lane g: shard g's
+    uint32_t n_shards = 0;
+    __device__ __forceinline__ void load(const SparseSources &src)
+    {
+        const uint32_t lane = (uint32_t)lane_id();
+        n_shards = src.n_shards;
+        if (lane < n_shards) {
+            entries = (uint64_t)src.entries[lane];
+            index = (uint64_t)src.index[lane];
+        }
+    }
+};
 template <typename CountT>
-__device__ __forceinline__ void merge_partial_lists(const SparseSources &src, WaveLds<CountT> lds, uint64_t item,
-                                                    uint32_t rows_pad)
-{
+struct ListWalk {
     typedef PartialEntry<CountT> Entry;
     typedef typename Entry::raw_t raw_t;
-    constexpr int kTrip = 4;  // chunks of 64 entries
-    const uint32_t lane = (uint32_t)lane_id();
-    const uint32_t n_shards = src.n_shards;
-    // lane g: where shard g's list lies and how long it is
-    uint32_t my_first = 0, my_count = 0;
-    if (lane < n_shards) {
-        const uint2 ix = src.index[lane][item];
-        my_first = ix.x;
-        my_count = ix.y == kSparseOverflow ? 0u : ix.y;  // (the caller has checked: see epik_amd.h)
-    }
+    static constexpr int kTrip = 4;  // chunks of 64 entries
     struct Trip {
         raw_t e[kTrip];
     };
-    const uint32_t dummy = rows_pad - 1u;
-    // the walk over (shard, first entry of the trip), scalar
-    uint32_t g = 0, at = 0, cnt = 0;
+    uint64_t item = ~0ull;             // whose lists these are
+    uint32_t first = 0, count = 0;     // lane g: where shard g's list lies in its part, and how long it is
+                                       // (as loaded: nothing looks at them before settle(), or the request would wait)
+    bool started = false, more = false;
+    Trip trip0;                        // the first trip (started && more)
+    uint32_t g = 0, at = 0, cnt = 0;   // the walk: shard, next entry of its list, the list's length (scalar)
     const uint8_t *base = nullptr;
-    auto settle = [&]() {  // on the next trip that exists; false at the end
-        while (g < n_shards) {
-            cnt = (uint32_t)__builtin_amdgcn_readlane(my_count, (int)g);
+
+    __device__ __forceinline__ void request(const ListSources &src, uint64_t it)
+    {
+        const uint32_t lane = (uint32_t)lane_id();
+        item = it;
+        first = count = 0;
+        started = false;
+        if (lane < src.n_shards) {
+            typedef __attribute__((address_space(1))) const v2u global_v2u;
+            const v2u ix = ((global_v2u *)(uintptr_t)src.index)[it];
+            first = ix.x;
+            count = ix.y;
+        }
+    }
+    // on the next trip that exists; false at the end
+    __device__ __forceinline__ bool settle(const ListSources &src)
+    {
+        while (g < src.n_shards) {
+            cnt = (uint32_t)__builtin_amdgcn_readlane(count, (int)g);
+            if (cnt == kSparseOverflow) cnt = 0;  // (the caller has checked: see epik_amd.h)
             if (at < cnt) {
-                base = src.entries[g] + (uint64_t)(uint32_t)__builtin_amdgcn_readlane(my_first, (int)g) * Entry::kBytes;
+                base = reinterpret_cast<const uint8_t *>(readlane_u64(src.entries, (int)g)) +
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane(first, (int)g) * Entry::kBytes;
                 return true;
             }
             ++g, at = 0;
         }
         return false;
-    };
-    auto load_trip = [&]() {
+    }
+    __device__ __forceinline__ Trip load_trip(uint32_t dummy)
+    {
+        const uint32_t lane = (uint32_t)lane_id();
         Trip t;
-        const raw_t *list = reinterpret_cast<const raw_t *>(base);
+        // (a pointer that came through v_readlane is generic to the compiler: say that it is global memory, or the
+        // loads become flat_load)
+        typedef __attribute__((address_space(1))) const raw_t global_raw_t;
+        global_raw_t *list = (global_raw_t *)(uintptr_t)base;
 #pragma unroll
         for (int c = 0; c < kTrip; ++c) {
             t.e[c] = Entry::make(0u, dummy, 0u);  // lanes behind the list's end: +0 on the dummy row
@@ -480,8 +517,16 @@ __device__ __forceinline__ void merge_partial_lists(const SparseSources &src, Wa
         }
         at += (uint32_t)kTrip * (uint32_t)kWave;
         return t;
-    };
-    auto add_trip = [&](const Trip &t) {
+    }
+    __device__ __forceinline__ void start(const ListSources &src, uint32_t dummy)
+    {
+        g = 0, at = 0;
+        more = settle(src);
+        if (more) trip0 = load_trip(dummy);
+        started = true;
+    }
+    __device__ static __forceinline__ void add_trip(WaveLds<CountT> lds, const Trip &t)
+    {
         float old_s[kTrip];
         uint32_t old_c[kTrip], row[kTrip];
 #pragma unroll
@@ -495,18 +540,22 @@ __device__ __forceinline__ void merge_partial_lists(const SparseSources &src, Wa
             lds.score[row[c]] = __fadd_rn(old_s[c], __uint_as_float(t.e[c].x));
             lds.count[row[c]] = (CountT)(old_c[c] + Entry::count(t.e[c]));
         }
-    };
-    if (!settle()) return;
-    Trip cur = load_trip();
-    for (;;) {
-        const bool more = settle();
-        Trip next;
-        if (more) next = load_trip();
-        add_trip(cur);
-        if (!more) break;
-        cur = next;
     }
-}
+    __device__ __forceinline__ void run(const ListSources &src, WaveLds<CountT> lds, uint32_t dummy)
+    {
+        if (!started) start(src, dummy);
+        if (!more) return;
+        Trip cur = trip0;
+        for (;;) {
+            const bool again = settle(src);
+            Trip next;
+            if (again) next = load_trip(dummy);
+            add_trip(lds, cur);
+            if (!again) break;
+            cur = next;
+        }
+    }
+};
 
 }  // namespace
 }  // namespace epik_amd

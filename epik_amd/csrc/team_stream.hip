@@ -51,7 +51,8 @@ namespace epik_amd {
 // how many entries the list of every (read, slice) may take -- the postings of the slice's sublists, at most
 // the slice's rows -- into tp.sparse_cap; team_sparse_scan_kernel lays the lists out from that.
 template <int W, bool kLists>
-__global__ __launch_bounds__(64, W == 4 ? EPIK_AMD_FRONT_OCC : 1) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
+// (kLists: the four extra sums do not fit the 64 registers of eight waves per SIMD: six)
+__global__ __launch_bounds__(64, W == 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
 {
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
@@ -429,17 +430,47 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     };
     uint32_t word_cur = 0, word_next = 0;
     uint64_t desc_cur = null_desc;
+    // ... and the postings of its first chunks (the ring's first fill) are asked for behind this read's stream, in
+    // front of its epilogue: a trip to HBM that the wave would otherwise sit out at the start of every read
+    Preloaded<(int)kTeamRing> pre;
+    auto preload = [&](uint64_t descs) {
+#pragma unroll
+        for (int i = 0; i < (int)kTeamRing; ++i) preload_chunk<TeamChunks>(readlane_u64(descs, i), pre.cell[i], pre.score[i]);
+    };
+    // partial lists in (finish): the walk over the shards' lists of this item and of the one behind it
+    [[maybe_unused]] ListWalk<CountT> walk, walk_next;
+    [[maybe_unused]] ListSources lists;
+    if constexpr (kMode == kTeamModeFinishLists) lists.load(src);
+    // partial lists out (accumulate), lane pass: where the list of (read, pass * W + wave) begins in its part and how
+    // much room it has -- loaded a read ahead, like the descriptors
+    [[maybe_unused]] uint32_t room_cur = 0, first_cur = 0;
+    auto load_room = [&](uint64_t r, uint32_t &first_out, uint32_t &room_out) {
+        if constexpr (kMode == kTeamModeAccumulateLists) {
+            first_out = room_out = 0;
+            if ((uint32_t)lane < tp.passes) {
+                const uint64_t at = r * n_slices + (uint32_t)lane * W + wave;
+                first_out = tp.sparse_index[at].x;
+                room_out = tp.sparse_cap[at];
+            }
+        }
+    };
+    if constexpr (kMode == kTeamModeAccumulateLists)
+        if (first_read < p.n_reads) load_room(first_read, first_cur, room_cur);
     if (first_read < p.n_reads) {
         word_cur = load_header(first_read);
         if (first_read + read_stride < p.n_reads) word_next = load_header(first_read + read_stride);
         desc_cur = first_round(word_cur);
     }
+    if constexpr (kMode != kTeamModeFinish && kMode != kTeamModeFinishLists) preload(desc_cur);
     for (uint64_t read = first_read; read < p.n_reads; read += read_stride) {
         const uint32_t word = word_cur;
         const uint64_t my_desc = desc_cur;
         word_cur = word_next;
         desc_cur = read + read_stride < p.n_reads ? first_round(word_cur) : null_desc;
         if (read + 2ull * read_stride < p.n_reads) word_next = load_header(read + 2ull * read_stride);
+        [[maybe_unused]] const uint32_t my_first = first_cur, my_room = room_cur;
+        if constexpr (kMode == kTeamModeAccumulateLists)
+            if (read + read_stride < p.n_reads) load_room(read + read_stride, first_cur, room_cur);
         STREAM_STAMP(9)  // next read
         const uint32_t flags = __builtin_amdgcn_readlane(word, 1);
         // place.cpp:322 underflows for len < k; we report "no placement".  A read with more k-mers than this
@@ -454,9 +485,13 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                     p.partial_counts[read * p.num_branches + base + i] = 0u;
                 }
             }
+            preload(desc_cur);  // (every turn of the loop leaves the first postings of the wave's next read on their way)
             continue;
         }
-        if (flags & (kFrontNoRows | kFrontTooNarrow | kFrontSlow)) continue;
+        if (flags & (kFrontNoRows | kFrontTooNarrow | kFrontSlow)) {
+            if constexpr (kMode != kTeamModeFinish && kMode != kTeamModeFinishLists) preload(desc_cur);
+            continue;
+        }
         const uint64_t len = __builtin_amdgcn_readlane(word, 2);
         const uint64_t n_kmers = len - k + 1;  // :322
 
@@ -492,9 +527,27 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                     lds.store(i, __float_as_uint(sc), c);
                 }
             } else if constexpr (kMode == kTeamModeFinishLists) {
-                // ... the same from the shards' partial lists, in shard order; then the ambiguous record
-                merge_partial_lists<CountT>(src, lds, slice_at, rows_pad);
+                // ... the same from the shards' partial lists, in shard order; then the ambiguous record.  The
+                // item behind this one (the read's next pass, or the wave's next read) has its index asked for
+                // before this one's lists are added and its first entries before this one's epilogue: the two
+                // dependent trips to memory of an item lie under the work on the item in front of it.
+                // (the copy of the prepared walk HERE, behind the epilogue of the item in front: its first entries are
+                // on their way until then, and a copy is a use)
+                if (walk_next.item == slice_at) walk = walk_next;
+                // (the read's slot is asked for here, not behind the requests below: vector memory operations
+                // return in order, and waiting for this one would wait for those)
                 const int64_t slot = p.amb_slot ? (int64_t)p.amb_slot[read] : -1;
+                if (walk.item != slice_at) walk.request(lists, slice_at);
+                uint64_t next_item = ~0ull;
+                if (pass + 1 < tp.passes)
+                    next_item = slice_at + W;
+                else if (read + read_stride < p.n_reads &&
+                         !(__builtin_amdgcn_readlane(word_cur, 1) & (kFrontSlow | kFrontNoRows | kFrontTooNarrow)))
+                    next_item = (read + read_stride) * n_slices + wave;
+                walk_next.item = ~0ull;
+                if (next_item != ~0ull) walk_next.request(lists, next_item);
+                walk.run(lists, lds, rows_pad - 1u);
+                if (next_item != ~0ull) walk_next.start(lists, rows_pad - 1u);
                 if (slot >= 0) {
                     for (uint32_t i = lane; i < ctx.rows_; i += kWave) {
                         const float avg = p.amb_avg[(uint64_t)slot * p.num_branches + ctx.base_ + i];
@@ -518,9 +571,14 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
 #ifdef EPIK_AMD_ABLATION
                 if (p.ablate & 8u) continue;  // (timing experiments: nothing streamed)
 #endif
-                stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_round, score_top, count_top);
+                if (pass == 0 && r0 == 0)
+                    stream_round<TeamChunks, CountT, (int)kTeamRing, true>(p, lds.desc, n_round, score_top, count_top, &pre);
+                else
+                    stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_round, score_top, count_top);
                 STREAM_STAMP(1)  // stream
             }
+            // the wave's next read: its first chunks' postings, on their way under what follows
+            if (pass + 1 == tp.passes) preload(desc_cur);
             // (no ambiguous k-mers here: the front kernel leaves such a read to team_place_kernel)
             }
             if constexpr (kMode == kTeamModeAccumulate) {
@@ -538,14 +596,13 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             }
             if constexpr (kMode == kTeamModeAccumulateLists) {
                 // ... as a list of the rows that received a k-mer, where the scan kernel made room for it
-                const uint2 ix = tp.sparse_index[slice_at];
-                const uint32_t room = tp.sparse_cap[slice_at];
+                const uint32_t room = (uint32_t)__builtin_amdgcn_readlane(my_room, (int)pass);
                 const uint32_t part = (uint32_t)(read / tp.sparse_part_reads);
-                const uint64_t first = readlane_u64(part_first, (int)part) + ix.x;
+                const uint64_t first = readlane_u64(part_first, (int)part) + (uint32_t)__builtin_amdgcn_readlane(my_first, (int)pass);
                 const bool fits = first + room <= tp.sparse_entries_cap;
                 const uint32_t n_out = emit_partial_list<CountT>(lds, rows_pad, ctx.rows_,
                                                                  tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
-                                                                 fits ? room : 0u);
+                                                                 fits ? room : 0u, p.ablate);
                 if (lane == 0) tp.sparse_index[slice_at].y = fits ? n_out : kSparseOverflow;
                 continue;
             }
@@ -577,43 +634,75 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
 }
 
 // Partial lists: room for every (read, slice) list of a part, one after the other in read order, from the front
-// kernel's bounds.  One workgroup per part (a part = the reads of one finisher); 4 096 items per trip.
-__global__ __launch_bounds__(1024) void team_sparse_scan_kernel(TeamParams tp, uint32_t n_slices)
+// kernel's bounds (a part = the reads of one finisher): an exclusive prefix sum per part, in two kernels -- the
+// sum of every tile of kScanTile items, then, per tile, the tiles in front of it added up and the tile scanned.
+constexpr uint32_t kScanTile = 4096, kScanThreads = 256;  // 16 items per thread
+__device__ __forceinline__ uint64_t scan_block_sum(uint64_t v, unsigned long long *wave_sums /*[kScanThreads / 64]*/)
 {
-    __shared__ unsigned long long wave_total[16];
-    __shared__ unsigned long long carry_s;
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+    if ((threadIdx.x & 63u) == 0) wave_sums[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t total = 0;
+    for (uint32_t w = 0; w < kScanThreads / 64u; ++w) total += wave_sums[w];
+    __syncthreads();
+    return total;
+}
+// grid (tiles per part, parts)
+__global__ __launch_bounds__(kScanThreads) void team_sparse_sums_kernel(TeamParams tp, uint32_t n_slices, unsigned long long *tile_sums)
+{
+    __shared__ unsigned long long wave_sums[kScanThreads / 64];
+    const PlaceParams &p = tp.base;
+    const uint64_t r0 = (uint64_t)blockIdx.y * tp.sparse_part_reads;
+    const uint64_t r1 = r0 + tp.sparse_part_reads < p.n_reads ? r0 + tp.sparse_part_reads : p.n_reads;
+    const uint64_t items = r1 > r0 ? (r1 - r0) * n_slices : 0;
+    const uint32_t *__restrict__ room = tp.sparse_cap + r0 * n_slices;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kScanTile;
+    uint64_t mine = 0;
+    for (uint32_t u = 0; u < kScanTile / kScanThreads; ++u) {
+        const uint64_t i = t0 + (uint64_t)u * kScanThreads + threadIdx.x;  // (coalesced: the order does not matter for a sum)
+        if (i < items) mine += room[i];
+    }
+    const uint64_t total = scan_block_sum(mine, wave_sums);
+    if (threadIdx.x == 0) tile_sums[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void team_sparse_scan_kernel(TeamParams tp, uint32_t n_slices, const unsigned long long *tile_sums)
+{
+    __shared__ unsigned long long wave_sums[kScanThreads / 64];
     const PlaceParams &p = tp.base;
     const uint32_t lane = (uint32_t)lane_id(), wave = threadIdx.x >> 6;
-    const uint64_t r0 = (uint64_t)blockIdx.x * tp.sparse_part_reads;
+    const uint64_t r0 = (uint64_t)blockIdx.y * tp.sparse_part_reads;
     const uint64_t r1 = r0 + tp.sparse_part_reads < p.n_reads ? r0 + tp.sparse_part_reads : p.n_reads;
     const uint64_t items = r1 > r0 ? (r1 - r0) * n_slices : 0;
     const uint32_t *__restrict__ room = tp.sparse_cap + r0 * n_slices;
     uint2 *__restrict__ index = tp.sparse_index + r0 * n_slices;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint64_t t0 = 0; t0 < items; t0 += 4096u) {
-        const uint64_t i0 = t0 + 4ull * threadIdx.x;
-        uint32_t v[4];
+    // the tiles of this part in front of this one (the first tile's workgroup adds up all of them: the part's size)
+    const unsigned long long *sums = tile_sums + (uint64_t)blockIdx.y * gridDim.x;
+    const uint32_t n_before = blockIdx.x == 0 ? gridDim.x : blockIdx.x;
+    uint64_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < n_before; t += kScanThreads) mine += sums[t];
+    const uint64_t before = scan_block_sum(mine, wave_sums);
+    if (blockIdx.x == 0 && threadIdx.x == 0) tp.sparse_part_total[blockIdx.y] = before;
+    // this tile: 16 consecutive items per thread
+    constexpr uint32_t kPer = kScanTile / kScanThreads;
+    const uint64_t i0 = (uint64_t)blockIdx.x * kScanTile + (uint64_t)kPer * threadIdx.x;
+    uint32_t v[kPer];
+    uint32_t own = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = i0 + (uint64_t)u < items ? room[i0 + (uint64_t)u] : 0u;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];  // (a list has at most the slice's rows: no wrap)
-        const uint32_t incl = wave_incl_scan_u32(mine);
-        if (lane == 63) wave_total[wave] = incl;
-        __syncthreads();
-        unsigned long long before = carry_s;
-        for (uint32_t w = 0; w < wave; ++w) before += wave_total[w];
-        unsigned long long at = before + (incl - mine);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            // (offsets inside a part are 32-bit: the host keeps a part's entries below 2^32, see capi.hip)
-            if (i0 + (uint64_t)u < items) index[i0 + (uint64_t)u] = make_uint2((uint32_t)at, 0u);
-            at += v[u];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = at;
-        __syncthreads();
+    for (uint32_t u = 0; u < kPer; ++u) {
+        v[u] = i0 + u < items ? room[i0 + u] : 0u;
+        own += v[u];  // (a list has at most the slice's rows, a tile 4096 lists: no wrap)
     }
-    if (threadIdx.x == 0) tp.sparse_part_total[blockIdx.x] = carry_s;
+    const uint32_t incl = wave_incl_scan_u32(own);
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint64_t at = (blockIdx.x == 0 ? 0ull : before) + (incl - own);
+    for (uint32_t w = 0; w < wave; ++w) at += wave_sums[w];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        // (offsets inside a part are 32-bit: the host keeps a part's entries below 2^32, see capi.hip)
+        if (i0 + u < items) index[i0 + u] = make_uint2((uint32_t)at, 0u);
+        at += v[u];
+    }
 }
 
 // The headers of a batch whose descriptors nobody needs (finish): length and the two "no placement" flags.
@@ -755,9 +844,14 @@ hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, bool l
     return hipGetLastError();
 }
 
-hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, hipStream_t stream)
+uint64_t sparse_scan_tiles(uint64_t part_reads, uint32_t slices) { return std::max<uint64_t>(1, (part_reads * slices + kScanTile - 1) / kScanTile); }
+
+hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, unsigned long long *tile_sums, hipStream_t stream)
 {
-    hipLaunchKernelGGL(team_sparse_scan_kernel, dim3(tp.sparse_parts), dim3(1024), 0, stream, tp, (uint32_t)waves * tp.passes);
+    const uint32_t slices = (uint32_t)waves * tp.passes;
+    const dim3 grid((unsigned)sparse_scan_tiles(tp.sparse_part_reads, slices), tp.sparse_parts);
+    hipLaunchKernelGGL(team_sparse_sums_kernel, grid, dim3(kScanThreads), 0, stream, tp, slices, tile_sums);
+    hipLaunchKernelGGL(team_sparse_scan_kernel, grid, dim3(kScanThreads), 0, stream, tp, slices, tile_sums);
     return hipGetLastError();
 }
 
