@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EPIK_AMD_LIB") or os.path.join(_HERE, "libepik_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 
@@ -42,6 +42,7 @@ EXPORTS = (
     "epik_amd_placer_accumulate_lists_device",
     "epik_amd_placer_finish_lists_device",
     "epik_amd_placer_last_path",
+    "epik_amd_placer_place_sharded",
     "epik_amd_placer_set_wide_counts",
     "epik_amd_placer_choose_counts",
     "epik_amd_placer_launch_info",
@@ -70,6 +71,8 @@ class PlacerDesc(ctypes.Structure):
         ("char_class", ctypes.c_void_p),
         ("device", ctypes.c_int32),
         ("reserved", ctypes.c_uint32),
+        ("keys", ctypes.c_void_p),
+        ("num_present", ctypes.c_uint64),
     ]
 
 
@@ -153,6 +156,8 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_placer_finish_lists_device.restype = i32
     lib.epik_amd_placer_finish_lists_device.argtypes = [vp, vp, u64, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                                         vp, vp, vp, vp, vp, vp]
+    lib.epik_amd_placer_place_sharded.restype = i32
+    lib.epik_amd_placer_place_sharded.argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, vp, vp, u64, vp, vp, vp]
     lib.epik_amd_placer_last_path.restype = i32
     lib.epik_amd_placer_last_path.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.epik_amd_placer_plan.restype = i32

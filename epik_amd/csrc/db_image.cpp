@@ -129,11 +129,15 @@ int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard
     const Source src{d, 0, 1};
     if (d->offset_bits == 32 && d->num_entries > 0xffffffffull)
         return fail(EPIK_AMD_ERR_INVALID, "num_entries needs 64-bit offsets");
-    if (src.offset_at(0) != 0 || src.offset_at(d->num_keys) != d->num_entries)
-        return fail(EPIK_AMD_ERR_INVALID, "offsets[0] != 0 or offsets[num_keys] != num_entries");
+    if (src.sparse() && d->num_present > d->num_keys) return fail(EPIK_AMD_ERR_INVALID, "num_present > num_keys");
+    if (!src.sparse() && d->num_present != 0) return fail(EPIK_AMD_ERR_INVALID, "num_present without keys");
+    const uint64_t n_lists = src.offsets_len() - 1;  // dense: one (possibly empty) list per code; sparse: per present code
+    if (src.offset_at(0) != 0 || src.offset_at(n_lists) != d->num_entries)
+        return fail(EPIK_AMD_ERR_INVALID, "offsets[0] != 0 or the last offset != num_entries");
     // The lists themselves: monotone offsets, lists shorter than 2^24, every branch below num_branches,
     // finite scores, and -- what the kernels' lane-parallel read-add-write of a list relies on -- no
     // branch twice in one list (the reference's lists are built per branch, one score each: main.cpp:257).
+    // Sparse form: the codes strictly ascending and inside the key space.
     std::vector<uint32_t> seen_in;  // seen_in[b] = 1 + the last list that held branch b
     try {
         seen_in.assign(d->num_branches, 0);
@@ -141,8 +145,12 @@ int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard
         return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
     }
     uint32_t list_id = 0;
-    for (uint64_t key = 0; key < d->num_keys; ++key) {
-        const uint64_t b = src.offset_at(key), e = src.offset_at(key + 1);
+    for (uint64_t i = 0; i < n_lists; ++i) {
+        if (src.sparse()) {
+            if (d->keys[i] >= d->num_keys) return fail(EPIK_AMD_ERR_INVALID, "keys[] holds a code outside the key space");
+            if (i && d->keys[i] <= d->keys[i - 1]) return fail(EPIK_AMD_ERR_INVALID, "keys[] not strictly ascending");
+        }
+        const uint64_t b = src.offset_at(i), e = src.offset_at(i + 1);
         if (e < b || e > d->num_entries) return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
         if (e - b >= (1ull << 24)) return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
         if (e == b) continue;
@@ -150,10 +158,10 @@ int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard
             std::fill(seen_in.begin(), seen_in.end(), 0u);
             list_id = 1;
         }
-        for (uint64_t i = b; i < e; ++i) {
-            const uint32_t branch = d->values[i].branch;
+        for (uint64_t j = b; j < e; ++j) {
+            const uint32_t branch = d->values[j].branch;
             if (branch >= d->num_branches) return fail(EPIK_AMD_ERR_INVALID, "posting with branch >= num_branches");
-            if (!std::isfinite(d->values[i].score))  // the kernels mark "no edge" with -inf
+            if (!std::isfinite(d->values[j].score))  // the kernels mark "no edge" with -inf
                 return fail(EPIK_AMD_ERR_INVALID, "posting with a non-finite score");
             if (seen_in[branch] == list_id)
                 return fail(EPIK_AMD_ERR_INVALID, "a posting list names the same branch twice");
@@ -204,10 +212,13 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
         std::strcmp(forced_layout, "filtered") != 0)
         return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed, paired or filtered");
 
-    for (uint64_t key = 0; key < d->num_keys; ++key) {
-        const uint64_t len = src.kept_len(key);
-        plan.kept_entries += len;
-        plan.present_codes += len != 0;
+    {
+        Cursor all(src);
+        for (uint64_t key = 0; key < d->num_keys; ++key) {
+            const uint64_t len = all.list(key);
+            plan.kept_entries += len;
+            plan.present_codes += len != 0;
+        }
     }
 
     if (team) {
@@ -231,13 +242,15 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
         if (plan.team_paired) plan.team_quarter_lines.assign((size_t)c.passes * 4, 0);
         std::vector<uint64_t> pass_lines(c.passes, 0);  // lines of each pass so far (a pass's lines are numbered from the region's start: see build)
         const uint64_t quarter = d->num_keys / 4;
+        Cursor walk(src);
         for (uint64_t key = 0; key < d->num_keys; ++key) {
             if (plan.team_paired && quarter && key % quarter == 0 && key / quarter < 4)
                 for (uint32_t p = 0; p < c.passes; ++p) plan.team_quarter_lines[(size_t)p * 4 + key / quarter] = pass_lines[p];
-            const uint64_t len = src.kept_len(key);
+            uint64_t first = 0;
+            const uint64_t len = walk.list(key, &first);
             if (len == 0) continue;
             std::fill(cnt.begin(), cnt.end(), 0u);
-            const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+            const epik_amd_pkdb_value *v = d->values + first;
             for (uint64_t i = 0; i < len; ++i) ++cnt[v[i].branch / c.slice_rows];
             for (uint32_t p = 0; p < c.passes; ++p) {
                 uint32_t bytes = 0;
@@ -279,16 +292,17 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     }
     if (!packed) {
         plan.layout = d->offset_bits == 64 ? DbLayout::kCompact64 : DbLayout::kCompact32;
-        plan.table_bytes = (d->num_keys + 1) * (d->offset_bits / 8u);
+        plan.table_bytes = (d->num_keys + 1) * (d->offset_bits / 8u);  // (the device table is dense whatever the form handed over)
         plan.posting_bytes = plan.kept_entries * 8u + 512u;
         return EPIK_AMD_OK;
     }
     plan.layout = paired ? DbLayout::kPaired : filtered ? DbLayout::kFiltered : DbLayout::kPacked;
     uint64_t lines = 0;
     const uint64_t quarter = d->num_keys / 4;
+    Cursor walk(src);
     for (uint64_t key = 0; key < d->num_keys; ++key) {
         if (paired && quarter && key % quarter == 0 && key / quarter < 4) plan.quarter_lines[key / quarter] = lines;
-        lines += packed_lines(src.kept_len(key));
+        lines += packed_lines(walk.list(key));
     }
     if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
     plan.posting_bytes = lines * 128u + 512u;
@@ -308,10 +322,11 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             const size_t entry_bytes = (size_t)team_entry_bytes(W);
             std::vector<std::vector<epik_amd_pkdb_value>> sub((size_t)W);
             // sublist lengths of a code in a pass, and the 128-byte lines its sublists take
-            auto slice_counts = [&](uint64_t key, uint32_t first_slice, uint32_t *cnt) {
+            auto slice_counts = [&](Cursor &at, uint64_t key, uint32_t first_slice, uint32_t *cnt) {
                 for (int w = 0; w < W; ++w) cnt[w] = 0;
-                const uint64_t len = src.kept_len(key);
-                const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+                uint64_t first = 0;
+                const uint64_t len = at.list(key, &first);
+                const epik_amd_pkdb_value *v = d->values + first;
                 for (uint64_t i = 0; i < len; ++i) {
                     const uint32_t slice = v[i].branch / rows;
                     if (slice >= first_slice && slice < first_slice + (uint32_t)W) ++cnt[slice - first_slice];
@@ -335,12 +350,14 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
                 const uint64_t pass_first_line = line;
                 // ---- the postings of the pass, in code order (and, unpaired, the table with them) ----------
                 RecordWriter entries(table, entry_bytes, plan.team_paired ? 0 : num_keys);
+                Cursor walk(src);
                 for (uint64_t key = 0; key < num_keys; ++key) {
                     uint8_t *entry = plan.team_paired ? nullptr : entries.next();
-                    const uint64_t len = src.kept_len(key);
+                    uint64_t first = 0;
+                    const uint64_t len = walk.list(key, &first);
                     if (len == 0) continue;
                     for (auto &s : sub) s.clear();
-                    const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+                    const epik_amd_pkdb_value *v = d->values + first;
                     for (uint64_t i = 0; i < len; ++i) {  // stable: a sublist keeps the list's order
                         const uint32_t slice = v[i].branch / rows;
                         if (slice >= first_slice && slice < first_slice + (uint32_t)W)
@@ -370,15 +387,16 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
                 RecordWriter out(table, 8 * entry_bytes, blocks);
                 uint64_t quarter_line[4], seq_line = pass_first_line;
                 for (int a = 0; a < 4; ++a) quarter_line[a] = pass_first_line + plan.team_quarter_lines[(size_t)pass * 4 + a];
+                Cursor quarter_at[4] = {Cursor(src), Cursor(src), Cursor(src), Cursor(src)}, seq_at(src);
                 for (uint64_t x = 0; x < blocks; ++x) {
                     uint8_t *block = out.next();
                     for (uint32_t a = 0; a < 4; ++a) {
-                        const uint64_t n_lines = slice_counts(a * blocks + x, first_slice, cnt.data());
+                        const uint64_t n_lines = slice_counts(quarter_at[a], a * blocks + x, first_slice, cnt.data());
                         put_entry(block + entry_bytes * a, quarter_line[a], cnt.data(), n_lines);
                         quarter_line[a] += n_lines;
                     }
                     for (uint32_t bb = 0; bb < 4; ++bb) {
-                        const uint64_t n_lines = slice_counts(x * 4 + bb, first_slice, cnt.data());
+                        const uint64_t n_lines = slice_counts(seq_at, x * 4 + bb, first_slice, cnt.data());
                         put_entry(block + entry_bytes * (4 + bb), seq_line, cnt.data(), n_lines);
                         seq_line += n_lines;
                     }
@@ -393,6 +411,7 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             const uint32_t top = plan.n_pad - 1u;
             RecordWriter offsets(table, off_bytes, num_keys + 1);
             uint64_t at = 0;
+            Cursor walk(src);
             for (uint64_t key = 0; key <= num_keys; ++key) {
                 uint8_t *o = offsets.next();
                 if (off_bytes == 8) {
@@ -402,9 +421,10 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
                     std::memcpy(o, &at32, 4);
                 }
                 if (key == num_keys) break;
-                const uint64_t len = src.kept_len(key);
+                uint64_t first = 0;
+                const uint64_t len = walk.list(key, &first);
                 if (len == 0) continue;
-                const epik_amd_pkdb_value *v = d->values + src.offset_at(key);
+                const epik_amd_pkdb_value *v = d->values + first;
                 for (uint64_t c0 = 0; c0 < len; c0 += 4096) {
                     const uint64_t n = std::min<uint64_t>(4096, len - c0);
                     uint8_t *dst = postings.reserve((size_t)n * 8u);
@@ -421,11 +441,15 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
         }
         // ---- packed lists; plain, paired or filtered table -----------------------------------------------
         const uint32_t top = plan.n_pad - 1u;
-        for (uint64_t key = 0; key < num_keys; ++key) {
-            const uint64_t len = src.kept_len(key);
-            if (len == 0) continue;
-            uint8_t *dst = postings.reserve((size_t)packed_lines(len) * 128u);
-            write_chunks(dst, d->values + src.offset_at(key), len, top);
+        {
+            Cursor walk(src);
+            for (uint64_t key = 0; key < num_keys; ++key) {
+                uint64_t first = 0;
+                const uint64_t len = walk.list(key, &first);
+                if (len == 0) continue;
+                uint8_t *dst = postings.reserve((size_t)packed_lines(len) * 128u);
+                write_chunks(dst, d->values + first, len, top);
+            }
         }
         postings.reserve(512);
         if (plan.layout == DbLayout::kPaired) {
@@ -438,16 +462,17 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             uint64_t quarter_line[4] = {plan.quarter_lines[0], plan.quarter_lines[1], plan.quarter_lines[2],
                                         plan.quarter_lines[3]};
             uint64_t seq_line = 0;
+            Cursor quarter_at[4] = {Cursor(src), Cursor(src), Cursor(src), Cursor(src)}, seq_at(src);
             for (uint64_t x = 0; x < blocks; ++x) {
                 uint8_t *block = out.next();
                 for (uint32_t a = 0; a < 4; ++a) {
-                    const uint64_t len = src.kept_len(a * blocks + x);
+                    const uint64_t len = quarter_at[a].list(a * blocks + x);
                     put_u32(block + 8 * a, (uint32_t)len);
                     put_u32(block + 8 * a + 4, (uint32_t)quarter_line[a]);
                     quarter_line[a] += packed_lines(len);
                 }
                 for (uint32_t b = 0; b < 4; ++b) {
-                    const uint64_t len = src.kept_len(x * 4 + b);
+                    const uint64_t len = seq_at.list(x * 4 + b);
                     put_u32(block + 32 + 8 * b, (uint32_t)len);
                     put_u32(block + 32 + 8 * b + 4, (uint32_t)seq_line);
                     seq_line += packed_lines(len);
@@ -457,9 +482,10 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
         } else {
             RecordWriter out(table, 8, num_keys);
             uint64_t line = 0;
+            Cursor walk(src);
             for (uint64_t key = 0; key < num_keys; ++key) {
                 uint8_t *e = out.next();
-                const uint64_t len = src.kept_len(key);
+                const uint64_t len = walk.list(key);
                 put_u32(e, (uint32_t)len);
                 put_u32(e + 4, (uint32_t)line);
                 line += packed_lines(len);
@@ -474,12 +500,14 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             // filter[X], X a (k-1)-mer: bit a <=> code a.X has a list, bit sigma + b <=> code X.b has one
             const uint64_t sigma = d->alphabet_size, blocks = num_keys / sigma;  // sigma^(k-1)
             RecordWriter out(*filter, 8, blocks);
+            std::vector<Cursor> first_at(sigma, Cursor(src));  // a.X, a fixed, X rising: one walk per first letter
+            Cursor seq_at(src);                                 // X.b: the key space front to back
             for (uint64_t x = 0; x < blocks; ++x) {
                 uint64_t word = 0;
                 for (uint64_t a = 0; a < sigma; ++a)
-                    if (src.kept_len(a * blocks + x) != 0) word |= 1ull << a;
+                    if (first_at[a].list(a * blocks + x) != 0) word |= 1ull << a;
                 for (uint64_t b = 0; b < sigma; ++b)
-                    if (src.kept_len(x * sigma + b) != 0) word |= 1ull << (sigma + b);
+                    if (seq_at.list(x * sigma + b) != 0) word |= 1ull << (sigma + b);
                 std::memcpy(out.next(), &word, 8);
             }
         }

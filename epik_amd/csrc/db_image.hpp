@@ -26,15 +26,65 @@ namespace epik_amd::image {
 struct Source {
     const epik_amd_placer_desc *d = nullptr;
     uint32_t shard_index = 0, shard_count = 1;
-    uint64_t offset_at(uint64_t key) const
+    bool sparse() const { return d->keys != nullptr; }
+    // entry i of offsets[] (dense form: i = a k-mer code; sparse form: i = a position in keys[])
+    uint64_t offset_at(uint64_t i) const
     {
-        return d->offset_bits == 64 ? static_cast<const uint64_t *>(d->offsets)[key]
-                                    : static_cast<const uint32_t *>(d->offsets)[key];
+        return d->offset_bits == 64 ? static_cast<const uint64_t *>(d->offsets)[i]
+                                    : static_cast<const uint32_t *>(d->offsets)[i];
     }
-    uint64_t kept_len(uint64_t key) const
+    uint64_t offsets_len() const { return (sparse() ? d->num_present : d->num_keys) + 1; }
+    bool kept(uint64_t key) const { return shard_count == 1 || key % shard_count == shard_index; }
+};
+
+// The lists of the database by k-mer code, for walks that ask for rising codes (every loop of the image
+// builder does: the key space front to back, or a few such walks side by side for the tables keyed by a
+// (k-1)-mer).  Dense form: an array lookup.  Sparse form: a position in keys[] that moves forward with the
+// codes asked for -- amortised O(1); a code below the last one asked for is found by bisection.
+class Cursor {
+public:
+    explicit Cursor(const Source &src) : _s(src) {}
+    // the length of the list this placer keeps for `key` (0: none, or another shard's); *first = where it
+    // begins in values[]
+    uint64_t list(uint64_t key, uint64_t *first = nullptr)
     {
-        return (shard_count == 1 || key % shard_count == shard_index) ? offset_at(key + 1) - offset_at(key) : 0;
+        if (!_s.kept(key)) return 0;
+        if (!_s.sparse()) {
+            const uint64_t b = _s.offset_at(key);
+            if (first) *first = b;
+            return _s.offset_at(key + 1) - b;
+        }
+        const uint32_t *keys = _s.d->keys;
+        const uint64_t n = _s.d->num_present;
+        if (_pos > 0 && _pos <= n && keys[_pos - 1] >= key) {  // backwards: bisect
+            uint64_t lo = 0, hi = _pos;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) / 2;
+                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            _pos = lo;
+        }
+        // forward: gallop, then bisect inside the last step
+        if (_pos < n && keys[_pos] < key) {
+            uint64_t step = 1, lo = _pos;
+            while (lo + step < n && keys[lo + step] < key) lo += step, step *= 2;
+            uint64_t hi = lo + step < n ? lo + step : n;  // keys[hi] >= key or hi == n; keys[lo] < key
+            ++lo;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) / 2;
+                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            _pos = lo;
+        }
+        if (_pos >= n || keys[_pos] != key) return 0;
+        const uint64_t b = _s.offset_at(_pos);
+        if (first) *first = b;
+        return _s.offset_at(_pos + 1) - b;
     }
+
+private:
+    const Source &_s;
+    uint64_t _pos = 0;  // sparse form: the first position of keys[] not below the last code asked for
 };
 
 // What create() decided and how large the parts are.

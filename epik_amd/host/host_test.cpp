@@ -138,14 +138,26 @@ int main(int argc, char** argv)
         }
         auto db = load(path, 1.0f, 1.0f);  // log10((1/4)^2) = -1.20: everything passes
         CHECK(db.kmer_size() == 2 && db.num_keys() == 16 && db.get_num_entries_loaded() == 5);
-        CHECK(db.offsets()[1] == 0 && db.offsets()[2] == 2 && db.offsets()[6] == 4 && db.offsets()[16] == 5);
-        CHECK(db.values()[db.offsets()[5]].branch == 0 && db.values()[db.offsets()[9]].branch == 4);
+        // the sparse form: the present codes ascending, a list each
+        CHECK(db.keys().size() == 3 && db.keys()[0] == 1 && db.keys()[1] == 5 && db.keys()[2] == 9);
+        CHECK(db.offsets().size() == 4 && db.offsets()[1] == 2 && db.offsets()[2] == 4 && db.offsets()[3] == 5);
+        CHECK(db.search(5).second == 2 && db.search(5).first[0].branch == 0 && db.search(9).first[0].branch == 4);
+        CHECK(db.search(2).first == nullptr && db.search(15).second == 0);
         db = load(path, 1.0f, 1.5f);   // log10((1.5/4)^2) = -0.85: the -1.0 posting goes
         CHECK(db.get_num_entries_loaded() == 4 && db.get_num_entries_total() == 5 && db.omega() == 1.5f);
         db = load(path, 0.5f, 1.0f);   // best half of the k-mers: ceil(1.5) = 2 records
         CHECK(db.get_num_entries_loaded() == 4);
         db = load(path, 1.0f, 1.0f, 3);  // --max-ram: stops in front of the k-mer that does not fit
         CHECK(db.get_num_entries_loaded() == 2);
+        // --db-shard: the codes with code % 2 == 1 (1, 5, 9: all of them) / == 0 (none); % 4: 1, 5, 9 -> shard 1
+        db = load(path, 1.0f, 1.0f, std::numeric_limits<size_t>::max(), 1, 2);
+        CHECK(db.get_num_entries_loaded() == 5 && db.shard_index() == 1 && db.shard_count() == 2 && db.num_keys() == 16);
+        db = load(path, 1.0f, 1.0f, std::numeric_limits<size_t>::max(), 0, 2);
+        CHECK(db.get_num_entries_loaded() == 0 && db.keys().empty() && db.offsets().size() == 1);
+        db = load(path, 1.0f, 1.0f, std::numeric_limits<size_t>::max(), 1, 4);
+        CHECK(db.keys().size() == 3);
+        db = load(path, 1.0f, 1.0f, std::numeric_limits<size_t>::max(), 2, 4);
+        CHECK(db.keys().empty());
         bool threw = false;
         try { load(tmp + "/host_test.fasta"); } catch (const std::runtime_error& e) {
             threw = std::string(e.what()).find("EPIKAMD1") != std::string::npos;

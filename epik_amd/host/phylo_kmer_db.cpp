@@ -3,8 +3,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <fstream>
+#include <cstddef>
 #include <stdexcept>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace epik_amd {
 
@@ -55,49 +60,111 @@ std::vector<uint32_t> char_class_table(const std::string& sequence_type)
 
 namespace {
 
-template <typename T>
-T read_pod(std::istream& in)
-{
-    T v{};
-    in.read(reinterpret_cast<char*>(&v), sizeof(T));
-    if (!in) throw std::runtime_error("Unexpected end of the database file");
-    return v;
-}
+// a read-only mapping of a whole file
+class mapped_file {
+public:
+    explicit mapped_file(const std::string& filename)
+    {
+        _fd = ::open(filename.c_str(), O_RDONLY);
+        if (_fd < 0) throw std::runtime_error("Cannot open the database: " + filename);
+        struct stat st;
+        if (::fstat(_fd, &st) != 0 || st.st_size < 0) {
+            ::close(_fd);
+            throw std::runtime_error("Cannot stat the database: " + filename);
+        }
+        _size = (size_t)st.st_size;
+        if (_size) {
+            void* p = ::mmap(nullptr, _size, PROT_READ, MAP_PRIVATE, _fd, 0);
+            if (p == MAP_FAILED) {
+                ::close(_fd);
+                throw std::runtime_error("Cannot map the database: " + filename);
+            }
+            _data = static_cast<const unsigned char*>(p);
+            (void)::madvise(p, _size, MADV_SEQUENTIAL);
+        }
+    }
+    ~mapped_file()
+    {
+        if (_data) ::munmap(const_cast<unsigned char*>(_data), _size);
+        if (_fd >= 0) ::close(_fd);
+    }
+    mapped_file(const mapped_file&) = delete;
+    mapped_file& operator=(const mapped_file&) = delete;
+    const unsigned char* data() const { return _data; }
+    size_t size() const { return _size; }
+
+private:
+    int _fd = -1;
+    const unsigned char* _data = nullptr;
+    size_t _size = 0;
+};
+
+// sequential reads out of the mapping, bounds-checked
+struct cursor {
+    const unsigned char* at;
+    const unsigned char* end;
+    template <typename T>
+    T pod()
+    {
+        if ((size_t)(end - at) < sizeof(T)) throw std::runtime_error("Unexpected end of the database file");
+        T v;
+        std::memcpy(&v, at, sizeof(T));
+        at += sizeof(T);
+        return v;
+    }
+    const unsigned char* bytes(size_t n, const char* what)
+    {
+        if ((size_t)(end - at) < n) throw std::runtime_error(std::string("Unexpected end of the database file (") + what + ")");
+        const unsigned char* p = at;
+        at += n;
+        return p;
+    }
+};
 
 struct kmer_record {
     uint32_t key;
-    uint64_t first;  // into the temporary posting array
+    uint32_t kept;               // postings of the record at or above the threshold
+    const unsigned char* first;  // its postings in the mapping (all `n` of them)
     uint32_t n;
 };
 
 }  // namespace
 
-phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t max_entries)
+std::pair<const pkdb_value*, size_t> phylo_kmer_db::search(uint32_t key) const noexcept
 {
-    std::ifstream in(filename, std::ios::binary);
-    if (!in) throw std::runtime_error("Cannot open the database: " + filename);
-    char magic[8];
-    in.read(magic, 8);
-    if (!in) throw std::runtime_error("The database file is too short: " + filename);
-    if (std::memcmp(magic, "EPIKAMD1", 8) != 0) {
+    const auto it = std::lower_bound(_keys.begin(), _keys.end(), key);
+    if (it == _keys.end() || *it != key) return {nullptr, 0};
+    const size_t i = (size_t)(it - _keys.begin());
+    return {_values.data() + _offsets[i], (size_t)(_offsets[i + 1] - _offsets[i])};
+}
+
+phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t max_entries, uint32_t shard_index,
+                   uint32_t shard_count)
+{
+    if (shard_count == 0 || shard_index >= shard_count) throw std::runtime_error("shard_index must be below shard_count");
+    const mapped_file file(filename);
+    cursor in{file.data(), file.data() + file.size()};
+    if (file.size() < 8) throw std::runtime_error("The database file is too short: " + filename);
+    if (std::memcmp(in.bytes(8, "magic"), "EPIKAMD1", 8) != 0) {
         // Boost archives start with "22 serialization::archive"; zlib streams with 0x78
         throw std::runtime_error(
             "Unsupported database container: " + filename +
             " is not an EPIKAMD1 file.  IPK's .ipk files (Boost.Serialization inside i2l) cannot be "
-            "read by this build; convert the database with epik_amd/dbfile.py");
+            "read by this build; convert the database with tools/ipk2ekdb.cpp (needs i2l) or epik_amd/dbfile.py");
     }
     phylo_kmer_db db;
-    db._version = read_pod<uint32_t>(in);
-    const uint32_t seq_type = read_pod<uint32_t>(in);
+    db._shard_index = shard_index;
+    db._shard_count = shard_count;
+    db._version = in.pod<uint32_t>();
+    const uint32_t seq_type = in.pod<uint32_t>();
     db._sequence_type = seq_type == 0 ? "DNA" : "Proteins";
-    db._kmer_size = read_pod<uint32_t>(in);
-    const float built_omega = read_pod<float>(in);
-    const uint64_t num_kmers = read_pod<uint64_t>(in);
-    db._num_entries_total = (size_t)read_pod<uint64_t>(in);
-    const uint64_t newick_len = read_pod<uint64_t>(in);
-    db._tree.resize(newick_len);
-    in.read(db._tree.data(), (std::streamsize)newick_len);
-    if (!in) throw std::runtime_error("Unexpected end of the database file (tree)");
+    db._kmer_size = in.pod<uint32_t>();
+    const float built_omega = in.pod<float>();
+    const uint64_t num_kmers = in.pod<uint64_t>();
+    db._num_entries_total = (size_t)in.pod<uint64_t>();
+    const uint64_t newick_len = in.pod<uint64_t>();
+    const unsigned char* newick = in.bytes(newick_len, "tree");
+    db._tree.assign(reinterpret_cast<const char*>(newick), newick_len);
 
     const unsigned int sigma = alphabet_size(db._sequence_type);
     // The user's omega replaces the stored one when it is stricter (README.md:125)
@@ -109,40 +176,48 @@ phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t ma
         num_keys *= sigma;
         if (num_keys > 0xffffffffull) throw std::runtime_error("alphabet_size^k exceeds 2^32 k-mer codes");
     }
+    db._num_keys = num_keys;
     const uint64_t kmers_to_load = (uint64_t)std::ceil((double)mu * (double)num_kmers);
+    // ---- first walk: which records stay, and how many of their postings (file order: mu and --max-ram cut it)
     std::vector<kmer_record> records;
-    std::vector<pkdb_value> tmp;
-    std::vector<pkdb_value> buf;
+    uint64_t kept_total = 0;
     for (uint64_t r = 0; r < num_kmers && r < kmers_to_load; ++r) {
-        const uint32_t key = read_pod<uint32_t>(in);
-        const uint32_t n = read_pod<uint32_t>(in);
+        const uint32_t key = in.pod<uint32_t>();
+        const uint32_t n = in.pod<uint32_t>();
         if (key >= num_keys) throw std::runtime_error("k-mer code out of range in the database");
-        buf.resize(n);
-        in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(n * sizeof(pkdb_value)));
-        if (!in) throw std::runtime_error("Unexpected end of the database file (postings)");
-        kmer_record rec{key, tmp.size(), 0};
-        for (const auto& v : buf)
-            if (v.score >= log_thr) {
-                tmp.push_back(v);
-                ++rec.n;
-            }
-        if (tmp.size() > max_entries) {  // --max-ram: stop in front of the k-mer that does not fit
-            tmp.resize(rec.first);
-            break;
+        const unsigned char* first = in.bytes((size_t)n * sizeof(pkdb_value), "postings");
+        if (key % shard_count != shard_index) continue;
+        uint32_t kept = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            float score;
+            std::memcpy(&score, first + (size_t)j * sizeof(pkdb_value) + offsetof(pkdb_value, score), sizeof score);
+            kept += score >= log_thr;
         }
-        if (rec.n) records.push_back(rec);
+        if (kept_total + kept > max_entries) break;  // --max-ram: stop in front of the k-mer that does not fit
+        kept_total += kept;
+        if (kept) records.push_back(kmer_record{key, kept, first, n});
     }
-    // CSR by k-mer code
-    db._offsets.assign(num_keys + 1, 0);
-    for (const auto& rec : records) {
-        if (db._offsets[rec.key + 1] != 0) throw std::runtime_error("duplicate k-mer in the database");
-        db._offsets[rec.key + 1] = rec.n;
+    // ---- by k-mer code: the sparse CSR the C ABI takes
+    std::sort(records.begin(), records.end(), [](const kmer_record& a, const kmer_record& b) { return a.key < b.key; });
+    db._keys.resize(records.size());
+    db._offsets.resize(records.size() + 1);
+    db._offsets[0] = 0;
+    for (size_t i = 0; i < records.size(); ++i) {
+        if (i && records[i].key == records[i - 1].key) throw std::runtime_error("duplicate k-mer in the database");
+        db._keys[i] = records[i].key;
+        db._offsets[i + 1] = db._offsets[i] + records[i].kept;
     }
-    for (uint64_t i = 0; i < num_keys; ++i) db._offsets[i + 1] += db._offsets[i];
-    db._values.resize(tmp.size());
-    for (const auto& rec : records)
-        std::copy(tmp.begin() + (std::ptrdiff_t)rec.first, tmp.begin() + (std::ptrdiff_t)(rec.first + rec.n),
-                  db._values.begin() + (std::ptrdiff_t)db._offsets[rec.key]);
+    // ---- second walk: every kept posting once, straight to its place
+    db._values.resize(kept_total);
+    for (size_t i = 0; i < records.size(); ++i) {
+        pkdb_value* dst = db._values.data() + db._offsets[i];
+        const kmer_record& rec = records[i];
+        for (uint32_t j = 0; j < rec.n; ++j) {
+            pkdb_value v;
+            std::memcpy(&v, rec.first + (size_t)j * sizeof(pkdb_value), sizeof v);
+            if (v.score >= log_thr) *dst++ = v;
+        }
+    }
     db._tree_index = io::parse_newick(db._tree).tree_index();
     return db;
 }

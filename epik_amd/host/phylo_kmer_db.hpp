@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "epik_amd.h"
@@ -58,10 +59,18 @@ public:
     size_t get_num_entries_total() const noexcept { return _num_entries_total; }
     const std::vector<tree_index_entry>& tree_index() const noexcept { return _tree_index; }
 
-    // CSR view handed to the C ABI: key (dense k-mer code) -> values[offsets[key] .. offsets[key+1])
-    uint64_t num_keys() const noexcept { return _offsets.empty() ? 0 : _offsets.size() - 1; }
+    // The lists as handed to the C ABI, in its sparse form (memory per PRESENT k-mer, as the reference's hash
+    // map): keys() = the codes that have a list, ascending; the list of keys()[i] =
+    // values[offsets()[i] .. offsets()[i + 1]).
+    uint64_t num_keys() const noexcept { return _num_keys; }  // alphabet_size ^ k: the size of the key space
+    const std::vector<uint32_t>& keys() const noexcept { return _keys; }
     const std::vector<uint64_t>& offsets() const noexcept { return _offsets; }
     const std::vector<pkdb_value>& values() const noexcept { return _values; }
+    /// phylo_kmer_db::search (place.cpp:300): the list of a k-mer code, {nullptr, 0} when it has none
+    std::pair<const pkdb_value*, size_t> search(uint32_t key) const noexcept;
+    // which part of the database this object holds (k-mer-space shard: the codes with code % count == index)
+    uint32_t shard_index() const noexcept { return _shard_index; }
+    uint32_t shard_count() const noexcept { return _shard_count; }
 
     size_t _kmer_size = 0;
     float _omega = 0.0f;
@@ -70,14 +79,24 @@ public:
     unsigned int _version = 0;
     size_t _num_entries_total = 0;
     std::vector<tree_index_entry> _tree_index;
+    uint64_t _num_keys = 0;
+    uint32_t _shard_index = 0, _shard_count = 1;
+    std::vector<uint32_t> _keys;
     std::vector<uint64_t> _offsets;
     std::vector<pkdb_value> _values;
 };
 
 /// Loads at most `max_entries` postings of the best `mu` fraction of k-mers, dropping
 /// postings under the threshold of `omega`.  Throws std::runtime_error (caught main.cpp:384).
+/// shard_index / shard_count (--db-shard): only the k-mers with code % shard_count == shard_index are kept --
+/// a process (or device thread) of a k-mer-space-sharded run never holds the others; `mu` and `max_entries`
+/// cut the file's order as before, `max_entries` counting what THIS shard keeps.
+/// The file is mapped and walked twice (count, then place): every kept posting is written once, straight to
+/// its final place; nothing but the postings, 12 bytes per present k-mer and a transient 24-byte record
+/// per k-mer of the shard is allocated.
 phylo_kmer_db load(const std::string& filename, float mu = 1.0f, float omega = 1.5f,
-                   size_t max_entries = std::numeric_limits<size_t>::max());
+                   size_t max_entries = std::numeric_limits<size_t>::max(), uint32_t shard_index = 0,
+                   uint32_t shard_count = 1);
 
 }  // namespace epik_amd
 #endif

@@ -46,7 +46,9 @@ placer::placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t 
     desc.log_threshold = _log_threshold;
     desc.num_keys = db.num_keys();
     desc.num_entries = db.values().size();
-    desc.offsets = db.offsets().data();
+    desc.offsets = db.offsets().data();  // the sparse form: memory per present k-mer (ABI 3)
+    desc.keys = db.keys().data();
+    desc.num_present = db.keys().size();
     desc.values = db.values().data();
     desc.char_class = char_class.data();
     if (devices.empty()) devices.push_back(0);

@@ -17,6 +17,7 @@ The heavy lifting is the HIP kernel; nothing here computes a score.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Iterable, List, Sequence, Tuple
 
@@ -67,13 +68,26 @@ def pendant_lengths(branch_length: np.ndarray, subtree_num_nodes: np.ndarray,
 
 
 def make_desc(offsets, values, *, states: str, kmer_size: int, num_branches: int, threshold, log_threshold=None,
-              keep_at_most: int = 7, keep_factor: float = 0.01, device: int = 0, char_class=None):
+              keep_at_most: int = 7, keep_factor: float = 0.01, device: int = 0, char_class=None, keys=None,
+              sparse: bool = False):
     """`epik_amd_placer_desc` over host arrays (uint32 / uint64 offsets are handed over as they are, no
-    copy).  Returns (desc, the arrays it points into -- keep them alive as long as the descriptor)."""
+    copy).  `keys` (ascending uint32 codes that have a list): the sparse form, `offsets` then has
+    len(keys) + 1 entries; `sparse=True` turns dense offsets into that form first (EPIK_AMD_SPARSE_DESC=1
+    does it for every descriptor: the GPU tests run on both forms).  Returns (desc, the arrays it points
+    into -- keep them alive as long as the descriptor)."""
     sigma = alphabet.alphabet_size(states)
     if log_threshold is None:
         log_threshold = alphabet.log_threshold(np.float32(threshold))
     offsets = np.asarray(offsets)
+    num_keys = sigma ** int(kmer_size)
+    if keys is None and (sparse or os.environ.get("EPIK_AMD_SPARSE_DESC") == "1"):
+        lens = np.diff(offsets.astype(np.int64))
+        present = np.nonzero(lens)[0]
+        keys = present.astype(np.uint32)
+        offsets = np.concatenate([[0], np.cumsum(lens[present])]).astype(np.uint64)
+    if keys is not None:
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        assert offsets.shape[0] == keys.shape[0] + 1
     num_entries = int(offsets[-1])
     if offsets.dtype == np.uint64 and offsets.flags.c_contiguous:
         off, bits = offsets, 64
@@ -90,10 +104,11 @@ def make_desc(offsets, values, *, states: str, kmer_size: int, num_branches: int
         abi_version=capi.ABI_VERSION, kmer_size=int(kmer_size), alphabet_size=sigma,
         num_branches=int(num_branches), keep_at_most=int(keep_at_most), offset_bits=bits,
         keep_factor=float(keep_factor), threshold=float(threshold),
-        log_threshold=float(log_threshold), num_keys=int(off.shape[0] - 1),
+        log_threshold=float(log_threshold), num_keys=int(num_keys),
         num_entries=num_entries, offsets=off.ctypes.data, values=vals.ctypes.data,
-        char_class=cls.ctypes.data, device=int(device), reserved=0)
-    return desc, (off, vals, cls)
+        char_class=cls.ctypes.data, device=int(device), reserved=0,
+        keys=keys.ctypes.data if keys is not None else None, num_present=int(keys.shape[0]) if keys is not None else 0)
+    return desc, (off, vals, cls, keys)
 
 
 def plan(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 288 << 30, **kw) -> capi.Plan:
@@ -262,6 +277,23 @@ class Placer:
         capi.check(self._lib.epik_amd_placer_finish_lists_device(
             self._handle, d_seq_offsets, int(n), g, entries, index, d_amb_slot or None, d_amb_avg or None,
             d_rows, d_n_rows, d_kmer_counts or None, stream or None))
+
+    @staticmethod
+    def place_sharded(placers, seqs: np.ndarray, seq_offsets: np.ndarray):
+        """`epik_amd_placer_place_sharded`: host reads placed on `placers`, handle g holding shard g of
+        len(placers) of one database (any devices).  Returns like `place_packed`."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        n = int(seq_offsets.shape[0] - 1)
+        keep = placers[0].keep_at_most
+        rows = np.zeros((n, keep), dtype=capi.PLACEMENT)
+        n_rows = np.zeros(n, dtype=np.uint32)
+        counts = np.zeros((n, keep), dtype=np.uint32)
+        handles = (ctypes.c_void_p * len(placers))(*[p._handle for p in placers])
+        capi.check(placers[0]._lib.epik_amd_placer_place_sharded(
+            handles, len(placers), seqs.ctypes.data, seq_offsets.ctypes.data, n, rows.ctypes.data, n_rows.ctypes.data,
+            counts.ctypes.data))
+        return rows, n_rows, counts
 
     def last_path(self) -> int:
         """Which kernels the last launch ran: capi.PATH_WAVE / PATH_TEAM_ONE_KERNEL / PATH_TEAM_STREAMED."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EPIK_AMD_ABI_VERSION 2
+#define EPIK_AMD_ABI_VERSION 3
 
 enum epik_amd_status {
     EPIK_AMD_OK = 0,
@@ -61,11 +61,17 @@ typedef struct {
  * (k-mer code -> posting list) replacing the i2l hash map behind
  * `phylo_kmer_db::search` (place.cpp:300,311).
  *
- * Key space: dense.  The code of a k-mer is the base-`alphabet_size` number of
- * its k state codes, first character most significant; offsets[code] ..
- * offsets[code+1] delimit its postings in values[].  num_keys must equal
- * alphabet_size^kmer_size.  All pointers are HOST pointers; create() copies
- * them to the device, the caller may free them afterwards.
+ * The code of a k-mer is the base-`alphabet_size` number of its k state codes, first
+ * character most significant; num_keys must equal alphabet_size^kmer_size.  Two forms:
+ *   dense  (keys == NULL): offsets[code] .. offsets[code+1] delimit the postings of `code` in
+ *          values[]; offsets has num_keys + 1 entries -- 8 bytes per POSSIBLE k-mer, 10 GB for
+ *          amino k = 7 whatever the database holds;
+ *   sparse (keys != NULL, ABI 3): keys[num_present] are the codes that have a list, strictly
+ *          ascending, and offsets[i] .. offsets[i+1] delimit the postings of keys[i]; offsets has
+ *          num_present + 1 entries -- memory per PRESENT key, as the hash map behind
+ *          phylo_kmer_db::search (place.cpp:300,311) has it.
+ * All pointers are HOST pointers; create() streams them to the device (it keeps no copy and
+ * needs no array of its own per code), the caller may free them afterwards.
  */
 typedef struct {
     uint32_t abi_version;    /* EPIK_AMD_ABI_VERSION */
@@ -78,14 +84,16 @@ typedef struct {
     float threshold;         /* i2l::score_threshold(omega, k)       place.cpp:87 */
     float log_threshold;     /* std::log10(threshold), as float      place.cpp:88 */
     uint64_t num_keys;       /* alphabet_size ^ kmer_size */
-    uint64_t num_entries;    /* offsets[num_keys] = db.get_num_entries_loaded() */
-    const void *offsets;     /* uint32_t/uint64_t [num_keys + 1] */
+    uint64_t num_entries;    /* the last offset = db.get_num_entries_loaded() */
+    const void *offsets;     /* uint32_t/uint64_t [num_keys + 1] (dense) or [num_present + 1] (sparse) */
     const epik_amd_pkdb_value *values; /* [num_entries]; branches distinct within one list */
     const uint32_t *char_class; /* [256]: bit s set <=> the character may be state s;
                                    popcount 1 plain, >1 ambiguous, 0 invalid
                                    (i2l::to_kmers<one_ambiguity_policy>, place.cpp:294) */
     int32_t device;          /* HIP device ordinal */
     uint32_t reserved;
+    const uint32_t *keys;    /* NULL: dense form; else [num_present] ascending codes (sparse form) */
+    uint64_t num_present;    /* sparse form: number of codes that have a list */
 } epik_amd_placer_desc;
 
 typedef struct epik_amd_placer epik_amd_placer;
@@ -273,6 +281,21 @@ int epik_amd_placer_finish_lists_device(epik_amd_placer *p, const void *d_seq_of
                                         const void *const *d_entries, const void *const *d_index,
                                         const void *d_amb_slot, const void *d_amb_avg, void *d_rows, void *d_n_rows,
                                         void *d_kmer_counts, void *stream);
+
+/*
+ * The whole of it for a caller that drives all the devices from one process (epik-dna --db-shard): places n
+ * HOST reads on `n_shards` handles that together hold one database -- handle g created with shard g of n_shards
+ * (create() on a descriptor of its codes, or create_sharded()), on any devices, several on one if need be.
+ * Replaces the OpenMP loop of epik::placer::place (place.cpp:218-268) as epik_amd_placer_place does, same
+ * arguments and results.  Inside: chunks of the batch; every handle accumulates the partial lists of a chunk on
+ * its device, part r of each goes to the device of handle r with one peer copy per pair (its own xGMI link),
+ * handle r finishes its reads; the copies of a chunk run under the kernels of the next.  Reads with ambiguous
+ * characters follow the first-key rule over all shards.  Large trees only (partial lists): a database that needs
+ * several devices has one.  Synchronous; the handles must not be used by another thread meanwhile.
+ */
+int epik_amd_placer_place_sharded(epik_amd_placer *const *shards, uint32_t n_shards, const char *seqs,
+                                  const uint64_t *seq_offsets, uint64_t n, epik_amd_placement *rows,
+                                  uint32_t *n_rows, uint32_t *kmer_counts);
 
 /* Which kernels the last launch of this handle ran (reports; a large-tree handle falls back from the three-kernel
  * placement to the one-kernel one when the device has no room for the scratch of a launch). */

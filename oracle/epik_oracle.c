@@ -445,6 +445,12 @@ int orc_place_batch(const orc_db *db, const char *seqs, const uint64_t *seq_offs
             const int r = orc_place_read(db, s, seqs + b, (size_t)(e - b), rows + i * db->keep_at_most,
                                          counts ? counts + i * db->keep_at_most : NULL);
             n_rows[i] = r > 0 ? (uint32_t)r : 0;
+            if (r == -2) { /* the scratch could not grow: the call fails, it does not report "no placement" */
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+                failed = 1;
+            }
         }
         orc_scratch_destroy(s);
     }
@@ -518,7 +524,7 @@ int orc_place_batched(const orc_db *db, const char *seqs, const uint64_t *seq_of
             const int r = orc_place_read(db, s, seqs + seq_offsets[i], (size_t)(seq_offsets[i + 1] - seq_offsets[i]),
                                          rows + i * keep, counts ? counts + i * keep : NULL);
             n_rows[i] = r > 0 ? (uint32_t)r : 0;
-            if (r < 0) batch_failed |= 1;
+            if (r == -2) batch_failed |= 1; /* (-1: a read shorter than k, no placement) */
         }
         if (batch_failed) {
             failed = 1;

@@ -31,10 +31,11 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert capi.PLACEMENT.itemsize == 16
     assert capi.PKDB_VALUE.itemsize == 8
-    assert ctypes.sizeof(capi.PlacerDesc) == 88
+    assert ctypes.sizeof(capi.PlacerDesc) == 104
     assert capi.PlacerDesc.keep_factor.offset == 24
     assert capi.PlacerDesc.offsets.offset == 56
     assert capi.PlacerDesc.device.offset == 80
+    assert capi.PlacerDesc.keys.offset == 88 and capi.PlacerDesc.num_present.offset == 96
 
 
 def _desc(db, **over):

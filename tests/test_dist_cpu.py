@@ -59,7 +59,8 @@ def test_owner_bounds_are_equal_slices():
 @pytest.mark.parametrize("world", [2, 3])
 def test_gloo_kmer_sharded_placement_matches_oracle(world, oracle_lib):
     """The exchange step of the k-mer-space shard: all-to-all of the per-read branch vectors +
-    sum in rank order, numpy engine in place of the two kernel halves."""
+    sum in rank order, numpy engine in place of the two kernel halves; then the same batch in three pieces
+    with partial lists (epik_amd.dist.place_kmer_sharded_lists: variable-size all-to-all, index, overflow)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker_kmer.py")]
@@ -67,3 +68,6 @@ def test_gloo_kmer_sharded_placement_matches_oracle(world, oracle_lib):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert f"kmer-shard ok: world={world}" in out.stdout
+    # ... and with partial lists: three batches through the pipelined exchange, an overflow round among them
+    for b in range(3):
+        assert f"kmer-shard lists batch {b} ok: world={world}" in out.stdout, out.stdout[-2000:]

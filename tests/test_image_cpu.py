@@ -197,3 +197,62 @@ def test_build_streams_without_a_host_copy():
     assert plan.posting_bytes > 200 << 20
     grown = peak[0] - before
     assert grown < 32 << 20, f"the image build grew the process by {grown >> 20} MiB"
+
+
+@pytest.mark.parametrize("kernel,layout,shard", [
+    ("wave", "packed", (0, 1)), ("wave", "paired", (1, 3)), ("wave", "compact", (0, 1)), ("wave", "compact", (2, 3)),
+    ("team4", None, (0, 1)), ("team8x2", None, (1, 2)), ("team4x3", None, (0, 1))])
+def test_sparse_descriptor_builds_the_same_image(db, kernel, layout, shard, monkeypatch):
+    """ABI 3: keys[num_present] + offsets[num_present + 1] instead of an offset per possible k-mer -- the same
+    device image byte for byte, whole or as a k-mer-space shard."""
+    monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+    if layout:
+        monkeypatch.setenv("EPIK_AMD_LAYOUT", layout)
+    else:
+        monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
+    dense = eplacer.build_image(db, shard_index=shard[0], shard_count=shard[1])
+    sparse = eplacer.build_image(db, shard_index=shard[0], shard_count=shard[1], sparse=True)
+    for name in ("kernel", "layout", "table_bytes", "filter_bytes", "posting_bytes", "kept_entries"):
+        assert getattr(dense[0], name) == getattr(sparse[0], name), name
+    for a, b in zip(dense[1:], sparse[1:]):
+        assert a.tobytes() == b.tobytes()
+
+
+def test_sparse_descriptor_filtered_layout(amino_db, monkeypatch):
+    monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+    monkeypatch.setenv("EPIK_AMD_LAYOUT", "filtered")
+    for shard in ((0, 1), (1, 2)):
+        dense = eplacer.build_image(amino_db, shard_index=shard[0], shard_count=shard[1])
+        sparse = eplacer.build_image(amino_db, shard_index=shard[0], shard_count=shard[1], sparse=True)
+        assert dense[0].layout == 4 and dense[0].filter_bytes == sparse[0].filter_bytes
+        for a, b in zip(dense[1:], sparse[1:]):
+            assert a.tobytes() == b.tobytes()
+
+
+def test_sparse_descriptor_is_validated(db):
+    import ctypes
+    from epik_amd import capi
+    lens = np.diff(db.offsets.astype(np.int64))
+    keys = np.nonzero(lens)[0].astype(np.uint32)
+    offsets = np.concatenate([[0], np.cumsum(lens[keys])]).astype(np.uint64)
+    common = dict(states=db.states, kmer_size=db.kmer_size, num_branches=db.num_branches, threshold=db.threshold)
+
+    def plan_rc(k, o):
+        desc, keep = eplacer.make_desc(o, db.values, keys=k, **common)
+        rc = capi.load().epik_amd_placer_plan(ctypes.byref(desc), 0, 1, 1 << 34, ctypes.byref(capi.Plan()))
+        del keep
+        return rc
+
+    assert plan_rc(keys, offsets) == capi.OK
+    swapped = keys.copy()
+    swapped[[3, 4]] = swapped[[4, 3]]
+    assert plan_rc(swapped, offsets) == capi.ERR_INVALID          # not ascending
+    twice = keys.copy()
+    twice[5] = twice[4]
+    assert plan_rc(twice, offsets) == capi.ERR_INVALID            # a code twice
+    outside = keys.copy()
+    outside[-1] = db.num_keys
+    assert plan_rc(outside, offsets) == capi.ERR_INVALID          # outside the key space
+    bent = offsets.copy()
+    bent[2] = bent[4] + 1
+    assert plan_rc(keys, bent) == capi.ERR_INVALID                # offsets not monotone

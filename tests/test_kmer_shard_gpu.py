@@ -329,3 +329,54 @@ def test_n9999_lists_emulated_shards(gpu_available, oracle_lib, shards, db_layou
         data, offs = synth.pack_reads(reads)
         got = _emulated_shards_lists(db, data, offs, shards, shards)
         _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
+
+
+@pytest.mark.parametrize("shards,chunk,margin", [(1, "0", ""), (2, "300", ""), (3, "97", "0.2")])
+def test_place_sharded_native(gpu_available, oracle_lib, shards, chunk, margin, db_layout, monkeypatch):
+    """epik_amd_placer_place_sharded: the whole k-mer-space-sharded placement inside the library (what
+    epik-dna --db-shard calls) -- chunks of the batch, peer copies of the parts, the exchange of a chunk under the
+    accumulate of the next; here all handles on the one device, small chunks, and (margin 0.2) the first
+    capacity too small: the overflow round."""
+    assert gpu_available
+    if not db_layout.startswith("team") or "classic" in db_layout:
+        pytest.skip("dense partial vectors only on this kernel")
+    from epik_amd.placer import Placer
+    if chunk != "0":
+        monkeypatch.setenv("EPIK_AMD_SHARD_CHUNK", chunk)
+    if margin:
+        monkeypatch.setenv("EPIK_AMD_SHARD_MARGIN", margin)
+    db, (data, offs) = _case()
+    placers = [Placer.from_synth(db, shard_index=g, shard_count=shards) for g in range(shards)]
+    try:
+        got = Placer.place_sharded(placers, data, offs)
+        ref = oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0)
+        if shards == 1:
+            assert_rows_match(*got, *ref)
+        else:
+            _assert_close_to_oracle(got, ref)
+            # bit for bit what the lists give when the test drives the halves itself
+            assert_rows_match(*got, *_emulated_shards_lists(db, data, offs, shards, shards), lwr_tol=0.0)
+    finally:
+        for p in placers:
+            p.close()
+
+
+def test_place_sharded_native_n9999(gpu_available, oracle_lib, db_layout, monkeypatch):
+    assert gpu_available
+    if db_layout != "team4":
+        pytest.skip("one team geometry is enough at this size")
+    from epik_amd.placer import Placer
+    monkeypatch.setenv("EPIK_AMD_SHARD_CHUNK", "500")
+    tree = synth.make_tree(5000, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=8, seed=47, p_present=0.6, lognormal=(3.5, 1.7))
+    rng = np.random.default_rng(51)
+    reads = mixed_reads(rng, 600, db.kmer_size, max_len=151)
+    reads += ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(1200)] + ["ACGTN" * 70, "AC", ""]
+    data, offs = synth.pack_reads(reads)
+    placers = [Placer.from_synth(db, shard_index=g, shard_count=3) for g in range(3)]
+    try:
+        got = Placer.place_sharded(placers, data, offs)
+    finally:
+        for p in placers:
+            p.close()
+    _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
