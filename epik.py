@@ -38,6 +38,9 @@ PLACE_OPTIONS = [
                           help="Accepted for compatibility; placement runs on the GPU.")),
     (("--max-ram",), dict(type=str, default="", help="Approximate limit on the loaded database, e.g. 512, 256K, 42M, 4.2G.")),
     (("--gpus",), dict(type=int, default=1, show_default=True, help="MI355X devices to shard the reads across.")),
+    (("--db-shard",), dict(type=int, default=1, show_default=True,
+                           help="Cut the database in this many shards by k-mer code, one per device (a database "
+                                "larger than one device's memory); 1 = the whole database on every device.")),
 ]
 
 
@@ -51,13 +54,15 @@ def driver_path(states: str) -> str:
     return os.path.join(HERE, "epik_amd", "bin", name)
 
 
-def driver_command(database, states, omega, mu, outputdir, threads, max_ram, gpus, input_file):
+def driver_command(database, states, omega, mu, outputdir, threads, max_ram, gpus, input_file, db_shard=1):
     argv = [driver_path(states), "-d", str(database), "-q", str(input_file), "-j", str(threads),
             "--omega", str(omega), "--mu", str(mu), "-o", str(outputdir)]
     if max_ram:
         argv += ["--max-ram", max_ram]
     if gpus != 1:
         argv += ["--gpus", str(gpus)]
+    if db_shard != 1:
+        argv += ["--db-shard", str(db_shard)]
     return argv + [str(input_file)]  # the reference passes the query a second time, positionally
 
 

@@ -6,9 +6,12 @@
 // with the same defaults (1, 2000, 1.5, 1.0, -, -, 7, 0.01), the same exit codes
 // (0 / -1 on error, main.cpp:272,282,387,390), the same output file name
 // (main.cpp:34-37) and the same final report lines (main.cpp:368-382).  Not reproduced:
-// the progress bar and colours (indicators/termcolor).  Added: --gpus N | --devices a,b,c.
+// the progress bar and colours (indicators/termcolor).  Added: --gpus N | --devices a,b,c (the database on
+// every device, batches shared out) and --db-shard G (the database cut in G by k-mer code, shard g on device g:
+// every batch is placed by all of them together -- a database larger than one device's memory).
 // The two binaries differ as the reference's do (epik/CMakeLists.txt:72,124): epik-dna
 // accepts DNA databases, epik-aa protein ones.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -152,6 +155,8 @@ const char* kHelp =
     "      --keep-factor arg   Minimum LWR to report (default: 0.01)\n"
     "      --gpus arg          Number of MI355X devices to use (default: 1)\n"
     "      --devices arg       Comma-separated HIP device ordinals (overrides --gpus)\n"
+    "      --db-shard arg      Cut the database in so many shards by k-mer code, one per device\n"
+    "                          (a database larger than one device; default: 1 = replicate it)\n"
     "  -h, --help              Print usage\n";
 
 struct options {
@@ -240,12 +245,17 @@ int main(int argc, char** argv)
                       << " phylo-k-mers." << std::endl;
         }
 
+        const auto db_shards = (uint32_t)std::stoul(parsed.get("db-shard", "1"));
+        if (db_shards == 0 || db_shards > EPIK_AMD_MAX_SHARDS)
+            throw std::runtime_error("--db-shard must be between 1 and " + std::to_string(EPIK_AMD_MAX_SHARDS));
         std::vector<int> devices;
         if (parsed.has("devices")) {
             std::stringstream ss(parsed.require("devices"));
             for (std::string item; std::getline(ss, item, ',');) devices.push_back(std::stoi(item));
         } else {
-            const int n = std::stoi(parsed.get("gpus", "1"));
+            // (sharded: a device per shard while there are devices; --gpus / --devices say otherwise)
+            const int n = parsed.has("gpus") || db_shards == 1 ? std::stoi(parsed.get("gpus", "1"))
+                                                                : std::min<int>((int)db_shards, std::max(1, epik_amd_device_count()));
             for (int i = 0; i < n; ++i) devices.push_back(i);
         }
         for (int device : devices)
@@ -255,7 +265,9 @@ int main(int argc, char** argv)
                                          " visible (this placer has no CPU fallback)");
 
         std::cout << "Loading database with mu=" << user_mu << " and omega=" << user_omega << "..." << std::endl;
-        const auto db = epik_amd::load(db_file, user_mu, user_omega, max_entries);
+        // --db-shard G: this is shard 0 of G; the placer's constructor loads the others one after the other and
+        // drops each as soon as its lists are on its device (--max-ram then bounds what ONE shard keeps)
+        auto db = epik_amd::load(db_file, user_mu, user_omega, max_entries, 0, db_shards);
         if (db.version() < epik_amd::protocol::EARLIEST_INDEX) {
             std::cerr << "The serialization protocol version is too old (v" << db.version() << ").\n";
             return -1;
@@ -271,11 +283,19 @@ int main(int argc, char** argv)
                   << "\tPositions loaded: " << (db.positions_loaded() ? "true" : "false") << std::endl
                   << std::endl;
         std::cout << "Loaded " << epik_amd::human_count(db.get_num_entries_loaded()) << " of "
-                  << epik_amd::human_count(db.get_num_entries_total()) << " phylo-k-mers. " << std::endl
+                  << epik_amd::human_count(db.get_num_entries_total()) << " phylo-k-mers"
+                  << (db_shards > 1 ? " (shard 0 of " + std::to_string(db_shards) + ")" : std::string()) << ". " << std::endl
                   << std::endl;
 
         const auto tree = epik_amd::io::parse_newick(db.tree());
-        epik_amd::placer placer(db, tree, keep_at_most, keep_factor, num_threads, devices);
+        const epik_amd::placer::shard_loader load_shard = [&](uint32_t g) {
+            auto part = epik_amd::load(db_file, user_mu, user_omega, max_entries, g, db_shards);
+            std::cout << "Loaded " << epik_amd::human_count(part.get_num_entries_loaded()) << " phylo-k-mers (shard " << g
+                      << " of " << db_shards << ")." << std::endl;
+            return part;
+        };
+        epik_amd::placer placer(db, tree, keep_at_most, keep_factor, num_threads, devices, db_shards, load_shard);
+        db.drop_lists();  // the lists are on the devices now; tree, k and omega stay for the output
         const auto tree_as_newick = epik_amd::io::to_newick(tree, true);
         const auto jplace_filename = make_output_filename(query_file, output_dir);
         const auto invocation = make_invocation(argc, argv);
@@ -283,7 +303,8 @@ int main(int argc, char** argv)
         epik_amd::io::jplace_writer jplace(jplace_filename, invocation, tree_as_newick);
         jplace.start();
 
-        std::cout << "Instruction set: gfx950 (" << placer.device_count() << " device(s))" << std::endl;
+        std::cout << "Instruction set: gfx950 (" << placer.handle_count()
+                  << (db_shards > 1 ? " shard(s) of the database, one handle each)" : " device(s))") << std::endl;
         std::cout << "Placing " << query_file << "..." << std::endl;
         const auto begin = std::chrono::steady_clock::now();
         size_t num_seq_placed = 0;

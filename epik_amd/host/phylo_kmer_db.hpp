@@ -71,6 +71,14 @@ public:
     // which part of the database this object holds (k-mer-space shard: the codes with code % count == index)
     uint32_t shard_index() const noexcept { return _shard_index; }
     uint32_t shard_count() const noexcept { return _shard_count; }
+    /// Frees the lists (the placer has them on the device: place.cpp:300 is answered there); what the jplace
+    /// output needs -- tree, k, omega -- stays.
+    void drop_lists() noexcept
+    {
+        std::vector<uint32_t>().swap(_keys);
+        std::vector<uint64_t>().swap(_offsets);
+        std::vector<pkdb_value>().swap(_values);
+    }
 
     size_t _kmer_size = 0;
     float _omega = 0.0f;

@@ -12,7 +12,7 @@ using impl::placement;
 using impl::sequence_map_t;
 
 placer::placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t keep_at_most, double keep_factor,
-               size_t /*max_threads*/, std::vector<int> devices)
+               size_t /*max_threads*/, std::vector<int> devices, uint32_t db_shards, const shard_loader& load_shard)
     : _db{db}
     , _original_tree{original_tree}
     , _threshold{score_threshold(db.omega(), db.kmer_size(), alphabet_size(db.sequence_type()))}  // place.cpp:87
@@ -34,28 +34,45 @@ placer::placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t 
     }
 
     const auto char_class = char_class_table(db.sequence_type());
-    epik_amd_placer_desc desc{};
-    desc.abi_version = EPIK_AMD_ABI_VERSION;
-    desc.kmer_size = (uint32_t)db.kmer_size();
-    desc.alphabet_size = alphabet_size(db.sequence_type());
-    desc.num_branches = (uint32_t)original_tree.get_node_count();
-    desc.keep_at_most = (uint32_t)keep_at_most;
-    desc.offset_bits = 64;
-    desc.keep_factor = keep_factor;
-    desc.threshold = _threshold;
-    desc.log_threshold = _log_threshold;
-    desc.num_keys = db.num_keys();
-    desc.num_entries = db.values().size();
-    desc.offsets = db.offsets().data();  // the sparse form: memory per present k-mer (ABI 3)
-    desc.keys = db.keys().data();
-    desc.num_present = db.keys().size();
-    desc.values = db.values().data();
-    desc.char_class = char_class.data();
     if (devices.empty()) devices.push_back(0);
-    for (int device : devices) {
-        desc.device = device;
+    _sharded = db_shards > 1;
+    if (_sharded && (db.shard_count() != db_shards || db.shard_index() != 0 || !load_shard))
+        throw std::runtime_error("GPU placer: a sharded placer takes shard 0 of the database and a loader for the others");
+    // one handle per device (the database replicated) or per shard (shard g on devices[g % devices.size()])
+    const size_t n_handles = _sharded ? db_shards : devices.size();
+    for (size_t g = 0; g < n_handles; ++g) {
+        phylo_kmer_db loaded;  // shard g > 0: here until its lists are on the device
+        if (_sharded && g > 0) {
+            loaded = load_shard((uint32_t)g);
+            if (loaded.shard_index() != g || loaded.shard_count() != db_shards || loaded.kmer_size() != db.kmer_size() ||
+                loaded.num_keys() != db.num_keys() || loaded.omega() != db.omega())
+                throw std::runtime_error("GPU placer: shard " + std::to_string(g) + " does not belong to this database");
+        }
+        const phylo_kmer_db& part = (_sharded && g > 0) ? loaded : db;
+        epik_amd_placer_desc desc{};
+        desc.abi_version = EPIK_AMD_ABI_VERSION;
+        desc.kmer_size = (uint32_t)db.kmer_size();
+        desc.alphabet_size = alphabet_size(db.sequence_type());
+        desc.num_branches = (uint32_t)original_tree.get_node_count();
+        desc.keep_at_most = (uint32_t)keep_at_most;
+        desc.offset_bits = 64;
+        desc.keep_factor = keep_factor;
+        desc.threshold = _threshold;
+        desc.log_threshold = _log_threshold;
+        desc.num_keys = db.num_keys();
+        desc.num_entries = part.values().size();
+        desc.offsets = part.offsets().data();  // the sparse form: memory per present k-mer (ABI 3)
+        desc.keys = part.keys().data();
+        desc.num_present = part.keys().size();
+        desc.values = part.values().data();
+        desc.char_class = char_class.data();
+        desc.device = devices[g % devices.size()];
+        static const uint32_t no_key = 0;  // (an empty shard: keys must still be non-null to say "sparse form")
+        if (desc.num_present == 0) desc.keys = &no_key;
         epik_amd_placer* handle = nullptr;
-        if (epik_amd_placer_create(&desc, &handle) != EPIK_AMD_OK) {
+        const int rc = _sharded ? epik_amd_placer_create_sharded(&desc, (uint32_t)g, db_shards, &handle)
+                                : epik_amd_placer_create(&desc, &handle);
+        if (rc != EPIK_AMD_OK) {
             const std::string message = epik_amd_last_error();
             for (auto* h : _handles) epik_amd_placer_destroy(h);
             throw std::runtime_error("GPU placer: " + message);
@@ -78,7 +95,7 @@ placed_collection placer::place(const std::vector<seq_record>& seq_records, size
 std::vector<placed_collection> placer::place_batches(const std::vector<const std::vector<seq_record>*>& batches,
                                                      size_t device_index)
 {
-    if (device_index >= _handles.size()) throw std::runtime_error("GPU placer: no such device index");
+    if (device_index >= device_count()) throw std::runtime_error("GPU placer: no such device index");
     std::vector<placed_collection> out(batches.size());
     // identical sequences of a batch are placed once (place.cpp:73-81, 207-212); the unique reads of
     // all batches go through the boundary in one call
@@ -103,9 +120,11 @@ std::vector<placed_collection> placer::place_batches(const std::vector<const std
     if (n == 0) return out;
     std::vector<epik_amd_placement> rows(n * _keep_at_most);
     std::vector<uint32_t> n_rows(n), counts(n * _keep_at_most);
-    if (epik_amd_placer_place(_handles[device_index], bytes.data(), offsets.data(), n, rows.data(), n_rows.data(),
-                              counts.data()) != EPIK_AMD_OK)
-        throw std::runtime_error(std::string("GPU placer: ") + epik_amd_last_error());
+    const int rc = _sharded ? epik_amd_placer_place_sharded(_handles.data(), (uint32_t)_handles.size(), bytes.data(),
+                                                            offsets.data(), n, rows.data(), n_rows.data(), counts.data())
+                            : epik_amd_placer_place(_handles[device_index], bytes.data(), offsets.data(), n, rows.data(),
+                                                    n_rows.data(), counts.data());
+    if (rc != EPIK_AMD_OK) throw std::runtime_error(std::string("GPU placer: ") + epik_amd_last_error());
     for (size_t b = 0; b < batches.size(); ++b) {
         for (size_t u = 0; u < out[b].placed_seqs.size(); ++u) {
             const size_t i = first_unique[b] + u;

@@ -10,6 +10,7 @@
 #ifndef EPIK_AMD_HOST_PLACER_HPP
 #define EPIK_AMD_HOST_PLACER_HPP
 
+#include <functional>
 #include <string_view>
 #include <unordered_map>
 #include <vector>
@@ -56,9 +57,18 @@ class placer {
 public:
     using placed_collection = impl::placed_collection;
 
+    /// Shard g of a k-mer-space-sharded database (--db-shard), loaded when its turn comes and dropped as soon as
+    /// its lists are on the device: the process never holds more than one shard on the host.
+    using shard_loader = std::function<phylo_kmer_db(uint32_t shard_index)>;
+
     /// WARNING (as place.h:91-93): db and tree are kept by reference.
+    /// db_shards == 1: the database replicated on every device of `devices`, whole groups of batches go to them in
+    /// turn (no collective).  db_shards == G > 1: `db` holds shard 0 of G (phylo_kmer_db::shard_count() says so),
+    /// load_shard(g) the others; handle g is created on devices[g % devices.size()] and every batch is placed by
+    /// all of them together (epik_amd_placer_place_sharded) -- a database larger than one device's memory.
     placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t keep_at_most, double keep_factor,
-           size_t max_threads, std::vector<int> devices = {0});
+           size_t max_threads, std::vector<int> devices = {0}, uint32_t db_shards = 1,
+           const shard_loader& load_shard = {});
     placer(const placer&) = delete;
     placer& operator=(const placer&) = delete;
     ~placer() noexcept;
@@ -73,7 +83,10 @@ public:
     std::vector<placed_collection> place_batches(const std::vector<const std::vector<seq_record>*>& batches,
                                                  size_t device_index);
 
-    size_t device_count() const noexcept { return _handles.size(); }
+    /// How many callers may place at the same time (place_batches' device_index): the devices of a replicated
+    /// database, ONE for a sharded one (all its handles work on every batch).
+    size_t device_count() const noexcept { return _sharded ? 1 : _handles.size(); }
+    size_t handle_count() const noexcept { return _handles.size(); }
 
 private:
     const phylo_kmer_db& _db;
@@ -83,7 +96,8 @@ private:
     const size_t _keep_at_most;
     const double _keep_factor;
     std::vector<double> _pendant_lengths;
-    std::vector<epik_amd_placer*> _handles;  // one per device
+    std::vector<epik_amd_placer*> _handles;  // one per device (replicated) or per shard (sharded)
+    bool _sharded = false;
 };
 
 }  // namespace epik_amd

@@ -46,3 +46,20 @@ int epik_amd_placer_place(epik_amd_placer *p, const char *seqs, const uint64_t *
     }
     return EPIK_AMD_OK;
 }
+
+/* the sharded forms the driver's --db-shard path calls: the same canned rows (what matters under the
+ * sanitizers is the host side around the call) */
+int epik_amd_placer_create_sharded(const epik_amd_placer_desc *desc, uint32_t shard_index, uint32_t shard_count,
+                                   epik_amd_placer **out)
+{
+    if (shard_count == 0 || shard_index >= shard_count) return EPIK_AMD_ERR_INVALID;
+    return epik_amd_placer_create(desc, out);
+}
+
+int epik_amd_placer_place_sharded(epik_amd_placer *const *shards, uint32_t n_shards, const char *seqs,
+                                  const uint64_t *seq_offsets, uint64_t n, epik_amd_placement *rows, uint32_t *n_rows,
+                                  uint32_t *kmer_counts)
+{
+    if (n_shards == 0) return EPIK_AMD_ERR_INVALID;
+    return epik_amd_placer_place(shards[0], seqs, seq_offsets, n, rows, n_rows, kmer_counts);
+}

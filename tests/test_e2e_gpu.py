@@ -115,3 +115,50 @@ def test_epik_aa_places_proteins(tmp_path, oracle_lib):
     wrong = subprocess.run([os.path.join(ROOT, "epik_amd", "bin", "epik-dna"), "-d", db_path, "-q", fasta, "-o",
                             str(out_dir)], capture_output=True, text=True, timeout=600)
     assert wrong.returncode == 255 and "Proteins" in wrong.stderr
+
+
+@pytest.mark.parametrize("shards,devices", [("2", "0,0"), ("3", "0")])
+def test_db_shard_through_the_driver(tmp_path, oracle_lib, shards, devices, monkeypatch):
+    """`epik.py place --db-shard G` / epik-dna --db-shard G: the database cut in G by k-mer code, every shard loaded
+    on its own (the process never holds two), a handle per shard -- here on the one device --, every batch placed
+    by all of them together (epik_amd_placer_place_sharded).  A tree large enough for the kernels that leave
+    partial lists; reads with N follow the first-key rule over all shards.  The float32 sums of a branch are added
+    shard by shard: scores agree with the oracle's to rounding, rows of equal score may swap."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "epik_amd", "host")], check=True, stdout=subprocess.DEVNULL)
+    monkeypatch.setenv("EPIK_AMD_SHARD_CHUNK", "1500")   # several chunks per call: the pipelined exchange
+    tree = synth.make_tree(2000, seed=15)                # N = 3 999: front + streaming + merge kernels
+    db = synth.make_db(tree.num_nodes, kmer_size=8, seed=16, p_present=0.5, lognormal=(3.5, 1.5))
+    db_path = str(tmp_path / "db.ekdb")
+    dbfile.write_db(db_path, db, tree.newick())
+    rng = np.random.default_rng(8)
+    records = []
+    for i in range(6000):
+        alpha = "ACGT" if i % 5 else "ACGTN"
+        records.append((f"read_{i}", "".join(rng.choice(list(alpha), size=int(rng.integers(5, 250))))))
+    records += [("dup_a", records[0][1]), ("short", "ACG")]
+    fasta = str(tmp_path / "q.fasta")
+    with open(fasta, "w") as fh:
+        for h, s in records:
+            fh.write(f">{h}\n{s}\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    if devices == "0":
+        cmd = [sys.executable, os.path.join(ROOT, "epik.py"), "place", "-i", db_path, "-o", str(out_dir), "--db-shard",
+               shards, fasta]
+    else:
+        cmd = [os.path.join(ROOT, "epik_amd", "bin", "epik-dna"), "-d", db_path, "-q", fasta, "-o", str(out_dir),
+               "--devices", devices, "--db-shard", shards, "--batch-size", "777"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "Placed 6002 sequences." in run.stdout and f"(shard 0 of {shards})" in run.stdout
+    assert f"(shard {int(shards) - 1} of {shards})" in run.stdout and f"{shards} shard(s) of the database" in run.stdout
+    ref_path = str(tmp_path / "ref.jplace")
+    _oracle_jplace(ref_path, oracle_lib, db, tree, records)
+    got, ref = jplace.read_jplace(str(out_dir / "placements_q.fasta.jplace")), jplace.read_jplace(ref_path)
+    assert set(got) == set(ref) == {h for h, _ in records}
+    problems = jplace_diff.diff_strict(got, ref)
+    assert not [p for p in problems if "like_weight_ratio" in p or "rows vs" in p], problems[:5]
+    assert len(problems) <= 6, problems[:5]   # rows whose scores agree to float32 rounding may swap
+    for name in ("read_1", "dup_a"):
+        for x, y in zip(got[name], ref[name]):
+            assert x["likelihood"] == pytest.approx(y["likelihood"], rel=2e-6)

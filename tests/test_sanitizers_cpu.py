@@ -58,17 +58,18 @@ def driver_case(tmp_path_factory):
     return tmp, db_path, fasta, n + (n + 96) // 97
 
 
-@pytest.mark.parametrize("binary,devices,jobs", [("epik-dna_tsan", "0,1", "4"), ("epik-dna_tsan", "0", "1"),
-                                                 ("epik-dna_asan", "0,1", "3")])
-def test_driver_pipeline_under_sanitizers(san_bins, driver_case, binary, devices, jobs):
+@pytest.mark.parametrize("binary,devices,jobs,shards", [
+    ("epik-dna_tsan", "0,1", "4", "1"), ("epik-dna_tsan", "0", "1", "1"), ("epik-dna_asan", "0,1", "3", "1"),
+    ("epik-dna_tsan", "0,1", "2", "2"), ("epik-dna_asan", "0,1", "2", "3")])   # --db-shard: shards loaded one by one
+def test_driver_pipeline_under_sanitizers(san_bins, driver_case, binary, devices, jobs, shards):
     """Small batches, two device threads, several formatting threads: every hand-over of the pipeline
     is exercised many times; the output must name every read once, in input order."""
     tmp, db_path, fasta, n_records = driver_case
-    out_dir = tmp / f"out_{binary}_{devices.replace(',', '_')}"
+    out_dir = tmp / f"out_{binary}_{devices.replace(',', '_')}_{shards}"
     out_dir.mkdir()
     run = subprocess.run([os.path.join(san_bins, binary), "-d", db_path, "-q", fasta, "-o", str(out_dir), "--devices",
-                          devices, "--batch-size", "500", "-j", jobs], capture_output=True, text=True, env=ENV,
-                         timeout=600)
+                          devices, "--batch-size", "500", "-j", jobs, "--db-shard", shards], capture_output=True,
+                         text=True, env=ENV, timeout=600)
     _clean(run)
     assert f"Placed {n_records} sequences." in run.stdout
     with open(out_dir / "placements_q.fasta.jplace") as fh:
