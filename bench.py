@@ -178,20 +178,55 @@ def end_to_end(db, tree, data, read_length: int, n_reads: int, jobs: int):
         out_dir = os.path.join(tmp, "out")
         os.makedirs(out_dir)
         run = subprocess.run([binary, "-d", db_path, "-q", fasta, "-o", out_dir, "-j", str(jobs)],
-                             capture_output=True, text=True, timeout=600)
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, EPIK_AMD_STAGE_TIMES="1"))
         m = re.search(r"Placement time: .*\((\d+) ms\)", run.stdout)
         if run.returncode != 0 or not m:
             return {"reads_per_s": None, "note": (run.stdout + run.stderr)[-400:]}
         ms = max(int(m.group(1)), 1)
         jplace = os.path.join(out_dir, "placements_reads.fasta.jplace")
-        return {"reads_per_s": n_reads / (ms / 1e3), "reads": n_reads, "placement_time_ms": ms, "jobs": jobs,
-                "batch_size": 2000, "jplace_mb": os.path.getsize(jplace) / 1e6,
-                "what": "epik-dna: FASTA parse -> per-batch dedup -> GPU placement -> jplace written and closed "
-                        "(database load excluded, as the reference's timer)"}
+        result = {"reads_per_s": n_reads / (ms / 1e3), "reads": n_reads, "placement_time_ms": ms, "jobs": jobs,
+                  "batch_size": 2000, "jplace_mb": os.path.getsize(jplace) / 1e6,
+                  "what": "epik-dna: FASTA parse -> per-batch dedup -> GPU placement -> jplace written and closed "
+                          "(database load excluded, as the reference's timer)"}
+        stages = dict(re.findall(r"stage (read|place|write) ([0-9.]+) ms", run.stdout))
+        if stages:
+            result["stage_busy_ms"] = {k: float(v) for k, v in stages.items()}
+        result["cpu_baseline"] = end_to_end_cpu(db, tree, tmp, fasta, n_reads, jobs)
+        return result
     except (OSError, subprocess.SubprocessError) as e:
         return {"reads_per_s": None, "note": repr(e)[:400]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def end_to_end_cpu(db, tree, tmp, fasta, n_reads: int, threads: int):
+    """The CPU twin of `end_to_end` (timing (b)): oracle/epik_oracle_driver -- the restatement run
+    as the reference's driver runs, FASTA batch -> placer::place (dedup, hash-map lookup, OpenMP loop) -> jplace
+    appended, read and write on the main thread -- on the same database and the same reads, all host threads.
+    Kind "port": the reference's own driver cannot be built here."""
+    from epik_amd.placer import pendant_lengths
+    driver = os.path.join(ROOT, "oracle", "epik_oracle_driver")
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "epik_oracle_driver"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(os.path.join(tmp, "tree.txt"), "w") as fh:
+            fh.write(tree.newick(jplace=True))
+        distal, pendant = pendant_lengths(tree.branch_length, tree.subtree_num_nodes, tree.subtree_total_length)
+        np.stack([distal, pendant], 1).astype(np.float64).tofile(os.path.join(tmp, "lengths.f64"))
+        out = os.path.join(tmp, "cpu.jplace")
+        run = subprocess.run([driver, os.path.join(tmp, "db.ekdb"), fasta, out, os.path.join(tmp, "tree.txt"),
+                              os.path.join(tmp, "lengths.f64"), str(threads)], capture_output=True, text=True, timeout=900)
+        m = re.search(r"Placement time: (\d+) ms", run.stdout)
+        if run.returncode != 0 or not m:
+            return {"value": None, "note": (run.stdout + run.stderr)[-300:]}
+        ms = max(int(m.group(1)), 1)
+        return {"value": n_reads / (ms / 1e3), "unit": "reads/s", "cores": threads, "kind": "port",
+                "placement_time_ms": ms, "jplace_mb": os.path.getsize(out) / 1e6,
+                "sample": f"the same {n_reads} reads and database through oracle/epik_oracle_driver: FASTA -> jplace "
+                          "closed, batches of 2000, hash-map lookup, OpenMP loop, reading and writing on the main "
+                          "thread as main.cpp:332-361"}
+    except (OSError, subprocess.SubprocessError) as e:
+        return {"value": None, "note": repr(e)[:300]}
 
 
 def image_bytes(plan) -> int:

@@ -6,7 +6,7 @@
 #ifndef EPIK_AMD_HOST_JPLACE_HPP
 #define EPIK_AMD_HOST_JPLACE_HPP
 
-#include <fstream>
+#include <cstdint>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -19,19 +19,34 @@ class jplace_writer {
 public:
     jplace_writer(const std::string& filename, const std::string& invocation, std::string_view newick_tree);
     void start();
+    /// (optional) distal_length and pendant_length of a placement belong to its branch (place.cpp:435-437): with
+    /// them known per branch, their text is made once per branch and not once per row
+    void set_branch_lengths(const std::vector<double>& distal, const std::vector<double>& pendant);
     jplace_writer& operator<<(const impl::placed_collection& placed);
     /// the same, with the JSON text of the batch formatted by `num_threads` threads
     jplace_writer& write(const impl::placed_collection& placed, size_t num_threads);
     /// several batches, in order, as one piece of work for the formatting threads
     jplace_writer& write(const std::vector<const impl::placed_collection*>& group, size_t num_threads);
+    /// ... in the driver's flat form (placer::place_flat)
+    jplace_writer& write(const std::vector<const impl::placed_batch*>& group, size_t num_threads);
     void end();
 
+    ~jplace_writer();
+    jplace_writer(const jplace_writer&) = delete;
+    jplace_writer& operator=(const jplace_writer&) = delete;
+
 private:
+    template <typename Batch>
+    jplace_writer& write_group(const std::vector<const Batch*>& group, size_t num_threads);
+    void append(const char* data, size_t n);  // at the end of the file, by the calling thread
     std::string _filename;
-    std::ofstream _out;
+    int _fd = -1;
+    uint64_t _size = 0;  // bytes written so far: where the next piece goes
     std::string _invocation;
     std::string _tree;
     bool _first = true;
+    std::vector<std::string> _length_text;  // per branch: ", <distal>, <pendant>]"
+    std::vector<std::string> _buffers;  // one per formatting thread, kept from group to group (no fresh pages every time)
 };
 
 std::string json_escape(std::string_view s);

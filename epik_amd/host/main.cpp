@@ -301,6 +301,7 @@ int main(int argc, char** argv)
         const auto invocation = make_invocation(argc, argv);
 
         epik_amd::io::jplace_writer jplace(jplace_filename, invocation, tree_as_newick);
+        jplace.set_branch_lengths(placer.distal_lengths(), placer.pendant_lengths());
         jplace.start();
 
         std::cout << "Instruction set: gfx950 (" << placer.handle_count()
@@ -322,7 +323,7 @@ int main(int argc, char** argv)
         struct work_item {
             size_t sequence = 0;                          // position of the batch in the input
             std::vector<epik_amd::seq_record> batch;     // owns the bytes the views below point into
-            epik_amd::placer::placed_collection placed;
+            epik_amd::impl::placed_batch placed;
         };
         const size_t n_devices = placer.device_count();
         bounded_queue<work_item> to_place(2 * kGroupBatches * n_devices);
@@ -332,9 +333,10 @@ int main(int argc, char** argv)
         stage_clock read_clock, write_clock;
         std::vector<stage_clock> place_clocks(n_devices);
         std::mutex stats_mutex;
+        // (the records of a batch are views into the reader's mapping of the file: it stays until all is written)
+        epik_amd::io::batch_fasta reader(query_file, batch_size);
         std::thread reader_thread([&] {
             try {
-                epik_amd::io::batch_fasta reader(query_file, batch_size);
                 for (size_t sequence = 0;; ++sequence) {
                     read_clock.start();
                     auto batch = reader.next_batch();
@@ -353,7 +355,7 @@ int main(int argc, char** argv)
                 std::vector<work_item> arrived;
                 while (to_write.pop_all(arrived)) {
                     for (auto& item : arrived) waiting.emplace(item.sequence, std::move(item));
-                    std::vector<const epik_amd::placer::placed_collection*> group;
+                    std::vector<const epik_amd::impl::placed_batch*> group;
                     std::vector<work_item> ready;  // keeps the batches alive while they are written
                     for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
                         ready.push_back(std::move(it->second));
@@ -382,7 +384,7 @@ int main(int argc, char** argv)
                         place_clocks[device].start();
                         std::vector<const std::vector<epik_amd::seq_record>*> batches;
                         for (const auto& item : group) batches.push_back(&item.batch);
-                        auto placed = placer.place_batches(batches, device);
+                        auto placed = placer.place_flat(batches, device, num_threads);
                         place_clocks[device].stop();
                         auto ms_diff = (float)std::chrono::duration_cast<std::chrono::microseconds>(
                                            std::chrono::steady_clock::now() - begin_group).count() / 1000.0f;

@@ -49,6 +49,19 @@ struct placed_collection {
     std::vector<placed_sequence> placed_seqs;
 };
 
+/// The driver's own form of a placed batch: what a placed_collection holds, in five flat arrays (a
+/// placed_collection is a hash-map node, a vector of headers and a vector of placements PER READ -- three
+/// allocations each, made by the placing thread and freed by the writing one; at a million reads per second and
+/// device that is what the driver would spend its time on).  Unique sequences in first-occurrence order.
+struct placed_batch {
+    std::vector<std::string_view> sequences;  // [n_unique]
+    std::vector<uint32_t> row_begin;          // [n_unique + 1]: the placements of sequence u are rows[row_begin[u] .. row_begin[u + 1])
+    std::vector<placement> rows;
+    std::vector<uint32_t> name_begin;         // [n_unique + 1]: ... its headers names[name_begin[u] .. name_begin[u + 1]), input order
+    std::vector<std::string_view> names;
+    size_t size() const noexcept { return sequences.size(); }
+};
+
 }  // namespace epik_amd::impl
 
 namespace epik_amd {
@@ -80,13 +93,21 @@ public:
     /// Every batch is de-duplicated on its own, exactly as `place` does it (place.cpp:207-212: dedup is
     /// per batch), the unique reads of all of them cross the boundary together, and every batch gets
     /// its own placed_collection back.  Thread-safe across different devices.
+    /// The host work on either side of the launch -- dedup, joining the reads, the placements with their branch
+    /// lengths -- is per batch: `num_threads` threads share the batches.
     std::vector<placed_collection> place_batches(const std::vector<const std::vector<seq_record>*>& batches,
-                                                 size_t device_index);
+                                                 size_t device_index, size_t num_threads = 1);
+    /// The same placement in the driver's flat form (impl::placed_batch): what epik-dna / epik-aa call.
+    std::vector<impl::placed_batch> place_flat(const std::vector<const std::vector<seq_record>*>& batches,
+                                               size_t device_index, size_t num_threads = 1);
 
     /// How many callers may place at the same time (place_batches' device_index): the devices of a replicated
     /// database, ONE for a sharded one (all its handles work on every batch).
     size_t device_count() const noexcept { return _sharded ? 1 : _handles.size(); }
     size_t handle_count() const noexcept { return _handles.size(); }
+    /// distal_length / pendant_length of a placement on branch b (place.cpp:110-123, 435-437)
+    std::vector<double> distal_lengths() const;
+    const std::vector<double>& pendant_lengths() const noexcept { return _pendant_lengths; }
 
 private:
     const phylo_kmer_db& _db;
