@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--batch-size", type=int, nargs="+", default=[2000, 100_000])
     ap.add_argument("--leaves", type=int, default=500)
     ap.add_argument("--kmer-size", type=int, default=10)
-    ap.add_argument("--jobs", type=int, default=1)
+    ap.add_argument("--jobs", type=int, nargs="+", default=[1])
+    ap.add_argument("--devices", default="", help="passed to the driver (e.g. 0,0: two handles on the one device)")
     ap.add_argument("--keep", action="store_true", help="keep the scratch directory")
     ap.add_argument("--binary", nargs="+", default=["epik-dna"], help="driver binaries under epik_amd/bin to run")
     args = ap.parse_args()
@@ -62,11 +63,11 @@ def main():
     data, _ = synth.make_reads(args.reads, 150, seed=44)
     fasta = os.path.join(tmp, "reads.fasta")
     write_fasta(fasta, data, args.reads, 150)
-    for bs, binary in [(b, x) for b in args.batch_size for x in args.binary]:
+    for bs, binary, jobs in [(b, x, j) for b in args.batch_size for x in args.binary for j in args.jobs]:
         out_dir = os.path.join(tmp, f"out_{bs}")
         os.makedirs(out_dir, exist_ok=True)
         cmd = [os.path.join(ROOT, "epik_amd", "bin", binary), "-d", db_path, "-q", fasta, "-o", out_dir,
-               "--batch-size", str(bs), "-j", str(args.jobs)]
+               "--batch-size", str(bs), "-j", str(jobs)] + (["--devices", args.devices] if args.devices else [])
         t0 = time.perf_counter()
         run = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, EPIK_AMD_STAGE_TIMES="1"))
         wall = time.perf_counter() - t0
@@ -76,7 +77,7 @@ def main():
         m = re.search(r"Placement time: .*\((\d+) ms\)", run.stdout)
         place_ms = int(m.group(1)) if m else None
         jp = os.path.join(out_dir, "placements_reads.fasta.jplace")
-        print(json.dumps({"binary": binary, "reads": args.reads, "batch_size": bs, "jobs": args.jobs,
+        print(json.dumps({"binary": binary, "reads": args.reads, "batch_size": bs, "jobs": jobs, "devices": args.devices or "0",
                           "placement_time_ms": place_ms,
                           "reads_per_s_fasta_to_jplace": args.reads / (place_ms / 1e3) if place_ms else None,
                           "process_wall_s": wall, "fasta_mb": os.path.getsize(fasta) / 1e6,
