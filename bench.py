@@ -83,18 +83,26 @@ def parse_args():
 
 
 def load_traffic(workload: str):
-    """HBM bytes per launch from the committed PMC pass (profiles/traffic.json) -- only if it was
-    measured for this workload ON THESE KERNEL SOURCES (rocprofv3 --pmc cannot run inside this process)."""
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: one entry per workload string) --
+    only if they were measured ON THESE KERNEL SOURCES (rocprofv3 --pmc cannot run inside this process)."""
     from epik_amd import provenance
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
-        if doc.get("workload") == workload and doc.get("kernel_source_sha") == provenance.kernel_source_hash():
+        if doc.get("kernel_source_sha") != provenance.kernel_source_hash():
+            return None
+        if doc.get("workload") == workload:
             return doc.get("hbm_bytes_per_launch")
+        return (doc.get("workloads", {}).get(workload) or {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
     return None
+
+
+# What random 128-byte line reads get from a working set far larger than the Infinity Cache (tools/probe_mall.hip:
+# 6.3 TB/s on 4 GB, DESIGN.md 4): the bound of a workload made of table lookups rather than of posting streams.
+RANDOM_LINE_GBPS = 6300.0
 
 
 def host_cores() -> int:
@@ -286,9 +294,17 @@ def main():
     log("building the synthetic database ...")
     # k-mer-space shard: rank g builds and keeps the lists of the codes with code % G == g and never holds
     # the others -- they are empty lists in its descriptor (include/epik_amd.h, "k-mer-space shard")
-    db = synth.make_db(tree.num_nodes, states=args.states, kmer_size=args.kmer_size, seed=43,
-                       p_present=args.p_present, scattered=args.scattered,
-                       shard=(rank, world) if kmer_shard else None)
+    # (a key space too large to draw one number per code -- amino k = 7: 1.28 G codes -- gets its present codes drawn
+    # directly, and goes to create() in the sparse form of the descriptor: keys[present] + offsets, ABI 3)
+    big_key_space = alphabet.alphabet_size(args.states) ** args.kmer_size > (1 << 28)
+    if big_key_space and not kmer_shard:
+        db = synth.make_sparse_db(tree.num_nodes, states=args.states, kmer_size=args.kmer_size, seed=43,
+                                  p_present=args.p_present, dense=False)
+        db.total_entries = db.num_entries
+    else:
+        db = synth.make_db(tree.num_nodes, states=args.states, kmer_size=args.kmer_size, seed=43,
+                           p_present=args.p_present, scattered=args.scattered,
+                           shard=(rank, world) if kmer_shard else None)
     total_entries = db.total_entries
     data, offs = synth.make_reads(args.reads_per_step, args.read_length, states=args.states,
                                   seed=44 if kmer_shard else 44 + rank)
@@ -490,13 +506,26 @@ def main():
         alg_bytes = pl.algorithmic_bytes(d_seqs.data_ptr(), d_offs.data_ptr(), n, d_nrows.data_ptr(), stream.cuda_stream)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         working_set = image_bytes(pl_plan)
+        traffic = load_traffic(workload_name)
         # a working set of up to twice the Infinity Cache is served from it for a good part (the headline
         # database: 285 MB against 268 MB of cache); only well beyond that is the kernel bound by HBM alone
-        return {"bound": "hbm+mall" if working_set <= 2 * MALL_BYTES else "hbm", "achieved": achieved,
+        roof = {"bound": "hbm+mall" if working_set <= 2 * MALL_BYTES else "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": load_traffic(workload_name), "working_set_bytes": working_set, "mall_bytes": MALL_BYTES,
+                "traffic": traffic, "working_set_bytes": working_set, "mall_bytes": MALL_BYTES,
                 "kernel": kernel_name(pl_plan, pl, not kmer_shard), "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_read": alg_bytes / n}
+        if traffic:
+            # The SURVEY 8(d) formula charges 8 bytes per lookup; a lookup FETCHES a 128-byte line (of the table or
+            # of the presence filter).  A workload that is mostly lookups -- a sparse protein database: 294 of them
+            # per read against a few found lists -- is bound by how many random lines the memory system serves, so
+            # beside the algorithmic fraction: the lines really fetched (PMC) per second against that rate.
+            fetched = traffic / (ms * 1e-3) / 1e9
+            roof["fetched"] = {"achieved": fetched, "peak": RANDOM_LINE_GBPS, "unit": "GB/s", "frac": fetched / RANDOM_LINE_GBPS,
+                               "bytes_per_read": traffic / n, "lines_per_read": traffic / n / 128.0,
+                               "what": "bytes fetched past L2 (TCC_EA0_RDREQ x request size, profiles/traffic.json) per "
+                                       "second against the rate of random 128-byte reads on a working set beyond the "
+                                       "Infinity Cache (tools/probe_mall.hip)"}
+        return roof
 
     if rank == 0:
         info = placer.launch_info()

@@ -114,6 +114,7 @@ def make_desc(offsets, values, *, states: str, kmer_size: int, num_branches: int
 def plan(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 288 << 30, **kw) -> capi.Plan:
     """`epik_amd_placer_plan`: kernel, layout and device-image sizes create() would choose for a
     synthetic / loaded database `db` -- no device needed."""
+    kw.setdefault("keys", getattr(db, "keys", None))
     desc, keep = make_desc(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
                            num_branches=db.num_branches, threshold=db.threshold, log_threshold=db.log_threshold, **kw)
     out = capi.Plan()
@@ -126,6 +127,7 @@ def plan(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 28
 def build_image(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 288 << 30, discard=False, **kw):
     """`epik_amd_placer_build_image`: the device image as three uint8 arrays (table, filter, postings);
     with `discard` the image is produced and dropped (returns the plan only).  Host only."""
+    kw.setdefault("keys", getattr(db, "keys", None))
     desc, keep = make_desc(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
                            num_branches=db.num_branches, threshold=db.threshold, log_threshold=db.log_threshold, **kw)
     lib = capi.load()
@@ -148,7 +150,7 @@ class Placer:
                  num_branches: int, threshold, log_threshold=None, keep_at_most: int = 7,
                  keep_factor: float = 0.01, device: int = 0, branch_length=None,
                  subtree_num_nodes=None, subtree_total_length=None, char_class=None,
-                 shard_index: int = 0, shard_count: int = 1):
+                 shard_index: int = 0, shard_count: int = 1, keys=None, sparse: bool = False):
         lib = capi.load()
         sigma = alphabet.alphabet_size(states)
         self.states = states
@@ -160,7 +162,7 @@ class Placer:
         desc, keepalive = make_desc(
             offsets, values, states=states, kmer_size=kmer_size, num_branches=num_branches, threshold=threshold,
             log_threshold=log_threshold, keep_at_most=keep_at_most, keep_factor=keep_factor, device=device,
-            char_class=char_class)
+            char_class=char_class, keys=keys, sparse=sparse)
         handle = ctypes.c_void_p()
         # shard_count > 1: this placer keeps the posting lists of the codes with
         # code % shard_count == shard_index (k-mer-space shard, `epik_amd_placer_create_sharded`)
@@ -186,6 +188,7 @@ class Placer:
         if tree is not None:
             extra = dict(branch_length=tree.branch_length, subtree_num_nodes=tree.subtree_num_nodes,
                          subtree_total_length=tree.subtree_total_length)
+        kw.setdefault("keys", getattr(db, "keys", None))
         return cls(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
                    num_branches=db.num_branches, threshold=db.threshold,
                    log_threshold=db.log_threshold, **extra, **kw)

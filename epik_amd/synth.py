@@ -149,6 +149,7 @@ class SynthDB:
     threshold: np.float32 = None
     log_threshold: np.float32 = None
     total_entries: int = None     # postings of the whole database when this object holds one shard of it
+    keys: np.ndarray = None       # the sparse form: uint32 ascending codes that have a list, offsets[len(keys) + 1]
 
     def __post_init__(self):
         sigma = alphabet.alphabet_size(self.states)
@@ -163,7 +164,18 @@ class SynthDB:
 
     @property
     def num_keys(self) -> int:
-        return int(self.offsets.shape[0] - 1)
+        return self.alphabet_size ** self.kmer_size if self.keys is not None else int(self.offsets.shape[0] - 1)
+
+    def densified(self) -> "SynthDB":
+        """The same database with an offset per possible code (8 bytes each: what the CPU oracle indexes by)."""
+        if self.keys is None:
+            return self
+        lens = np.zeros(self.num_keys + 1, dtype=np.uint64)
+        lens[self.keys.astype(np.int64) + 1] = np.diff(self.offsets.astype(np.int64)).astype(np.uint64)
+        np.cumsum(lens, out=lens)
+        return SynthDB(states=self.states, kmer_size=self.kmer_size, omega=self.omega, num_branches=self.num_branches,
+                       offsets=lens, values=self.values, threshold=self.threshold, log_threshold=self.log_threshold,
+                       total_entries=self.total_entries)
 
     @property
     def num_entries(self) -> int:
@@ -248,7 +260,7 @@ def pack_reads(reads) -> tuple:
 
 
 def make_sparse_db(num_branches: int, states: str = "amino", kmer_size: int = 7, omega: float = 1.5,
-                   p_present: float = 0.0026, seed: int = 43, lognormal=(3.0, 1.5)) -> SynthDB:
+                   p_present: float = 0.0026, seed: int = 43, lognormal=(3.0, 1.5), dense: bool = True) -> SynthDB:
     """The database model of `make_db` for a key space too large to draw one uniform number per code
     (amino k = 7: 1.28 G codes): the present codes are drawn directly (Binomial count, distinct uniform
     codes), everything else is the same.  Peak host memory = the uint64 offsets array (8 B per code)."""
@@ -262,9 +274,12 @@ def make_sparse_db(num_branches: int, states: str = "amino", kmer_size: int = 7,
     n_present = int(keys.shape[0])
     raw = np.floor(rng.lognormal(lognormal[0], lognormal[1], size=n_present))
     lengths = (1 + np.minimum(num_branches - 1, raw)).astype(np.int64)
-    offsets = np.zeros(num_keys + 1, dtype=np.uint64)
-    offsets[keys + 1] = lengths.astype(np.uint64)
-    np.cumsum(offsets, out=offsets)
+    if dense:
+        offsets = np.zeros(num_keys + 1, dtype=np.uint64)
+        offsets[keys + 1] = lengths.astype(np.uint64)
+        np.cumsum(offsets, out=offsets)
+    else:
+        offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
     total = int(offsets[-1])
     values = np.empty(total, dtype=PKDB_VALUE)
     list_id = np.repeat(np.arange(n_present, dtype=np.int64), lengths)
@@ -275,7 +290,7 @@ def make_sparse_db(num_branches: int, states: str = "amino", kmer_size: int = 7,
     prob = float(threshold) + rng.random(total) * (1.0 - float(threshold))
     values["score"] = np.log10(prob).astype(np.float32)
     return SynthDB(states=states, kmer_size=kmer_size, omega=omega, num_branches=num_branches,
-                   offsets=offsets, values=values, threshold=threshold)
+                   offsets=offsets, values=values, threshold=threshold, keys=None if dense else keys.astype(np.uint32))
 
 
 def reads_hitting(db: SynthDB, n_reads: int, length: int, hit_rate: float, seed: int = 45, dirty: str = ""):

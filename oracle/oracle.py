@@ -98,6 +98,8 @@ class Oracle:
     @classmethod
     def from_synth(cls, db, states=None, keep_at_most=7, keep_factor=0.01):
         from epik_amd import alphabet  # tables only; not the product path
+        if getattr(db, "keys", None) is not None:
+            db = db.densified()  # the oracle's direct index: an offset per possible code
         return cls(db.offsets, db.values, alphabet.char_class_table(states or db.states),
                    kmer_size=db.kmer_size, alphabet_size=db.alphabet_size,
                    num_branches=db.num_branches, threshold=db.threshold,

@@ -37,6 +37,84 @@ def test_amino_k7_matches_the_oracle(amino_k7, oracle_lib, layout, monkeypatch):
     assert_rows_match(*got, *ref)
 
 
+def test_amino_k7_sparse_descriptor_needs_no_array_per_code(amino_k7, oracle_lib, monkeypatch):
+    """ABI 3: keys[num_present] + offsets[num_present + 1].  The dense form costs 8 bytes per POSSIBLE k-mer
+    before a posting is loaded -- 10 GB for amino k = 7 --, the sparse one memory per present key, like the hash map
+    behind phylo_kmer_db::search (place.cpp:300).  create() streams from it: beyond the caller's arrays the process
+    grows by its staging buffers only (the dense test_build_streams_without_a_host_copy asserts the same)."""
+    import threading
+    import time
+    import psutil
+    from epik_amd.placer import Placer
+    db, data, offs = amino_k7
+    monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
+    monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
+    # the sparse form of the same database (built here from the dense arrays the oracle needs anyway)
+    lens = np.diff(db.offsets.view(np.int64))
+    present = np.nonzero(lens)[0]
+    keys = present.astype(np.uint32)
+    offsets = np.concatenate([[0], np.cumsum(lens[present])]).astype(np.uint64)
+    del lens, present
+    assert keys.nbytes + offsets.nbytes < 64 << 20   # against 10 GB of dense offsets
+    proc = psutil.Process()
+    peak, stop = [0], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            peak[0] = max(peak[0], proc.memory_info().rss)
+            time.sleep(0.005)
+
+    before = proc.memory_info().rss
+    t = threading.Thread(target=sample)
+    t.start()
+    try:
+        pl = Placer(offsets, db.values, keys=keys, states=db.states, kmer_size=db.kmer_size, num_branches=db.num_branches,
+                    threshold=db.threshold, log_threshold=db.log_threshold)
+    finally:
+        stop.set()
+        t.join()
+    grown = peak[0] - before
+    assert grown < 1 << 30, f"create() from the sparse descriptor grew the process by {grown >> 20} MiB"
+    with pl:
+        got = pl.place_packed(data, offs)
+    assert_rows_match(*got, *oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
+
+
+def test_amino_k7_100k_reads(amino_k7, oracle_lib, monkeypatch):
+    """configs[3] beyond a handful of reads: 100 000 protein reads of 300 residues (B / Z / X / J / * in a quarter of
+    them) through the size-independent properties -- well-formed rows, idempotent, independent of the order of
+    the batch -- and a random sample of them through the oracle, bit for bit (as test_fullsize_gpu does for DNA)."""
+    from epik_amd.placer import Placer
+    db, _, _ = amino_k7
+    monkeypatch.delenv("EPIK_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)   # what create() chooses: the filtered layout
+    n = 100_000
+    data, offs = synth.reads_hitting(db, n, 300, hit_rate=0.25, seed=52, dirty="BZXJ*")
+    with Placer.from_synth(db) as pl:
+        first = pl.place_packed(data, offs)
+        again = pl.place_packed(data, offs)
+        perm = np.random.default_rng(6).permutation(n)
+        shuffled = pl.place_packed(data.reshape(n, 300)[perm].reshape(-1), offs)
+    rows, n_rows, counts = first
+    keep = rows.shape[1]
+    assert n_rows.min() >= 1 and n_rows.max() <= keep
+    valid = np.arange(keep)[None, :] < n_rows[:, None]
+    assert rows["branch"][valid].max() < db.num_branches
+    assert (np.diff(rows["score"], axis=1)[valid[:, 1:]] <= 0).all(), "scores must be sorted in descending order"
+    lwr = np.where(valid, rows["lwr"], 0.0)
+    assert (lwr >= 0).all() and (lwr.sum(axis=1) <= 1.0 + 1e-9).all() and (lwr[:, :1] >= lwr).all()
+    assert (lwr[valid] >= 0.01 * np.repeat(lwr[:, 0], n_rows) - 1e-15).all()     # filter_by_ratio, place.cpp:188-199
+    assert (counts[valid] <= 294).all()
+    for a, b in zip(first, again):
+        assert a.tobytes() == b.tobytes()
+    for a, b in zip(first, shuffled):
+        assert a[perm].tobytes() == b.tobytes()
+    pick = np.sort(np.random.default_rng(10).choice(n, size=2500, replace=False))
+    sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
+    ref = oracle_lib.Oracle.from_synth(db).place(sample, sample_offs, num_threads=0)
+    assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
+
+
 @pytest.fixture(scope="module")
 def large_tree(gpu_available):
     assert gpu_available
