@@ -90,6 +90,8 @@ class Plan(ctypes.Structure):
         ("filter_bytes", ctypes.c_uint64),
         ("posting_bytes", ctypes.c_uint64),
         ("kept_entries", ctypes.c_uint64),
+        ("run_coded", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 

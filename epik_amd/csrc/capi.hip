@@ -460,9 +460,9 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
             for (uint32_t wpb = 4; wpb >= 1; wpb >>= 1) {
                 const uint32_t block_bytes = wpb * g.lds_wave_bytes;
                 if (block_bytes > kMaxLdsPerBlock) continue;
-                CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, block_bytes));
+                CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, p->plan.runs, counts, block_bytes));
                 int per_cu = 0;
-                CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, counts, (int)(wpb * 64u), block_bytes, &per_cu));
+                CREATE_TRY(epik_amd::place_reads_occupancy(p->layout, p->plan.runs, counts, (int)(wpb * 64u), block_bytes, &per_cu));
                 const uint32_t lds_units = (block_bytes + epik_amd::kLdsGranule - 1u) / epik_amd::kLdsGranule;
                 per_cu = std::min<int>(per_cu, (int)(128u / std::max(lds_units, 1u)));
                 if (per_cu < 1) per_cu = 1;
@@ -474,7 +474,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
                 }
             }
             g.resident_waves = best_waves;
-            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, counts, g.lds_block_bytes));
+            CREATE_TRY(epik_amd::set_place_reads_lds_limit(p->layout, p->plan.runs, counts, g.lds_block_bytes));
             CREATE_TRY(epik_amd::set_finish_reads_lds_limit(counts, g.lds_block_bytes));
         }
     }
@@ -560,6 +560,7 @@ int epik_amd_placer_plan(const epik_amd_placer_desc *d, uint32_t shard_index, ui
         out->filter_bytes = plan.filter_bytes;
         out->posting_bytes = plan.posting_bytes;
         out->kept_entries = plan.kept_entries;
+        out->run_coded = plan.runs ? 1u : 0u;
         return EPIK_AMD_OK;
     } catch (const std::exception &e) {
         return fail(EPIK_AMD_ERR_INVALID, std::string("plan: ") + e.what());
@@ -859,7 +860,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         HIP_TRY(epik_amd::launch_finish_reads(pp, p->counts, dim3((unsigned)blocks), dim3(g.waves_per_block * 64u),
                                               g.lds_block_bytes, stream));
     } else {
-        HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->counts, dim3((unsigned)blocks),
+        HIP_TRY(epik_amd::launch_place_reads(pp, p->layout, p->plan.runs, p->counts, dim3((unsigned)blocks),
                                              dim3(g.waves_per_block * 64u), g.lds_block_bytes, stream));
     }
     if (timed) {
@@ -1203,7 +1204,7 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
         tp.passes = p->team_passes;
         HIP_TRY(epik_amd::launch_team_algorithmic_bytes(tp, p->team_waves, p->d_total, s));
     } else {
-        HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->layout, p->d_total, s));
+        HIP_TRY(epik_amd::launch_algorithmic_bytes(pp, p->layout, p->plan.runs, p->d_total, s));
     }
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, p->d_total, sizeof(total), hipMemcpyDeviceToHost, s));

@@ -54,7 +54,43 @@ void write_chunks(uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len, ui
     }
 }
 
-inline uint64_t packed_lines(uint64_t len) { return (len * 6u + 127u) / 128u; }
+
+// The run-coded form of the packed layouts (place_device.hpp, kRuns): a list whose branches are one ascending
+// run b, b + 1, ... is stored without its cells -- 4 bytes per posting -- and its table entry carries the first
+// cell.  Lists of 65536 postings or more (no tree of the one-wavefront kernels has that many branches) and lists
+// that are not a run stay explicit.  EPIK_AMD_RUNS=0: every list explicit (measurements).
+// Run-coding pays where the kernel is bound by what HBM delivers: measured (r03, N = 999, 1 M x 150 bp reads), the
+// k = 11 database (1.13 GB explicit) gains 5-8 % from a third fewer lines per list, while the headline database
+// (285 MB, served mostly by the 256 MiB Infinity Cache) loses 3 % to the three more instructions per chunk.  So:
+// when the explicit image would be beyond twice the Infinity Cache.  EPIK_AMD_RUNS=0 / 1 forces it.
+inline bool choose_runs(uint64_t explicit_image_bytes, uint64_t postings, uint64_t postings_in_runs)
+{
+    if (const char *e = std::getenv("EPIK_AMD_RUNS")) return e[0] != '0';
+    // (... and nearly all postings in runs: the kernels with the run path wait longer than needed behind chunks
+    // with explicit cells, place_device.hpp)
+    return explicit_image_bytes > (512ull << 20) && postings_in_runs * 10u >= postings * 9u;
+}
+inline bool is_run(const epik_amd_pkdb_value *v, uint64_t len)
+{
+    if (len == 0 || len >= 65536u) return false;
+    for (uint64_t i = 1; i < len; ++i)
+        if (v[i].branch != v[i - 1].branch + 1u) return false;
+    return true;
+}
+// bytes / lines of a list in that form, and the first word of its table entry
+inline uint64_t run_lines(const epik_amd_pkdb_value *v, uint64_t len, bool runs)
+{
+    return ((runs && is_run(v, len) ? len * 4u : len * 6u) + 127u) / 128u;
+}
+inline uint32_t run_entry_word(const epik_amd_pkdb_value *v, uint64_t len, bool runs, uint32_t top)
+{
+    // len | first cell << 16; first cell 0 = explicit cells (cell 0 is the dummy row, never a posting's)
+    return (uint32_t)len | ((runs && is_run(v, len)) ? (top - v[0].branch) << 16 : 0u);
+}
+void write_run_scores(uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len)
+{
+    for (uint64_t j = 0; j < len; ++j) std::memcpy(dst + 4u * j, &src[j].score, 4);
+}
 inline uint32_t pad4(uint32_t bytes) { return (bytes + 3u) & ~3u; }
 
 struct TeamChoice {
@@ -299,10 +335,27 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     plan.layout = paired ? DbLayout::kPaired : filtered ? DbLayout::kFiltered : DbLayout::kPacked;
     uint64_t lines = 0;
     const uint64_t quarter = d->num_keys / 4;
+    if (plan.n_pad > 65536u) return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the packed layouts");
+    const uint64_t table_bytes = d->num_keys * (paired ? 16u : 8u) + 8u;
+    {   // how large the image is with every list explicit decides whether the lists are run-coded
+        uint64_t explicit_lines = 0, in_runs = 0;
+        Cursor walk(src);
+        for (uint64_t key = 0; key < d->num_keys; ++key) {
+            uint64_t first = 0;
+            const uint64_t len = walk.list(key, &first);
+            explicit_lines += (len * 6u + 127u) / 128u;
+            if (is_run(d->values + first, len)) in_runs += len;
+        }
+        plan.runs = choose_runs(explicit_lines * 128u + table_bytes, plan.kept_entries, in_runs);
+    }
+    const bool runs = plan.runs;
     Cursor walk(src);
     for (uint64_t key = 0; key < d->num_keys; ++key) {
         if (paired && quarter && key % quarter == 0 && key / quarter < 4) plan.quarter_lines[key / quarter] = lines;
-        lines += packed_lines(walk.list(key));
+        uint64_t first = 0;
+        const uint64_t len = walk.list(key, &first);
+        if (len >= 65536u) return fail(EPIK_AMD_ERR_INVALID, "a posting list of 65536 entries or more in a tree of fewer branches");
+        lines += run_lines(d->values + first, len, runs);
     }
     if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
     plan.posting_bytes = lines * 128u + 512u;
@@ -441,14 +494,19 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
         }
         // ---- packed lists; plain, paired or filtered table -----------------------------------------------
         const uint32_t top = plan.n_pad - 1u;
+        const bool runs = plan.runs;
         {
             Cursor walk(src);
             for (uint64_t key = 0; key < num_keys; ++key) {
                 uint64_t first = 0;
                 const uint64_t len = walk.list(key, &first);
                 if (len == 0) continue;
-                uint8_t *dst = postings.reserve((size_t)packed_lines(len) * 128u);
-                write_chunks(dst, d->values + first, len, top);
+                const epik_amd_pkdb_value *v = d->values + first;
+                uint8_t *dst = postings.reserve((size_t)run_lines(v, len, runs) * 128u);
+                if (runs && is_run(v, len))
+                    write_run_scores(dst, v, len);
+                else
+                    write_chunks(dst, v, len, top);
             }
         }
         postings.reserve(512);
@@ -466,16 +524,18 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             for (uint64_t x = 0; x < blocks; ++x) {
                 uint8_t *block = out.next();
                 for (uint32_t a = 0; a < 4; ++a) {
-                    const uint64_t len = quarter_at[a].list(a * blocks + x);
-                    put_u32(block + 8 * a, (uint32_t)len);
+                    uint64_t first = 0;
+                    const uint64_t len = quarter_at[a].list(a * blocks + x, &first);
+                    put_u32(block + 8 * a, run_entry_word(d->values + first, len, runs, top));
                     put_u32(block + 8 * a + 4, (uint32_t)quarter_line[a]);
-                    quarter_line[a] += packed_lines(len);
+                    quarter_line[a] += run_lines(d->values + first, len, runs);
                 }
                 for (uint32_t b = 0; b < 4; ++b) {
-                    const uint64_t len = seq_at.list(x * 4 + b);
-                    put_u32(block + 32 + 8 * b, (uint32_t)len);
+                    uint64_t first = 0;
+                    const uint64_t len = seq_at.list(x * 4 + b, &first);
+                    put_u32(block + 32 + 8 * b, run_entry_word(d->values + first, len, runs, top));
                     put_u32(block + 32 + 8 * b + 4, (uint32_t)seq_line);
-                    seq_line += packed_lines(len);
+                    seq_line += run_lines(d->values + first, len, runs);
                 }
             }
             table.reserve(8);
@@ -485,10 +545,11 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             Cursor walk(src);
             for (uint64_t key = 0; key < num_keys; ++key) {
                 uint8_t *e = out.next();
-                const uint64_t len = walk.list(key);
-                put_u32(e, (uint32_t)len);
+                uint64_t first = 0;
+                const uint64_t len = walk.list(key, &first);
+                put_u32(e, run_entry_word(d->values + first, len, runs, top));
                 put_u32(e + 4, (uint32_t)line);
-                line += packed_lines(len);
+                line += run_lines(d->values + first, len, runs);
             }
             table.reserve(8);
         }

@@ -100,6 +100,7 @@ struct Plan {
     // device image
     uint64_t table_bytes = 0, filter_bytes = 0, posting_bytes = 0;
     uint64_t kept_entries = 0, present_codes = 0;
+    bool runs = false;  // packed layouts: run-coded lists (place_device.hpp, kRuns)
     uint64_t quarter_lines[4] = {0, 0, 0, 0};  // paired table: posting lines in front of each quarter of the key space
     uint32_t wave_resident[3] = {0, 0, 0};     // resident waves per CU by count width (what chose the kernel)
 };

@@ -187,8 +187,17 @@ constexpr int kRawBufferFormat = 0x00020000;  // 4th descriptor word: untyped 32
 template <typename OffT>
 struct CompactLayout {
     static constexpr int kLoads = 1;  // vector-memory instructions per chunk
+    static constexpr int kWaitLoads = 1;  // ... that the ring's waits may count on per chunk
     static constexpr uint32_t kChunkBytes = 64u * 8u;
     static constexpr int kFields = 3;  // base lo, base hi, bytes
+    // what lookup() returns as `len` is the list's length and nothing else
+    __device__ static __forceinline__ uint32_t length(uint32_t w) { return w; }
+    // the descriptor of chunk c (`cnt` postings) of the list at byte offset `addr`
+    __device__ static __forceinline__ uint64_t descriptor(const PlaceParams &p, uint64_t addr, uint32_t /*w*/, uint32_t c, uint64_t cnt)
+    {
+        return (uint64_t)(p.postings + addr + (uint64_t)c * kChunkBytes) | (cnt << 48);
+    }
+    __device__ static __forceinline__ uint64_t null_descriptor(const PlaceParams &p) { return (uint64_t)p.postings; }
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t /*position*/,
                                                   uint64_t &addr, uint32_t &len)
     {
@@ -203,7 +212,7 @@ struct CompactLayout {
     {
         if (wanted) lookup(p, t.key, position, addr, len);
     }
-    __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
+    __device__ static __forceinline__ void prepare(const PlaceParams &, uint64_t d, uint32_t (&f)[kFields])
     {
         const uint32_t hi = (uint32_t)(d >> 32);
         f[0] = (uint32_t)d;
@@ -251,12 +260,39 @@ struct CompactLayout {
 // word per (k-1)-mer X: bit a says whether a.X has a list, bit sigma + b whether X.b has one.
 // Two consecutive k-mers read the same word; only the k-mers that are present go on to the
 // table (keyed by code, as in the plain layout).  8 bytes of filter per (k-1)-mer.
+//
+// kRuns (the layouts of the one-wavefront kernels): a list whose branches are ONE ascending run b, b+1, b+2, ...
+// -- a clade, what most lists of a phylo-k-mer database are (SURVEY.md 8d models all of them so) -- is stored
+// without its cells: f32 score[cnt] per chunk, 4 bytes per posting instead of 6, and the cells come out of the
+// table entry, whose first word is then len | first cell << 16 (0: the cells are stored, as above; cell 0 is the
+// dummy row, never a posting's).  A list of 60 postings takes two 128-byte lines instead of three: a third fewer
+// lines requested per read, which is what bounds these kernels.
 enum : int { kPlainTable = 0, kPairedTable = 1, kFilteredTable = 2 };
-template <int kTable>
+template <int kTable, bool kRuns = false>
 struct PackedLayout {
     static constexpr int kLoads = 2;
+    // kRuns: a run chunk is ONE load (its scores), a chunk with explicit cells two -- the cells FIRST, so that the
+    // scores' arrival says both are there (loads return in order).  The ring waits for "at most N younger loads in
+    // flight": with a load per chunk counted it is exact for runs and waits longer than needed behind explicit
+    // chunks -- never too short.  (The builder run-codes databases whose postings are nearly all in runs.)
+    static constexpr int kWaitLoads = kRuns ? 1 : 2;
     static constexpr uint32_t kChunkBytes = 64u * 6u;
-    static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk
+    static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk (kRuns: | the chunk's first cell << 7)
+    __device__ static __forceinline__ uint32_t length(uint32_t w) { return kRuns ? (w & 0xffffu) : w; }
+    // kRuns: byte offset / 2 from the start of the posting region (37 bits: 256 GiB) | cnt << 37 | first cell of the
+    // chunk << 44 (0: explicit cells); else the chunk's address | cnt << 48
+    __device__ static __forceinline__ uint64_t descriptor(const PlaceParams &p, uint64_t addr, uint32_t w, uint32_t c, uint64_t cnt)
+    {
+        if constexpr (kRuns) {
+            const uint32_t first_cell = w >> 16;
+            const uint64_t at = addr + (uint64_t)c * (first_cell ? 256u : kChunkBytes);
+            const uint64_t cell = first_cell ? (uint64_t)(first_cell - (c << 6)) : 0ull;  // the run goes down the cells
+            return (at >> 1) | (cnt << 37) | (cell << 44);
+        } else {
+            return (uint64_t)(p.postings + addr + (uint64_t)c * kChunkBytes) | (cnt << 48);
+        }
+    }
+    __device__ static __forceinline__ uint64_t null_descriptor(const PlaceParams &p) { return kRuns ? 0ull : (uint64_t)p.postings; }
     // by code alone (the cold paths; the filter only saves traffic, the table is complete)
     __device__ static __forceinline__ void lookup(const PlaceParams &p, uint32_t key, uint32_t position,
                                                   uint64_t &addr, uint32_t &len)
@@ -286,12 +322,20 @@ struct PackedLayout {
         }
         if (wanted) lookup(p, t.key, position, addr, len);
     }
-    __device__ static __forceinline__ void prepare(uint64_t d, uint32_t (&f)[kFields])
+    __device__ static __forceinline__ void prepare(const PlaceParams &p, uint64_t d, uint32_t (&f)[kFields])
     {
-        const uint32_t hi = (uint32_t)(d >> 32);
-        f[0] = (uint32_t)d;
-        f[1] = hi & 0xffffu;
-        f[2] = hi >> 16;
+        if constexpr (kRuns) {
+            const uint64_t a = (uint64_t)p.postings + ((d & ((1ull << 37) - 1ull)) << 1);
+            f[0] = (uint32_t)a;
+            f[1] = (uint32_t)(a >> 32) & 0xffffu;
+            f[2] = (uint32_t)(d >> 37);  // cnt (7 bits) | first cell << 7
+        } else {
+            (void)p;
+            const uint32_t hi = (uint32_t)(d >> 32);
+            f[0] = (uint32_t)d;
+            f[1] = hi & 0xffffu;
+            f[2] = hi >> 16;
+        }
     }
     // One descriptor over the whole chunk; the cell load adds the scalar offset 4*cnt, which
     // takes part in the range check: lane l < cnt reads score l and cell l, every other lane
@@ -299,16 +343,44 @@ struct PackedLayout {
     __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
                                                  uint32_t &score)
     {
-        // f[2] sits in a scalar register (v_readlane): the two products are scalar instructions
-        const v4i srd = {(int)f[0], (int)f[1], (int)(f[2] * 6u), kRawBufferFormat};
-        asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
-                     : "=&v"(score), "=&v"(cell)
-                     : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[2] * 4u)
-                     : "memory");
+        // f[2] sits in a scalar register (v_readlane): the products are scalar instructions
+        if constexpr (kRuns) {
+            // A run (first cell != 0): the cells are first_cell, first_cell - 1, ... down the lanes -- nothing to
+            // fetch for them; the lanes behind the chunk's end get cell 0, the dummy row, as a load past the end
+            // would give them.
+            // ONE asm statement with the branch inside: two statements in the arms of an `if` would let the
+            // compiler give the slot different registers in each arm and copy them where the arms meet.
+            const uint32_t cnt = f[2] & 127u, first_cell = f[2] >> 7;
+            const v4i srd = {(int)f[0], (int)f[1], (int)(cnt * (first_cell ? 4u : 6u)), kRawBufferFormat};
+            asm volatile("s_nop 4\n\t"
+                         "s_cmp_eq_u32 %6, 0\n\t"
+                         "s_cbranch_scc1 .Lexplicit%=\n\t"
+                         "buffer_load_dword %0, %2, %4, 0 offen\n\t"
+                         "v_sub_u32 %1, %6, %7\n\t"
+                         "v_cmp_gt_u32 vcc, %8, %7\n\t"
+                         "v_cndmask_b32 %1, 0, %1, vcc\n\t"
+                         "s_branch .Lissued%=\n"
+                         ".Lexplicit%=:\n\t"
+                         "buffer_load_ushort %1, %3, %4, %5 offen\n\t"
+                         "buffer_load_dword %0, %2, %4, 0 offen\n"
+                         ".Lissued%=:"
+                         : "=&v"(score), "=&v"(cell)
+                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u), "s"(first_cell), "v"(lane), "s"(cnt)
+                         : "memory", "vcc", "scc");
+        } else {
+            const v4i srd = {(int)f[0], (int)f[1], (int)(f[2] * 6u), kRawBufferFormat};
+            asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
+                         : "=&v"(score), "=&v"(cell)
+                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[2] * 4u)
+                         : "memory");
+        }
     }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint32_t rows_pad, uint64_t addr,
-                                                         uint32_t len, uint32_t j)
+                                                         uint32_t w, uint32_t j)
     {
+        const uint32_t len = length(w);
+        if (kRuns && (w >> 16) != 0u)  // a run: scores back to back, the cells count down from the first
+            return make_uint2(rows_pad - 1u - ((w >> 16) - j), *reinterpret_cast<const uint32_t *>(p.postings + addr + 4ull * j));
         const uint32_t chunk = j >> 6, r = j & 63u;
         const uint32_t rest = len - (chunk << 6);
         const uint32_t cnt = rest < 64u ? rest : 64u;
@@ -539,7 +611,6 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
     typedef __attribute__((address_space(3))) float lds_f32;
     typedef __attribute__((address_space(3))) CountT lds_count;
     const int lane = lane_id();
-    (void)p;
     uint32_t ring_c[kDepth], ring_s[kDepth];
 #pragma unroll
     for (int i = 0; i < kDepth; ++i) {
@@ -593,7 +664,7 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
     uint64_t d_next = chunks[kFirst + (lane & (kDepth - 1))];  // descriptors of the first trip, lane i <-> stage i
     for (uint32_t c0 = kFirst; c0 < n_padded; c0 += kDepth) {
         uint32_t field[Layout::kFields];
-        Layout::prepare(d_next, field);
+        Layout::prepare(p, d_next, field);
         d_next = chunks[c0 + kDepth + (lane & (kDepth - 1))];  // next trip (spare entries behind the end)
 #pragma unroll
         for (int i = 0; i < kDepth; ++i) {
@@ -604,7 +675,7 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
                 [&]() {
 #pragma unroll
                     for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
-                    addresses(ring_c[(i + 1) % kDepth], std::integral_constant<int, Layout::kLoads *(kDepth - 2)>{}, sa_next, ca_next, score_top,
+                    addresses(ring_c[(i + 1) % kDepth], std::integral_constant<int, Layout::kWaitLoads *(kDepth - 2)>{}, sa_next, ca_next, score_top,
                               count_top);
                 },
                 [&]() { Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]); });
@@ -713,11 +784,12 @@ __device__ __attribute__((noinline)) void place_ambiguous(const PlaceParams *__r
                     // position of this key among the read's ambiguous keys (k-mer, then state)
                     const uint32_t order = ((uint32_t)tile_pos + (uint32_t)m) * sigma + st;
                     uint64_t b0;
-                    uint32_t n;
-                    ctx.template lookup<Layout>(p, key, b0, n);
+                    uint32_t w;  // the list's length (with the run layouts: | its first cell << 16)
+                    ctx.template lookup<Layout>(p, key, b0, w);
+                    const uint32_t n = Layout::length(w);
                     for (uint32_t off = 0; off < n; off += kWave) {
                         if (off + (uint32_t)lane < n) {
-                            const uint2 e = Layout::load_posting(p, rows_pad, b0, n, off + (uint32_t)lane);  // {row, score bits}
+                            const uint2 e = Layout::load_posting(p, rows_pad, b0, w, off + (uint32_t)lane);  // {row, score bits}
                             uint2 cv = lds.load(e.x);
                             const uint32_t c = cv.y;
                             // Only the first ambiguous key that reaches a branch scores it:

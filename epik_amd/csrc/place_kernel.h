@@ -152,15 +152,15 @@ hipError_t set_team_stream_lds_limit(int waves, int counts);
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream);
 
-hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts, dim3 grid, dim3 block,
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool runs, int counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream);
-hipError_t set_place_reads_lds_limit(DbLayout layout, int counts, size_t lds_bytes);
-hipError_t place_reads_occupancy(DbLayout layout, int counts, int block_threads, size_t lds_bytes,
+hipError_t set_place_reads_lds_limit(DbLayout layout, bool runs, int counts, size_t lds_bytes);
+hipError_t place_reads_occupancy(DbLayout layout, bool runs, int counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu);
 hipError_t launch_finish_reads(const PlaceParams &p, int counts, dim3 grid, dim3 block, size_t lds_bytes,
                                hipStream_t stream);
 hipError_t set_finish_reads_lds_limit(int counts, size_t lds_bytes);
-hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
+hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, bool runs, unsigned long long *d_total,
                                     hipStream_t stream);
 
 }  // namespace epik_amd

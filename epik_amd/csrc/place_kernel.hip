@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
             uint32_t total = 0;
 #pragma unroll
             for (int t = 0; t < kTilesPerPass; ++t) {
-                nch[t] = (llen[t] + (uint32_t)kWave - 1u) >> 6;
+                nch[t] = (Layout::length(llen[t]) + (uint32_t)kWave - 1u) >> 6;
                 const uint32_t incl = wave_incl_scan_u32(nch[t]);
                 first[t] = total + incl - nch[t];
                 total += __builtin_amdgcn_readlane(incl, 63);
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                     for (uint32_t c = 0; c < kOwnChunks; ++c) {
                         const uint32_t idx = first[t] + c - w0;  // wraps when in front of the window
                         if (nch[t] > c && idx < kChunkCap) {
-                            const uint32_t rest = llen[t] - (c << 6);
+                            const uint32_t rest = Layout::length(llen[t]) - (c << 6);
                             const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                            chunks[idx] = chunk_address<Layout>(p, start[t], c) | (cnt << 48);
+                            chunks[idx] = Layout::descriptor(p, start[t], llen[t], c, cnt);
                         }
                     }
                     uint64_t long_lists = __ballot(nch[t] > kOwnChunks);
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                         const int m = __builtin_ctzll(long_lists);
                         long_lists &= long_lists - 1;
                         const uint32_t l_first = __builtin_amdgcn_readlane(first[t], m);
-                        const uint32_t l_len = __builtin_amdgcn_readlane(llen[t], m);
+                        const uint32_t l_w = __builtin_amdgcn_readlane(llen[t], m);
+                        const uint32_t l_len = Layout::length(l_w);
                         const uint64_t l_start = readlane_u64(start[t], m);
                         // lists of more than 64 + kOwnChunks chunks: the lanes take further turns
                         for (uint32_t c = (uint32_t)lane + kOwnChunks; (c << 6) < l_len; c += kWave) {
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                             if (idx < kChunkCap) {
                                 const uint32_t rest = l_len - (c << 6);
                                 const uint64_t cnt = rest < (uint32_t)kWave ? rest : (uint32_t)kWave;
-                                chunks[idx] = chunk_address<Layout>(p, l_start, c) | (cnt << 48);
+                                chunks[idx] = Layout::descriptor(p, l_start, l_w, c, cnt);
                             }
                         }
                     }
                 }
-                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = null_chunk(p);
+                if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = Layout::null_descriptor(p);
 
                 // (3) stream the chunks through the ring of kRing in-flight loads (place_device.hpp)
                 stream_round<Layout, CountT>(p, chunks, n_padded, score_top, count_top);
@@ -294,7 +295,7 @@ __global__ void algorithmic_bytes_kernel(PlaceParams p, unsigned long long *tota
         uint64_t addr;
         uint32_t llen;
         Layout::lookup(p, key, 0u, addr, llen);
-        return llen;
+        return Layout::length(llen);
     });
 }
 
@@ -311,15 +312,20 @@ hipError_t dispatch_counts(int counts, F &&f)
     }
     return hipErrorInvalidValue;
 }
+// runs: the packed lists in their run-coded form (place_device.hpp, kRuns; chosen by the image builder for
+// databases well beyond the Infinity Cache)
 template <typename F>
-hipError_t dispatch(DbLayout layout, int counts, F &&f)
+hipError_t dispatch(DbLayout layout, bool runs, int counts, F &&f)
 {
     switch (layout) {
         case DbLayout::kCompact32: return dispatch_counts<CompactLayout<uint32_t>>(counts, f);
         case DbLayout::kCompact64: return dispatch_counts<CompactLayout<uint64_t>>(counts, f);
-        case DbLayout::kPacked: return dispatch_counts<PackedLayout<kPlainTable>>(counts, f);
-        case DbLayout::kPaired: return dispatch_counts<PackedLayout<kPairedTable>>(counts, f);
-        case DbLayout::kFiltered: return dispatch_counts<PackedLayout<kFilteredTable>>(counts, f);
+        case DbLayout::kPacked:
+            return runs ? dispatch_counts<PackedLayout<kPlainTable, true>>(counts, f) : dispatch_counts<PackedLayout<kPlainTable>>(counts, f);
+        case DbLayout::kPaired:
+            return runs ? dispatch_counts<PackedLayout<kPairedTable, true>>(counts, f) : dispatch_counts<PackedLayout<kPairedTable>>(counts, f);
+        case DbLayout::kFiltered:
+            return runs ? dispatch_counts<PackedLayout<kFilteredTable, true>>(counts, f) : dispatch_counts<PackedLayout<kFilteredTable>>(counts, f);
         case DbLayout::kTeam: break;  // team_kernel.hip
     }
     return hipErrorInvalidValue;
@@ -327,10 +333,10 @@ hipError_t dispatch(DbLayout layout, int counts, F &&f)
 
 }  // namespace
 
-hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts, dim3 grid, dim3 block,
+hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool runs, int counts, dim3 grid, dim3 block,
                               size_t lds_bytes, hipStream_t stream)
 {
-    return dispatch(layout, counts, [&]<typename L, typename C>() {
+    return dispatch(layout, runs, counts, [&]<typename L, typename C>() {
         hipLaunchKernelGGL((place_reads_kernel<L, C>), grid, block, lds_bytes, stream, p);
         return hipGetLastError();
     });
@@ -339,18 +345,18 @@ hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, int counts,
 // The attribute is a cap per kernel and process, not a reservation (what a launch occupies is what it
 // asks for): it is always raised to the whole LDS of a CU, so that placers of different trees alive in
 // one process can never lower it under each other's launches.
-hipError_t set_place_reads_lds_limit(DbLayout layout, int counts, size_t /*lds_bytes*/)
+hipError_t set_place_reads_lds_limit(DbLayout layout, bool runs, int counts, size_t /*lds_bytes*/)
 {
-    return dispatch(layout, counts, [&]<typename L, typename C>() {
+    return dispatch(layout, runs, counts, [&]<typename L, typename C>() {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(&place_reads_kernel<L, C>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     });
 }
 
-hipError_t place_reads_occupancy(DbLayout layout, int counts, int block_threads, size_t lds_bytes,
+hipError_t place_reads_occupancy(DbLayout layout, bool runs, int counts, int block_threads, size_t lds_bytes,
                                  int *blocks_per_cu)
 {
-    return dispatch(layout, counts, [&]<typename L, typename C>() {
+    return dispatch(layout, runs, counts, [&]<typename L, typename C>() {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, place_reads_kernel<L, C>,
                                                             block_threads, lds_bytes);
     });
@@ -373,12 +379,12 @@ hipError_t set_finish_reads_lds_limit(int counts, size_t /*lds_bytes*/)
     });
 }
 
-hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, unsigned long long *d_total,
+hipError_t launch_algorithmic_bytes(const PlaceParams &p, DbLayout layout, bool runs, unsigned long long *d_total,
                                     hipStream_t stream)
 {
     const dim3 block(256);
     const dim3 grid((unsigned)((p.n_reads + 255) / 256));
-    return dispatch(layout, kCounts16, [&]<typename L, typename C>() {
+    return dispatch(layout, runs, kCounts16, [&]<typename L, typename C>() {
         hipLaunchKernelGGL((algorithmic_bytes_kernel<L>), grid, block, 0, stream, p, d_total);
         return hipGetLastError();
     });

@@ -128,6 +128,9 @@ typedef struct {
     uint64_t filter_bytes;
     uint64_t posting_bytes;
     uint64_t kept_entries;   /* postings this placer keeps (its shard) */
+    uint32_t run_coded;      /* 1: lists that are one ascending run of branches are stored without their cells
+                                (4 bytes per posting; databases well beyond the Infinity Cache) */
+    uint32_t reserved;
 } epik_amd_plan;
 int epik_amd_placer_plan(const epik_amd_placer_desc *desc, uint32_t shard_index, uint32_t shard_count,
                          uint64_t free_bytes, epik_amd_plan *plan);

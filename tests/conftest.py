@@ -35,11 +35,15 @@ def select_kernel(monkeypatch, name):
     (paired, filtered, packed, compact), or teamW[xP] -- the team placement as front kernel +
     streaming kernel (team_stream.hip) --, teamW[xP]-classic -- team_place_kernel alone --, or
     teamW[xP]-smallpool -- a descriptor pool so small that some reads of a batch fall to
-    team_place_kernel behind the streaming kernel.  Any of them with -fewblocks: a device that holds two
+    team_place_kernel behind the streaming kernel.  A layout of the one-wavefront kernel with -runs: lists that
+    are one ascending run of branches stored without their cells (the kernels with the run path).  Any of them with -fewblocks: a device that holds two
     workgroups (EPIK_AMD_MAX_BLOCKS), so that the waves of a test-sized batch place several reads one after
     the other on the grids of a million-read batch (capi.hip: spread_grid)."""
-    for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT", "EPIK_AMD_MAX_BLOCKS"):
+    for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT", "EPIK_AMD_MAX_BLOCKS", "EPIK_AMD_RUNS"):
         monkeypatch.delenv(var, raising=False)
+    if name.endswith("-runs"):  # the packed lists run-coded (by itself the builder does that for large databases only)
+        name = name[:-len("-runs")]
+        monkeypatch.setenv("EPIK_AMD_RUNS", "1")
     if name.endswith("-fewblocks"):
         name = name[:-len("-fewblocks")]
         monkeypatch.setenv("EPIK_AMD_MAX_BLOCKS", "2")

@@ -33,15 +33,30 @@ def _pad(b, n):
     return b + bytes(-len(b) % n)
 
 
-def _reference_packed(db, n_pad):
+def _is_run(values, b, e):
+    """A list whose branches are one ascending run b, b + 1, ...: stored without its cells (place_device.hpp, kRuns)."""
+    br = values["branch"][b:e].astype(np.int64)
+    return e > b and bool((np.diff(br) == 1).all())
+
+
+def _reference_packed(db, n_pad, runs=True):
+    """lens[key] = the first word of the table entry: len | first cell << 16 for a run (scores only in the posting
+    region, 4 bytes each), len alone for a list with explicit cells (6 bytes per posting)."""
     top = n_pad - 1
     post, lens, lines = bytearray(), [], []
     for b, e in _lists(db):
-        lens.append(e - b)
+        run = runs and _is_run(db.values, b, e)
+        lens.append((e - b) | ((top - int(db.values["branch"][b])) << 16 if run else 0))
         lines.append(len(post) // LINE)
-        post += _pad(_chunks(db.values, b, e, top), LINE)
+        post += _pad(db.values["score"][b:e].astype("<f4").tobytes() if run else _chunks(db.values, b, e, top), LINE)
     post += bytes(512)
     return np.array(lens, np.uint32), np.array(lines, np.uint32), bytes(post)
+
+
+@pytest.fixture(scope="module")
+def scattered_db():
+    tree = synth.make_tree(60, seed=7)
+    return synth.make_db(tree.num_nodes, kmer_size=5, seed=8, p_present=0.5, lognormal=(2.5, 1.5), scattered=True)
 
 
 @pytest.fixture(scope="module")
@@ -56,9 +71,19 @@ def amino_db():
     return synth.make_db(tree.num_nodes, states="amino", kmer_size=3, seed=10, p_present=0.1, lognormal=(1.0, 1.0))
 
 
-def test_packed_and_paired_tables(db, monkeypatch):
+@pytest.mark.parametrize("which,runs", [("runs", True), ("scattered", True), ("runs", False)])
+def test_packed_and_paired_tables(db, scattered_db, which, runs, monkeypatch):
+    """`runs`: every list of the database a contiguous run (the SURVEY 8d model) -- stored without cells;
+    `scattered`: lists of arbitrary distinct branches -- a few happen to be runs, most keep their cells;
+    EPIK_AMD_RUNS=0: every list explicit."""
+    db = db if which == "runs" else scattered_db
+    # (by itself the builder run-codes databases of more than 512 MB only: DESIGN.md 4)
+    monkeypatch.setenv("EPIK_AMD_RUNS", "1" if runs else "0")
     n_pad = (db.num_branches + 1 + 63) // 64 * 64
-    lens, lines, post = _reference_packed(db, n_pad)
+    lens, lines, post = _reference_packed(db, n_pad, runs)
+    if runs:
+        n_runs = int(((lens >> 16) != 0).sum())
+        assert (n_runs > 0.9 * int((lens != 0).sum())) if which == "runs" else (0 < n_runs < 0.5 * int((lens != 0).sum()))
     monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
     monkeypatch.setenv("EPIK_AMD_LAYOUT", "packed")
     plan, table, filt, postings = eplacer.build_image(db)
@@ -88,7 +113,7 @@ def test_filtered_layout_and_shard(amino_db, monkeypatch):
         lens = np.diff(db.offsets.astype(np.int64))
         lens[np.arange(db.num_keys) % shard_count != shard_index] = 0
         assert plan.kept_entries == int(lens.sum())
-        assert table[:-8].view(np.uint32).reshape(-1, 2)[:, 0].tolist() == lens.tolist()
+        assert (table[:-8].view(np.uint32).reshape(-1, 2)[:, 0] & 0xFFFF).tolist() == lens.tolist()
         words = filt.view(np.uint64)
         for x in range(blocks):
             want = 0
@@ -161,9 +186,15 @@ def test_team_layout(db, kernel, waves, table, monkeypatch):
 def test_plan_chooses_the_kernel_by_tree_size(monkeypatch):
     monkeypatch.delenv("EPIK_AMD_KERNEL", raising=False)
     monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
+    monkeypatch.delenv("EPIK_AMD_RUNS", raising=False)
     small = synth.make_db(999, kmer_size=6, seed=1)
     p = eplacer.plan(small)
     assert p.kernel == 0 and p.layout == 3 and list(p.resident_waves) == [20, 20, 16]
+    assert p.run_coded == 0      # a database the Infinity Cache holds keeps its cells (the kernel without the run path)
+    monkeypatch.setenv("EPIK_AMD_RUNS", "1")
+    q = eplacer.plan(small)
+    assert q.run_coded == 1 and q.posting_bytes < 0.8 * p.posting_bytes
+    monkeypatch.delenv("EPIK_AMD_RUNS")
     large = synth.make_db(9999, kmer_size=6, seed=1)
     p = eplacer.plan(large)
     assert p.kernel == 1 and p.team_passes == 1 and p.team_waves * p.slice_rows >= 9999
