@@ -80,6 +80,8 @@ const char *epik_amd_last_error(void) { return g_last_error.c_str(); }
 void epik_amd_placer_destroy(epik_amd_placer *p)
 {
     if (!p) return;
+    if (p->shard_state && p->shard_state_free) p->shard_state_free(p->shard_state);  // (before the streams go)
+    p->shard_state = nullptr;
     (void)hipSetDevice(p->device);
 #ifdef EPIK_AMD_ABLATION
     if (p->params.dbg) {  // diagnostic build: where the waves spent their cycles, by phase

@@ -22,6 +22,9 @@ struct epik_amd_placer {
     uint8_t *d_postings = nullptr; // 6-byte postings
     uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
+    // buffers of epik_amd_placer_place_sharded, kept from call to call on the first handle of the set (shard_place.hip)
+    void *shard_state = nullptr;
+    void (*shard_state_free)(void *) = nullptr;
     std::vector<uint32_t> h_char_class;  // the same on the host (shard_place.hip: which reads may hold an ambiguous k-mer)
     epik_amd::PlaceParams params{};  // batch fields are filled per call
     epik_amd::image::Plan plan{};    // kernel, layout and sizes chosen at create()

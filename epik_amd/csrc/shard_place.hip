@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "placer_impl.hpp"
@@ -106,17 +107,38 @@ struct ShardSide {
     DevBuf recv_order[2][EPIK_AMD_MAX_SHARDS], recv_avg[2][EPIK_AMD_MAX_SHARDS], my_avg[2], my_slot[2];
     DevBuf rows[2], n_rows[2], counts[2];
     hipEvent_t arrived[2] = {nullptr, nullptr}, finished[2] = {nullptr, nullptr};
+    // its rows on their way home: pinned, so that the copy out of the device does not hold the calling thread (a
+    // copy into the caller's pageable arrays would, until everything queued in front of it has run -- the next
+    // chunk's accumulate among it); handed to the caller's arrays when the set is waited for
+    struct HostOut {
+        void *p = nullptr;
+        size_t cap = 0;
+        hipError_t reserve(size_t bytes)
+        {
+            if (bytes <= cap) return hipSuccess;
+            if (p) (void)hipHostFree(p);
+            p = nullptr, cap = 0;
+            const hipError_t e = hipHostMalloc(&p, bytes + bytes / 4 + 4096, hipHostMallocDefault);
+            if (e == hipSuccess) cap = bytes + bytes / 4 + 4096;
+            return e;
+        }
+        void release()
+        {
+            if (p) (void)hipHostFree(p);
+            p = nullptr, cap = 0;
+        }
+    } h_rows[2], h_n_rows[2], h_counts[2];
+    uint64_t out_at[2] = {0, 0}, out_reads[2] = {0, 0};  // which reads of the batch set b's rows belong to
 };
 
-struct Cleanup {
-    std::vector<ShardSide> &sides;
-    ~Cleanup()
+// The sides of a set of handles, with their buffers: kept on the set's first handle from call to call (a driver
+// places group after group of batches through the same handles), freed with it.
+struct ShardState {
+    std::vector<epik_amd_placer *> handles;
+    std::vector<ShardSide> sides;
+    bool ready = false;
+    ~ShardState()
     {
-        for (auto &s : sides) {
-            (void)hipSetDevice(s.device);
-            if (s.compute) (void)hipStreamSynchronize(s.compute);
-            if (s.copy) (void)hipStreamSynchronize(s.copy);
-        }
         for (auto &s : sides) {
             (void)hipSetDevice(s.device);
             s.seqs.release(), s.offsets.release();
@@ -126,11 +148,26 @@ struct Cleanup {
                 s.my_avg[b].release(), s.my_slot[b].release(), s.rows[b].release(), s.n_rows[b].release(), s.counts[b].release();
                 for (int g = 0; g < EPIK_AMD_MAX_SHARDS; ++g)
                     s.recv_entries[b][g].release(), s.recv_index[b][g].release(), s.recv_order[b][g].release(), s.recv_avg[b][g].release();
+                s.h_rows[b].release(), s.h_n_rows[b].release(), s.h_counts[b].release();
                 if (s.h_part[b]) (void)hipHostFree(s.h_part[b]);
                 if (s.accumulated[b]) (void)hipEventDestroy(s.accumulated[b]);
                 if (s.arrived[b]) (void)hipEventDestroy(s.arrived[b]);
                 if (s.finished[b]) (void)hipEventDestroy(s.finished[b]);
             }
+        }
+    }
+};
+void free_shard_state(void *p) { delete static_cast<ShardState *>(p); }
+
+// whatever way a call ends, nothing of it is still running on the handles' streams
+struct Quiesce {
+    std::vector<ShardSide> &sides;
+    ~Quiesce()
+    {
+        for (auto &s : sides) {
+            (void)hipSetDevice(s.device);
+            if (s.compute) (void)hipStreamSynchronize(s.compute);
+            if (s.copy) (void)hipStreamSynchronize(s.copy);
         }
     }
 };
@@ -188,13 +225,27 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     // which reads may hold an ambiguous k-mer: any character that is not one plain state (dist.py: amb_slots)
     const std::vector<uint32_t> &cls = shards[0]->h_char_class;
     std::vector<uint8_t> dirty(n, 0);
-    for (uint64_t i = 0; i < n; ++i) {
-        for (uint64_t c = seq_offsets[i]; c < seq_offsets[i + 1]; ++c) {
-            const uint32_t m = cls[(unsigned char)seqs[c]];
-            if (m == 0 || (m & (m - 1)) != 0) {
-                dirty[i] = 1;
-                break;
+    {
+        uint8_t not_plain[256];
+        for (int c = 0; c < 256; ++c) not_plain[c] = (cls[c] == 0 || (cls[c] & (cls[c] - 1)) != 0) ? 1 : 0;
+        auto scan = [&](uint64_t begin, uint64_t end) {
+            for (uint64_t i = begin; i < end; ++i) {
+                const unsigned char *s = reinterpret_cast<const unsigned char *>(seqs) + seq_offsets[i];
+                const uint64_t len = seq_offsets[i + 1] - seq_offsets[i];
+                uint8_t any = 0;
+                for (uint64_t c = 0; c < len; ++c) any |= not_plain[s[c]];  // (no early exit: nearly every read is clean)
+                dirty[i] = any;
             }
+        };
+        // (a byte per character at a load each: tens of milliseconds per hundred megabytes on one core -- more than
+        // the devices take for the batch -- so a few threads share a large batch)
+        const unsigned workers = n >= 65536 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (workers <= 1) {
+            scan(0, n);
+        } else {
+            std::vector<std::thread> threads;
+            for (unsigned t = 0; t < workers; ++t) threads.emplace_back(scan, n * t / workers, n * (t + 1) / workers);
+            for (auto &t : threads) t.join();
         }
     }
 
@@ -207,10 +258,43 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     }
     const uint64_t n_chunks = (n + chunk_reads - 1) / chunk_reads;
 
-    std::vector<ShardSide> sides(G);
-    Cleanup cleanup{sides};
+    // the sides of this set of handles: from the last call, or new
+    ShardState *state = static_cast<ShardState *>(shards[0]->shard_state);
+    if (state && (state->handles.size() != G || !std::equal(state->handles.begin(), state->handles.end(), shards))) {
+        delete state;
+        state = nullptr;
+        shards[0]->shard_state = nullptr;
+    }
+    if (!state) {
+        state = new ShardState();
+        state->handles.assign(shards, shards + G);
+        state->sides.resize(G);
+        shards[0]->shard_state = state;
+        shards[0]->shard_state_free = free_shard_state;
+    }
+    struct HalfBuilt {  // a set-up that failed half way is not kept for the next call
+        ShardState *state;
+        epik_amd_placer *owner;
+        ~HalfBuilt()
+        {
+            if (!state->ready) {
+                owner->shard_state = nullptr;
+                delete state;
+            }
+        }
+    } half_built{state, shards[0]};
+    std::vector<ShardSide> &sides = state->sides;
+    Quiesce quiesce{sides};
     for (uint32_t g = 0; g < G; ++g) {
         ShardSide &s = sides[g];
+        if (state->ready) {  // (the batch itself is new every call)
+            SHARD_TRY(hipSetDevice(s.device));
+            SHARD_TRY(s.seqs.reserve((size_t)seq_offsets[n] + 64));
+            SHARD_TRY(s.offsets.reserve((size_t)(n + 1) * sizeof(uint64_t)));
+            if (seq_offsets[n]) SHARD_TRY(hipMemcpyAsync(s.seqs.p, seqs, (size_t)seq_offsets[n], hipMemcpyHostToDevice, s.compute));
+            SHARD_TRY(hipMemcpyAsync(s.offsets.p, seq_offsets, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.compute));
+            continue;
+        }
         s.h = shards[g];
         s.device = shards[g]->device;
         s.compute = shards[g]->stream;
@@ -242,6 +326,7 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
         if (seq_offsets[n]) SHARD_TRY(hipMemcpyAsync(s.seqs.p, seqs, (size_t)seq_offsets[n], hipMemcpyHostToDevice, s.compute));
         SHARD_TRY(hipMemcpyAsync(s.offsets.p, seq_offsets, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.compute));
     }
+    state->ready = true;
 
     // room for a chunk's entries: the mean postings per k-mer of the shard times the chunk's k-mers, and margin; a
     // chunk that does not fit is accumulated again with what it asked for
@@ -396,11 +481,15 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
                     f.n_rows[b].p, f.counts[b].p, f.compute);
                 rc != EPIK_AMD_OK)
                 return rc;
-            const uint64_t at = ch.first + begin;
-            SHARD_TRY(hipMemcpyAsync(rows + at * keep, f.rows[b].p, m * keep * sizeof(epik_amd_placement), hipMemcpyDeviceToHost, f.compute));
-            SHARD_TRY(hipMemcpyAsync(n_rows + at, f.n_rows[b].p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, f.compute));
+            SHARD_TRY(f.h_rows[b].reserve(m * keep * sizeof(epik_amd_placement)));
+            SHARD_TRY(f.h_n_rows[b].reserve(m * sizeof(uint32_t)));
+            SHARD_TRY(f.h_counts[b].reserve(m * keep * sizeof(uint32_t)));
+            SHARD_TRY(hipMemcpyAsync(f.h_rows[b].p, f.rows[b].p, m * keep * sizeof(epik_amd_placement), hipMemcpyDeviceToHost, f.compute));
+            SHARD_TRY(hipMemcpyAsync(f.h_n_rows[b].p, f.n_rows[b].p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, f.compute));
             if (kmer_counts)
-                SHARD_TRY(hipMemcpyAsync(kmer_counts + at * keep, f.counts[b].p, m * keep * sizeof(uint32_t), hipMemcpyDeviceToHost, f.compute));
+                SHARD_TRY(hipMemcpyAsync(f.h_counts[b].p, f.counts[b].p, m * keep * sizeof(uint32_t), hipMemcpyDeviceToHost, f.compute));
+            f.out_at[b] = ch.first + begin;
+            f.out_reads[b] = m;
             SHARD_TRY(hipEventRecord(f.finished[b], f.compute));
         }
         return EPIK_AMD_OK;
@@ -409,12 +498,21 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     // sources' entries in place or through copies that they waited for)
     auto wait_set = [&](int b) -> int {
         for (uint32_t r = 0; r < G; ++r) {
-            SHARD_TRY(hipSetDevice(sides[r].device));
-            SHARD_TRY(hipEventSynchronize(sides[r].finished[b]));
+            ShardSide &f = sides[r];
+            SHARD_TRY(hipSetDevice(f.device));
+            SHARD_TRY(hipEventSynchronize(f.finished[b]));
+            if (const uint64_t m = f.out_reads[b]) {  // its rows are home: into the caller's arrays
+                const uint64_t at = f.out_at[b];
+                std::memcpy(rows + at * keep, f.h_rows[b].p, m * keep * sizeof(epik_amd_placement));
+                std::memcpy(n_rows + at, f.h_n_rows[b].p, m * sizeof(uint32_t));
+                if (kmer_counts) std::memcpy(kmer_counts + at * keep, f.h_counts[b].p, m * keep * sizeof(uint32_t));
+                f.out_reads[b] = 0;
+            }
         }
         return EPIK_AMD_OK;
     };
 
+    for (auto &side : sides) side.out_reads[0] = side.out_reads[1] = 0;
     std::vector<Chunk> chunk(2);
     bool used[2] = {false, false};
     for (uint64_t c = 0; c < n_chunks; ++c) {
@@ -428,6 +526,9 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
             if (const int rc = complete(chunk[b ^ 1], b ^ 1); rc != EPIK_AMD_OK) return rc;  // ... while chunk c - 1 crosses and finishes
     }
     if (const int rc = complete(chunk[(n_chunks - 1) & 1], (int)((n_chunks - 1) & 1)); rc != EPIK_AMD_OK) return rc;
+    for (int b = 0; b < 2; ++b)
+        if (used[b])
+            if (const int rc = wait_set(b); rc != EPIK_AMD_OK) return rc;
     for (uint32_t g = 0; g < G; ++g) {
         SHARD_TRY(hipSetDevice(sides[g].device));
         SHARD_TRY(hipStreamSynchronize(sides[g].copy));
