@@ -8,7 +8,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ("place_kernel.hip", "place_device.hpp", "team_kernel.hip", "team_stream.hip", "team_device.hpp",
-                  "place_kernel.h", "db_layout.h", "db_image.cpp", "capi.hip")
+                  "place_kernel.h", "db_layout.h", "db_image.cpp", "capi.hip", "shard_place.hip", "placer_impl.hpp")
 
 
 def kernel_source_hash() -> str:

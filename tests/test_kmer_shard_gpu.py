@@ -380,3 +380,21 @@ def test_place_sharded_native_n9999(gpu_available, oracle_lib, db_layout, monkey
         for p in placers:
             p.close()
     _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
+
+
+def test_dense_partials_mark_reads_of_more_than_65535_kmers(gpu_available, db_layout):
+    """The dense partial vectors count in uint16: a read of more k-mers must come back marked
+    (EPIK_AMD_ROWS_COUNTS_TOO_NARROW), never with wrapped counts -- whatever the LDS counts of the launch hold
+    (32-bit for such a read).  The partial lists have no such limit (test_n9999_lists_emulated_shards)."""
+    assert gpu_available
+    import torch
+    from epik_amd import capi
+    from epik_amd.placer import Placer
+    db, _ = _case()
+    rng = np.random.default_rng(31)
+    data, offs = synth.pack_reads(["".join(rng.choice(list("ACGT"), size=70_000)), "ACGTACGTACGTAAC"])
+    dev = torch.device("cuda", 0)
+    with Placer.from_synth(db) as pl:
+        accumulate, finish = edist.kmer_sharded_gpu_fns(pl, data, offs, dev)
+        rows, n_rows, _ = edist.place_kmer_sharded(accumulate, finish, 2, None)
+    assert int(n_rows[0]) == capi.ROWS_COUNTS_TOO_NARROW and 1 <= int(n_rows[1]) <= 7

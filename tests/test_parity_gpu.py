@@ -240,3 +240,22 @@ def test_large_tree_short_reads_take_the_8_bit_counts(placer_cls, oracle_lib, db
         assert_rows_match(*got2, *orc.place(data2, offs2, num_threads=0))
         if not db_layout.startswith("team"):
             assert narrow["lds_bytes_per_block"] < pl.launch_info()["lds_bytes_per_block"] * narrow["waves_per_block"] / pl.launch_info()["waves_per_block"]
+
+
+@pytest.mark.parametrize("forced", ["2", "0"])
+def test_place_widens_forced_counts_instead_of_marking_reads(placer_cls, oracle_lib, small_case, forced, monkeypatch):
+    """EPIK_AMD_WIDE_COUNTS forces a count width for experiments; a read with more k-mers than that width holds must
+    still be placed by the host entry point (its consumers take n_rows as a row count: the mark of the
+    device-pointer entry points, EPIK_AMD_ROWS_COUNTS_TOO_NARROW, must never come out of epik_amd_placer_place)."""
+    from epik_amd import capi
+    _, db = small_case
+    monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", forced)   # 8-bit counts (255 k-mers) / 16-bit (32767)
+    rng = np.random.default_rng(21)
+    long_read = "".join(rng.choice(list("ACGT"), size=40_000 if forced == "0" else 700))
+    data, offs = synth.pack_reads(["ACGTACGTAC", long_read, "ACGTTGCA" * 4])
+    ref = oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0)
+    with placer_cls.from_synth(db) as pl:
+        got = pl.place_packed(data, offs)
+        assert int(got[1].max()) <= pl.keep_at_most and capi.ROWS_COUNTS_TOO_NARROW not in got[1]
+        # ... while a device-pointer launch with counts the caller chose too narrow says so, per read
+    assert_rows_match(*got, *ref)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r02_* and
+"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r03_* and
 rewrites profiles/traffic.json from the PMC summaries, stamped with the hash of the kernel sources in
 the tree (run it on the same sources the GPU run used).
 
-    python tools/collect_profiles.py r02_c
+    python tools/collect_profiles.py r03_a
 """
 import json
 import os
@@ -14,25 +14,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from epik_amd import provenance  # noqa: E402
 
+ROUND = "r03"
 FILES = {
-    "bench.json": "r02_bench.json",
-    "bench_headline.json": "r02_bench_headline_trace_run.json",
-    "bench_k11.json": "r02_bench_k11.json",
-    "bench_n9999.json": "r02_bench_n9999_team.json",
-    "bench_amino_k7.json": "r02_bench_amino_k7.json",
-    "bench_kmer_shard_n9999.json": "r02_bench_kmer_shard_n9999_1gpu.json",
-    "kernel_stats_headline.csv": "r02_kernel_stats.csv",
-    "kernel_stats_k11.csv": "r02_kernel_stats_k11.csv",
-    "kernel_stats_n9999.csv": "r02_kernel_stats_n9999_team.csv",
-    "kernel_stats_amino_k7.csv": "r02_kernel_stats_amino_k7.csv",
-    "pmc_summary_headline.txt": "r02_pmc_summary.txt",
-    "pmc_summary_k11.txt": "r02_pmc_summary_k11.txt",
-    "pmc_summary_n9999.txt": "r02_pmc_summary_n9999_team.txt",
-    "sq_counters_headline.txt": "r02_sq_counters.txt",
-    "sq_counters_n9999_team.txt": "r02_sq_counters_n9999_team.txt",
-    "team_instruction_counts.txt": "r02_team_instruction_counts.txt",
-    "team_stream_wave_timeline.txt": "r02_team_stream_wave_timeline.txt",
-    "sweep_tree_sizes_passes.txt": "r02_sweep_tree_sizes_passes.txt",
+    "bench.json": f"{ROUND}_bench.json",
+    "bench_headline.json": f"{ROUND}_bench_headline_trace_run.json",
+    "bench_k11.json": f"{ROUND}_bench_k11.json",
+    "bench_n9999.json": f"{ROUND}_bench_n9999_team.json",
+    "bench_amino_k7.json": f"{ROUND}_bench_amino_k7_1g.json",
+    "bench_kmer_shard_n9999.json": f"{ROUND}_bench_kmer_shard_n9999_1gpu.json",
+    "bench_kmer_shard_n9999_256k.json": f"{ROUND}_bench_kmer_shard_n9999_1gpu_256k_reads.json",
+    "kernel_stats_headline.csv": f"{ROUND}_kernel_stats.csv",
+    "kernel_stats_k11.csv": f"{ROUND}_kernel_stats_k11.csv",
+    "kernel_stats_n9999.csv": f"{ROUND}_kernel_stats_n9999_team.csv",
+    "kernel_stats_amino_k7.csv": f"{ROUND}_kernel_stats_amino_k7_1g.csv",
+    "kernel_stats_kmer_shard_n9999.csv": f"{ROUND}_kernel_stats_kmer_shard_n9999.csv",
+    "kernel_stats_kmer_shard_n9999_256k.csv": f"{ROUND}_kernel_stats_kmer_shard_n9999_256k_reads.csv",
+    "pmc_summary_headline.txt": f"{ROUND}_pmc_summary.txt",
+    "pmc_summary_k11.txt": f"{ROUND}_pmc_summary_k11.txt",
+    "pmc_summary_n9999.txt": f"{ROUND}_pmc_summary_n9999_team.txt",
+    "pmc_summary_amino_k7.txt": f"{ROUND}_pmc_summary_amino_k7_1g.txt",
+    "e2e_driver.txt": f"{ROUND}_e2e_driver.txt",
+    "shard_rate.txt": f"{ROUND}_shard_rate_place_sharded.txt",
+    "sq_counters_headline.txt": f"{ROUND}_sq_counters.txt",
+    "sq_counters_n9999_team.txt": f"{ROUND}_sq_counters_n9999_team.txt",
+    "team_instruction_counts.txt": f"{ROUND}_team_instruction_counts.txt",
+    "team_stream_wave_timeline.txt": f"{ROUND}_team_stream_wave_timeline.txt",
+    "sweep_tree_sizes_passes.txt": f"{ROUND}_sweep_tree_sizes_passes.txt",
 }
 
 
@@ -57,13 +64,12 @@ def main():
         if a.endswith(".json"):
             text = text.strip().splitlines()[-1] + "\n"
         open(os.path.join(dst, b), "w").write(text)
-    head = json.loads(open(os.path.join(dst, "r02_bench.json")).read())
+    head = json.loads(open(os.path.join(dst, f"{ROUND}_bench.json")).read())
     old = json.load(open(os.path.join(dst, "traffic.json")))
     c = counters(os.path.join(src, "pmc_summary_headline.txt"), "place_reads_kernel")
     doc = {
         "workload": head["config"]["workload"],
-        "kernel": "place_reads_kernel<PackedLayout<1>, uint16_t> (paired lookup table, range-checked buffer loads, "
-                  "16-bit counts: the default for DNA)",
+        "kernel": head["roofline"]["kernel"],
         "hbm_bytes_per_launch": c["TCC_EA0_RDREQ_128B_sum"] * 128.0,
         "kernel_source_sha": provenance.kernel_source_hash(),
         "commit": subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip(),
@@ -74,24 +80,33 @@ def main():
                    f"(MI355X_MICROARCH.md, HBM section) -> x2 x 1024 = {c['FETCH_SIZE'] * 2048:.4g} B; calibration streams of "
                    "tools/calib_fetch.hip in the same summary file"),
         "l2_hit_rate": c["TCC_HIT_sum"] / c["TCC_REQ_sum"],
-        "source": "profiles/r02_pmc_summary.txt",
-        "note": "bench.py reports this number only while kernel_source_sha equals the hash of the kernel sources it "
-                "runs (epik_amd/provenance.py)",
-        "other_workloads_same_sources": {},
-        "previous": old.get("previous", {}),
+        "source": f"profiles/{ROUND}_pmc_summary.txt",
+        "note": "bench.py reports these numbers only while kernel_source_sha equals the hash of the kernel sources it "
+                "runs (epik_amd/provenance.py); `workloads` is keyed by the exact config.workload string of the bench line",
+        "workloads": {},
+        "previous": dict(old.get("previous", {}), **{"r02 final (headline)": old.get("hbm_bytes_per_launch")}),
     }
-    for name, kerns, f, out in (("k=11 database (1.13 GB on the device)", ("place_reads_kernel",), "pmc_summary_k11.txt",
-                                 "r02_pmc_summary_k11.txt"),
-                                ("N=9999 tree, team placement (front + streaming + merge kernels, summed)",
-                                 ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"), "pmc_summary_n9999.txt",
-                                 "r02_pmc_summary_n9999_team.txt")):
-        per_kernel = [counters(os.path.join(src, f), kern) for kern in kerns]
+    for bench_file, kerns, f, out in (("bench_k11.json", ("place_reads_kernel",), "pmc_summary_k11.txt", f"{ROUND}_pmc_summary_k11.txt"),
+                                      ("bench_n9999.json", ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"),
+                                       "pmc_summary_n9999.txt", f"{ROUND}_pmc_summary_n9999_team.txt"),
+                                      ("bench_amino_k7.json", ("place_reads_kernel",), "pmc_summary_amino_k7.txt",
+                                       f"{ROUND}_pmc_summary_amino_k7_1g.txt")):
+        try:
+            line = json.loads(open(os.path.join(src, bench_file)).read().strip().splitlines()[-1])
+            per_kernel = [counters(os.path.join(src, f), kern) for kern in kerns]
+        except (OSError, ValueError, IndexError):
+            print("missing", bench_file, "or", f)
+            continue
         total = lambda key: sum(c.get(key, 0.0) for c in per_kernel)  # noqa: E731
-        doc["other_workloads_same_sources"][name] = {"hbm_bytes_per_launch": total("TCC_EA0_RDREQ_128B_sum") * 128.0,
-                                                      "l2_hit_rate": total("TCC_HIT_sum") / total("TCC_REQ_sum"),
-                                                      "source": "profiles/" + out}
+        if not total("TCC_REQ_sum"):
+            print("no counters in", f)
+            continue
+        doc["workloads"][line["config"]["workload"]] = {
+            "hbm_bytes_per_launch": total("TCC_EA0_RDREQ_128B_sum") * 128.0 + total("TCC_EA0_RDREQ_64B_sum") * 64.0
+                                    + total("TCC_EA0_RDREQ_32B_sum") * 32.0,
+            "l2_hit_rate": total("TCC_HIT_sum") / total("TCC_REQ_sum"), "kernels": list(kerns), "source": "profiles/" + out}
     json.dump(doc, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-    print("traffic:", doc["hbm_bytes_per_launch"], "sha", doc["kernel_source_sha"])
+    print("traffic:", doc["hbm_bytes_per_launch"], "sha", doc["kernel_source_sha"], "workloads", len(doc["workloads"]))
 
 
 if __name__ == "__main__":

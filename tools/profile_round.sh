@@ -30,12 +30,16 @@ trace() { # name args...
 trace headline
 trace k11 --kmer-size 11
 trace n9999 --leaves 5000
-trace amino_k7 --states amino --kmer-size 7 --read-length 300 --p-present 0.0026
-log "k-mer-space shard, N = 9999, one GPU"
-python3 $R/bench.py --mode kmer-shard --leaves 5000 --reads-per-step 65536 --steps 10 --warmup 2 --cpu-baseline-seconds 0 \
-    > $OUT/bench_kmer_shard_n9999.json 2> $OUT/bench_kmer_shard_n9999.err
+# configs[3] at its stated size: ~1 G postings, the sparse form of the descriptor
+trace amino_k7 --states amino --kmer-size 7 --read-length 300 --p-present 0.0133
+trace kmer_shard_n9999 --mode kmer-shard --leaves 5000 --reads-per-step 65536
+trace kmer_shard_n9999_256k --mode kmer-shard --leaves 5000 --reads-per-step 262144
+log "end to end through the native driver, 1 M reads"
+(cd $R && python3 tools/e2e_bench.py --reads 1000000 --batch-size 2000 --jobs 1 4 16 > $OUT/e2e_driver.txt 2>&1; python3 tools/e2e_bench.py --reads 1000000 --batch-size 2000 --jobs 16 --devices 0,0 >> $OUT/e2e_driver.txt 2>&1)
+log "epik_amd_placer_place_sharded (the --db-shard path), N = 9999"
+(cd $R && python3 tools/shard_rate.py > $OUT/shard_rate.txt 2>&1)
 
-for cfg in "headline:" "k11:--kmer-size 11" "n9999:--leaves 5000"; do
+for cfg in "headline:" "k11:--kmer-size 11" "n9999:--leaves 5000" "amino_k7:--states amino --kmer-size 7 --read-length 300 --p-present 0.0133"; do
   name=${cfg%%:*}; args=${cfg#*:}
   log "PMC passes: $name"
   (cd $R && BENCH_ARGS="$args" bash tools/pmc_passes.sh ${TAG}_$name > $OUT/pmc_$name.log 2>&1)
