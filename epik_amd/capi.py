@@ -43,6 +43,7 @@ EXPORTS = (
     "epik_amd_placer_finish_lists_device",
     "epik_amd_placer_last_path",
     "epik_amd_placer_place_sharded",
+    "epik_amd_placer_release_scratch",
     "epik_amd_placer_set_wide_counts",
     "epik_amd_placer_choose_counts",
     "epik_amd_placer_launch_info",
@@ -160,6 +161,8 @@ def load() -> ctypes.CDLL:
                                                         vp, vp, vp, vp, vp, vp]
     lib.epik_amd_placer_place_sharded.restype = i32
     lib.epik_amd_placer_place_sharded.argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, vp, vp, u64, vp, vp, vp]
+    lib.epik_amd_placer_release_scratch.restype = i32
+    lib.epik_amd_placer_release_scratch.argtypes = [vp]
     lib.epik_amd_placer_last_path.restype = i32
     lib.epik_amd_placer_last_path.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.epik_amd_placer_plan.restype = i32

@@ -1215,6 +1215,27 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
     return EPIK_AMD_OK;
 }
 
+int epik_amd_placer_release_scratch(epik_amd_placer *p)
+{
+    if (!p) return fail(EPIK_AMD_ERR_INVALID, "null placer");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (p->shard_state && p->shard_state_free) p->shard_state_free(p->shard_state);
+    p->shard_state = nullptr;
+    void **bufs[] = {reinterpret_cast<void **>(&p->d_front_hdr), reinterpret_cast<void **>(&p->d_slow_list), &p->d_slice_rows,
+                     &p->d_slice_sums, reinterpret_cast<void **>(&p->d_front_pool), reinterpret_cast<void **>(&p->d_sparse_cap),
+                     reinterpret_cast<void **>(&p->d_scan_tiles), reinterpret_cast<void **>(&p->d_seqs),
+                     reinterpret_cast<void **>(&p->d_seq_offsets), reinterpret_cast<void **>(&p->d_rows),
+                     reinterpret_cast<void **>(&p->d_n_rows), reinterpret_cast<void **>(&p->d_counts)};
+    for (void **b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    p->front_hdr_bytes = 0, p->slow_list_reads = 0, p->slice_out_reads = 0, p->front_pool_cap = 0, p->sparse_cap_items = 0;
+    p->d_seqs_cap = 0, p->d_reads_cap = 0, p->front_failed_reads = 0;
+    return EPIK_AMD_OK;
+}
+
 int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_block,
                                 uint32_t *blocks, uint32_t *lds_bytes)
 {

@@ -398,6 +398,17 @@ __device__ __forceinline__ uint32_t emit_partial_list(WaveLds<CountT> lds, uint3
 #pragma unroll
         for (int q = 0; q < Lds_t::kCountWords; ++q) words[q] = 0u;
         if (mine) lds.load4_packed(i0, raw, words);
+        // (a shard's lists reach a small part of the slice: a trip of 256 rows none of which has a count -- most of
+        // them with many shards -- is done with this test; its rows are zero already)
+        {
+            uint32_t any = 0;
+#pragma unroll
+            for (int q = 0; q < Lds_t::kCountWords; ++q) any |= words[q];  // (counts AND the "seen" flags of the ambiguous sweep)
+            if (__ballot(any != 0) == 0) {
+                // the dummy row (the last one) may hold what out-of-range lanes added: it is reset below like any other
+                if (base + 4u * (uint32_t)kWave < rows_pad) continue;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             uint32_t c;

@@ -298,6 +298,10 @@ class Placer:
             counts.ctypes.data))
         return rows, n_rows, counts
 
+    def release_scratch(self) -> None:
+        """Frees what the handle's launches have grown and kept (`epik_amd_placer_release_scratch`)."""
+        capi.check(self._lib.epik_amd_placer_release_scratch(self._handle))
+
     def last_path(self) -> int:
         """Which kernels the last launch ran: capi.PATH_WAVE / PATH_TEAM_ONE_KERNEL / PATH_TEAM_STREAMED."""
         out = ctypes.c_uint32(0)

@@ -307,6 +307,12 @@ int epik_amd_placer_place_sharded(epik_amd_placer *const *shards, uint32_t n_sha
 #define EPIK_AMD_PATH_TEAM_STREAMED 2u   /* team_front_kernel + team_stream_kernel + team_merge_kernel (+ the other for the rest) */
 int epik_amd_placer_last_path(const epik_amd_placer *p, uint32_t *path);
 
+/* Gives back what the handle's launches have grown and kept: the scratch of large-tree launches (descriptor pool,
+ * headers, slice results: up to ~1 GB after batches of a million reads), the staging buffers of the host entry
+ * points, the buffers of place_sharded.  The database stays; the next launch allocates again what it needs.
+ * Synchronises the handle's device. */
+int epik_amd_placer_release_scratch(epik_amd_placer *p);
+
 /* Launch geometry actually used (for reports): waves per workgroup (one read per wave with the
  * one-wavefront kernel, one slice of a read per wave on large trees), workgroups of the last launch,
  * dynamic LDS bytes per workgroup. */

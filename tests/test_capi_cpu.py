@@ -140,3 +140,8 @@ def test_generated_isa_keeps_its_hands_off_the_load_ring():
     run = subprocess.run(["make", "-C", os.path.join(root, "epik_amd", "csrc"), "asm"], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert run.stdout.count("ring-asm lint: 0 problem(s)") == 3   # place_kernel.hip, team_kernel.hip, team_stream.hip
+
+
+def test_release_scratch_rejects_null():
+    lib = capi.load()
+    assert lib.epik_amd_placer_release_scratch(None) == capi.ERR_INVALID

@@ -186,3 +186,27 @@ def test_placers_of_different_trees_share_a_process(large_tree, small_case, orac
     for a, b in zip(before, after):
         assert a.tobytes() == b.tobytes()
     assert_rows_match(*after, *oracle_lib.Oracle.from_synth(big).place(data, offs, num_threads=0))
+
+
+def test_release_scratch_and_place_again(large_tree, monkeypatch):
+    """A large-tree handle keeps the scratch of its launches (descriptor pool, headers, slice results) and the
+    staging of the host entry point; epik_amd_placer_release_scratch gives all of it back -- the device's free
+    memory returns to what it was after create() -- and the next placement allocates again and gives the same rows."""
+    import torch
+    from epik_amd.placer import Placer
+    _, db = large_tree
+    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL"):
+        monkeypatch.delenv(var, raising=False)
+    rng = np.random.default_rng(77)
+    data, offs = synth.pack_reads(["".join(rng.choice(list("ACGT"), size=150)) for _ in range(20000)])
+    with Placer.from_synth(db) as pl:
+        torch.cuda.synchronize()
+        free_created = torch.cuda.mem_get_info()[0]
+        first = pl.place_packed(data, offs)
+        free_used = torch.cuda.mem_get_info()[0]
+        assert free_used < free_created - (8 << 20), "the placement must have grown scratch on the device"
+        pl.release_scratch()
+        assert torch.cuda.mem_get_info()[0] >= free_created - (1 << 20)
+        again = pl.place_packed(data, offs)
+    for a, b in zip(first, again):
+        assert a.tobytes() == b.tobytes()
