@@ -145,6 +145,7 @@ void epik_amd_placer_destroy(epik_amd_placer *p)
     (void)hipFree(p->d_counts);
     (void)hipFree(p->d_total);
     (void)hipFree(p->d_front_hdr);
+    (void)hipFree(p->d_finish_hdr);
     (void)hipFree(p->d_slow_list);
     (void)hipFree(p->d_slice_rows);
     (void)hipFree(p->d_slice_sums);
@@ -651,6 +652,15 @@ uint64_t front_grid(const epik_amd_placer *p, uint64_t n)
 static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, bool with_pool, bool lists)
 {
     const uint32_t slices = (uint32_t)p->team_waves * p->team_passes;
+    if (!with_pool) {  // finish: headers of its own, the slices' results; nothing is looked up
+        const size_t bytes = (size_t)n * epik_amd::front_hdr_stride(slices);
+        if (bytes > p->finish_hdr_bytes) {
+            (void)hipFree(p->d_finish_hdr);
+            p->d_finish_hdr = nullptr, p->finish_hdr_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_finish_hdr), bytes));
+            p->finish_hdr_bytes = bytes;
+        }
+    }
     if (lists && (size_t)n * slices > p->sparse_cap_items) {
         (void)hipFree(p->d_sparse_cap);
         (void)hipFree(p->d_scan_tiles);
@@ -661,20 +671,22 @@ static int reserve_front(epik_amd_placer *p, uint64_t n, uint64_t total_chars, b
                           (size_t)(epik_amd::sparse_scan_tiles(n, slices) + EPIK_AMD_MAX_SHARDS) * sizeof(unsigned long long)));
         p->sparse_cap_items = (size_t)n * slices;
     }
-    const size_t hdr_bytes = (size_t)n * epik_amd::front_hdr_stride(slices);
+    const size_t hdr_bytes = with_pool ? (size_t)n * epik_amd::front_hdr_stride(slices) : 0;
     if (hdr_bytes > p->front_hdr_bytes) {
         (void)hipFree(p->d_front_hdr);
         p->d_front_hdr = nullptr, p->front_hdr_bytes = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_front_hdr), hdr_bytes));
         p->front_hdr_bytes = hdr_bytes;
     }
-    if (n > p->slow_list_reads) {
+    if (with_pool && n > p->slow_list_reads) {
         (void)hipFree(p->d_slow_list);
         p->d_slow_list = nullptr, p->slow_list_reads = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_slow_list), (size_t)n * sizeof(uint64_t)));
         p->slow_list_reads = n;
     }
-    if (n > p->slice_out_reads) {
+    // (the slices' results: placing and finishing; the accumulate of partial lists has none -- and must not free what a
+    // finish launch running beside it on another stream is using)
+    if (!(with_pool && lists) && n > p->slice_out_reads) {
         (void)hipFree(p->d_slice_rows);
         (void)hipFree(p->d_slice_sums);
         p->d_slice_rows = p->d_slice_sums = nullptr, p->slice_out_reads = 0;
@@ -799,7 +811,7 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             // kernel (a wave per read), and team_place_kernel for the reads whose descriptors found the pool
             // full.  The halves of a k-mer-space-sharded placement: accumulate = front (+ scan: partial lists) +
             // streaming (+ the other kernel for the rest), finish = headers + streaming + merge.
-            tp.front_hdr = p->d_front_hdr;
+            tp.front_hdr = is_finish(mode) ? p->d_finish_hdr : p->d_front_hdr;
             tp.front_hdr_stride = epik_amd::front_hdr_stride((uint32_t)p->team_waves * p->team_passes);
             tp.front_pool = p->d_front_pool;
             tp.front_pool_cap = p->front_pool_cap;
@@ -1222,7 +1234,8 @@ int epik_amd_placer_release_scratch(epik_amd_placer *p)
     HIP_TRY(hipDeviceSynchronize());
     if (p->shard_state && p->shard_state_free) p->shard_state_free(p->shard_state);
     p->shard_state = nullptr;
-    void **bufs[] = {reinterpret_cast<void **>(&p->d_front_hdr), reinterpret_cast<void **>(&p->d_slow_list), &p->d_slice_rows,
+    void **bufs[] = {reinterpret_cast<void **>(&p->d_front_hdr), reinterpret_cast<void **>(&p->d_finish_hdr),
+                     reinterpret_cast<void **>(&p->d_slow_list), &p->d_slice_rows,
                      &p->d_slice_sums, reinterpret_cast<void **>(&p->d_front_pool), reinterpret_cast<void **>(&p->d_sparse_cap),
                      reinterpret_cast<void **>(&p->d_scan_tiles), reinterpret_cast<void **>(&p->d_seqs),
                      reinterpret_cast<void **>(&p->d_seq_offsets), reinterpret_cast<void **>(&p->d_rows),
@@ -1231,7 +1244,7 @@ int epik_amd_placer_release_scratch(epik_amd_placer *p)
         if (*b) (void)hipFree(*b);
         *b = nullptr;
     }
-    p->front_hdr_bytes = 0, p->slow_list_reads = 0, p->slice_out_reads = 0, p->front_pool_cap = 0, p->sparse_cap_items = 0;
+    p->front_hdr_bytes = 0, p->finish_hdr_bytes = 0, p->slow_list_reads = 0, p->slice_out_reads = 0, p->front_pool_cap = 0, p->sparse_cap_items = 0;
     p->d_seqs_cap = 0, p->d_reads_cap = 0, p->front_failed_reads = 0;
     return EPIK_AMD_OK;
 }

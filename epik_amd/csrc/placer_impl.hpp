@@ -37,6 +37,8 @@ struct epik_amd_placer {
     bool team_front = false;
     uint8_t *d_front_hdr = nullptr;
     size_t front_hdr_bytes = 0;
+    uint8_t *d_finish_hdr = nullptr;  // the headers of a FINISH launch (its own: the finish of one batch may run beside
+    size_t finish_hdr_bytes = 0;      // the accumulate of the next on another stream, which writes d_front_hdr)
     uint64_t *d_slow_list = nullptr;
     size_t slow_list_reads = 0;
     void *d_slice_rows = nullptr, *d_slice_sums = nullptr;  // the slices' results on their way to the merge kernel

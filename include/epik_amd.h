@@ -263,6 +263,8 @@ int epik_amd_placer_finish_device(epik_amd_placer *p, const void *d_seq_offsets,
  * are those of the dense exchange's rank-order sum (0 + x is x) -- then finishes as finish_device does.  All
  * shards and the finisher must run with the same count width (epik_amd_placer_choose_counts with the batch's
  * longest read on each).  The ambiguous records cross as with the dense calls.
+ * accumulate_lists and finish_lists of ONE handle may run side by side on two streams (the finish of a batch beside
+ * the accumulate of the next: they keep separate scratch); two launches of the same kind may not.
  */
 #define EPIK_AMD_MAX_SHARDS 16
 typedef struct {

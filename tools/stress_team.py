@@ -68,6 +68,41 @@ def main():
                 assert a.tobytes() == b.tobytes(), ("accumulate+finish", run)
     print(f"accumulate + finish: {m} reads x {repeats} runs agree with the one-pass placement", flush=True)
 
+    # the same halves with partial lists (round 3), through the pipelined driver of epik_amd.dist in four batches, and
+    # the whole sharded placement inside the library (one shard: bit for bit the one-pass rows)
+    cls = alphabet.char_class_table(db.states)
+    with Placer.from_synth(db) as pl:
+        engine = edist.ListsGpuEngine(pl, dev)
+        cuts = [0, m // 7, m // 2, m - 1000, m]
+        for run in range(repeats):
+            batches = [(sub[int(sub_offs[a]):int(sub_offs[b])], (sub_offs[a:b + 1] - sub_offs[a]).astype(np.uint64))
+                       for a, b in zip(cuts, cuts[1:])]
+            got = list(edist.place_kmer_sharded_lists(engine, batches, None, char_class=cls))
+            for i in range(3):
+                joined = np.concatenate([g[i] for g in got])
+                assert joined.tobytes() == one_pass[i].tobytes(), ("accumulate_lists + finish_lists", run, i)
+            native = Placer.place_sharded([pl], sub, sub_offs)
+            for a, b in zip(native, one_pass):
+                assert a.tobytes() == b.tobytes(), ("place_sharded, one shard", run)
+    print(f"partial lists: {m} reads x {repeats} runs (pipelined halves and place_sharded) agree with the one-pass placement", flush=True)
+    # three shards on the one device: the library's own exchange against the halves driven from here, bit for bit
+    os.environ["EPIK_AMD_SHARD_CHUNK"] = "20000"
+    placers = [Placer.from_synth(db, shard_index=g, shard_count=3) for g in range(3)]
+    try:
+        first = Placer.place_sharded(placers, sub, sub_offs)
+        for run in range(repeats):
+            again = Placer.place_sharded(placers, sub, sub_offs)
+            for a, b in zip(first, again):
+                assert a.tobytes() == b.tobytes(), ("place_sharded, three shards, run to run", run)
+        assert np.array_equal(first[1], one_pass[1])
+        valid = np.arange(first[0].shape[1])[None, :] < first[1][:, None]
+        np.testing.assert_allclose(first[0]["score"][valid], one_pass[0]["score"][valid], rtol=2e-6)
+        assert np.abs(first[0]["lwr"][valid] - one_pass[0]["lwr"][valid]).max() <= 1e-5
+    finally:
+        for p in placers:
+            p.close()
+    print(f"place_sharded, 3 shards: {m} reads x {repeats + 1} runs identical, within rounding of the one-pass rows", flush=True)
+
 
 if __name__ == "__main__":
     main()
