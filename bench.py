@@ -82,22 +82,21 @@ def parse_args():
     return ap.parse_args()
 
 
-def load_traffic(workload: str):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: one entry per workload string) --
-    only if they were measured ON THESE KERNEL SOURCES (rocprofv3 --pmc cannot run inside this process)."""
+def load_counters(workload: str) -> dict:
+    """What the committed counter passes say about this workload (profiles/traffic.json: one entry per workload
+    string: HBM bytes per launch, share of cycles the vector ALUs are busy) -- only if they were measured ON THESE
+    KERNEL SOURCES (rocprofv3 --pmc cannot run inside this process)."""
     from epik_amd import provenance
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
         if doc.get("kernel_source_sha") != provenance.kernel_source_hash():
-            return None
-        if doc.get("workload") == workload:
-            return doc.get("hbm_bytes_per_launch")
-        return (doc.get("workloads", {}).get(workload) or {}).get("hbm_bytes_per_launch")
+            return {}
+        return doc if doc.get("workload") == workload else (doc.get("workloads", {}).get(workload) or {})
     except (OSError, ValueError):
         pass
-    return None
+    return {}
 
 
 # What random 128-byte line reads get from a working set far larger than the Infinity Cache (tools/probe_mall.hip:
@@ -154,6 +153,9 @@ def cpu_baseline(db, data, offs, target_seconds: float):
             variants[name] = {"reads_per_s": n / timed(n, n_threads), "reads": n}
         out[label] = {
             "value": variants["hash_map"]["reads_per_s"], "unit": "reads/s", "cores": n_threads, "kind": "port",
+            # (the box's cores beside the share this job may use: `value` x box_cores / cores is what the whole
+            # host would do if the loop scaled perfectly)
+            "box_cores": os.cpu_count(),
             "variants": {k: v["reads_per_s"] for k, v in variants.items()},
             "sample": f"{variants['hash_map']['reads']} reads of the step batch, median of 5 runs, "
                       "oracle/epik_oracle.c run as the reference's driver runs placer::place: batches of 2000 reads, "
@@ -516,7 +518,8 @@ def main():
         alg_bytes = pl.algorithmic_bytes(d_seqs.data_ptr(), d_offs.data_ptr(), n, d_nrows.data_ptr(), stream.cuda_stream)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         working_set = image_bytes(pl_plan)
-        traffic = load_traffic(workload_name)
+        measured = load_counters(workload_name)
+        traffic = measured.get("hbm_bytes_per_launch")
         # a working set of up to twice the Infinity Cache is served from it for a good part (the headline
         # database: 285 MB against 268 MB of cache); only well beyond that is the kernel bound by HBM alone
         roof = {"bound": "hbm+mall" if working_set <= 2 * MALL_BYTES else "hbm", "achieved": achieved,
@@ -524,6 +527,10 @@ def main():
                 "traffic": traffic, "working_set_bytes": working_set, "mall_bytes": MALL_BYTES,
                 "kernel": kernel_name(pl_plan, pl, not kmer_shard), "kernel_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_read": alg_bytes / n}
+        if measured.get("valu_busy") is not None:
+            # what else bounds the kernel: the share of its cycles in which a SIMD's vector ALU is executing
+            # (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles, the committed SQ counter pass of this workload)
+            roof["valu_busy"] = measured["valu_busy"]
         if traffic:
             # The SURVEY 8(d) formula charges 8 bytes per lookup; a lookup FETCHES a 128-byte line (of the table or
             # of the presence filter).  A workload that is mostly lookups -- a sparse protein database: 294 of them
@@ -577,7 +584,14 @@ def main():
         with Placer.from_synth(big, device=local_rank) as big_placer:
             big_placer.choose_counts(args.read_length)
             _, big_ms = timed_steps(make_step(big_placer), 6, 2)
-            roof = roofline_of(big_placer, big_plan, big_ms, "")
+            # (the workload string of `bench.py --kmer-size 11`, which is what the PMC passes of that database ran)
+            big_total = big.total_entries
+            roof = roofline_of(big_placer, big_plan, big_ms,
+                               f"{args.states} k=11 omega=1.5 mu=1.0 synthetic DB, N={tree.num_nodes} branches, "
+                               f"{big_total} postings ({big_total * 8 / 1e6:.0f} MB), "
+                               f"{args.reads_per_step} x {args.read_length} {unit} reads per step per GPU"
+                               + (", scattered branch sets" if args.scattered else "")
+                               + (f", {args.p_present:g} of the codes present" if args.p_present != 0.6 else ""))
         roof["workload"] = (f"nucl k=11, N={tree.num_nodes}, {big.num_entries} postings, the same "
                             f"{n} x {args.read_length} bp reads; 6 steps after 2 warm-ups")
         roof["reads_per_s"] = n / (big_ms * 1e-3)

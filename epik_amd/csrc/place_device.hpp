@@ -172,10 +172,10 @@ struct Tile {
 // (tools/probe_buffer.hip: the range check includes soffset; 6-byte {score, cell} structs
 // read as 2-byte-aligned dwords work too but halve the load throughput.)
 //
-// A chunk descriptor {address (48 bits) | count << 48} is unpacked by every lane at once,
-// once per trip of the ring (vector work), into the kFields variable words of the chunk's
-// loads; a stage then pulls its chunk's words out with v_readlane: the CU's single scalar
-// unit does no unpacking.  `issue` puts one chunk's loads in flight from inline asm (hipcc
+// A chunk descriptor {address (48 bits) | count << 48} is prepared by every lane at once,
+// once per trip of the ring (vector work), as the kFields words a stage pulls out of the
+// lanes with v_readlane (the packed layout without runs: the descriptor's two words as they
+// are, the count split off by two scalar instructions per chunk).  `issue` puts one chunk's loads in flight from inline asm (hipcc
 // must not count them, see the ring below); `load_posting` is the plain, compiler-counted
 // access of the cold ambiguous path and returns {LDS row, score bits}.
 // ---------------------------------------------------------------------------------
@@ -277,7 +277,8 @@ struct PackedLayout {
     // chunks -- never too short.  (The builder run-codes databases whose postings are nearly all in runs.)
     static constexpr int kWaitLoads = kRuns ? 1 : 2;
     static constexpr uint32_t kChunkBytes = 64u * 6u;
-    static constexpr int kFields = 3;  // base lo, base hi, postings in the chunk (kRuns: | the chunk's first cell << 7)
+    // kRuns: base lo, base hi, postings in the chunk | the chunk's first cell << 7; else the descriptor's two words
+    static constexpr int kFields = kRuns ? 3 : 2;
     __device__ static __forceinline__ uint32_t length(uint32_t w) { return kRuns ? (w & 0xffffu) : w; }
     // kRuns: byte offset / 2 from the start of the posting region (37 bits: 256 GiB) | cnt << 37 | first cell of the
     // chunk << 44 (0: explicit cells); else the chunk's address | cnt << 48
@@ -330,11 +331,11 @@ struct PackedLayout {
             f[1] = (uint32_t)(a >> 32) & 0xffffu;
             f[2] = (uint32_t)(d >> 37);  // cnt (7 bits) | first cell << 7
         } else {
+            // (the two words as they are: a stage takes them out of the lanes with two v_readlane and splits the
+            // count off with scalar instructions -- a vector instruction less per chunk than three prepared fields)
             (void)p;
-            const uint32_t hi = (uint32_t)(d >> 32);
             f[0] = (uint32_t)d;
-            f[1] = hi & 0xffffu;
-            f[2] = hi >> 16;
+            f[1] = (uint32_t)(d >> 32);
         }
     }
     // One descriptor over the whole chunk; the cell load adds the scalar offset 4*cnt, which
@@ -368,10 +369,11 @@ struct PackedLayout {
                          : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u), "s"(first_cell), "v"(lane), "s"(cnt)
                          : "memory", "vcc", "scc");
         } else {
-            const v4i srd = {(int)f[0], (int)f[1], (int)(f[2] * 6u), kRawBufferFormat};
+            const uint32_t cnt = f[1] >> 16;
+            const v4i srd = {(int)f[0], (int)(f[1] & 0xffffu), (int)(cnt * 6u), kRawBufferFormat};
             asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
                          : "=&v"(score), "=&v"(cell)
-                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(f[2] * 4u)
+                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u)
                          : "memory");
         }
     }
@@ -860,8 +862,16 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             }                                                                          \
         }                                                                              \
     }
+    // (timing experiments, EPIK_AMD_ABLATE bits 256 / 512 / 1024 / 2048: the epilogue stops behind its correction
+    // sweep / tau / scan sweep / rank -- rows cleared, no result; SQ_INSTS_VALU of such runs tells the parts apart)
+#define EPI_STOP(bit)                                                              \
+    if (p.ablate & (bit)) {                                                        \
+        lds.clear((uint32_t)__builtin_amdgcn_readfirstlane((int)ctx.rows_pad(p))); \
+        return;                                                                    \
+    }
 #else
 #define EPI_STAMP(k)
+#define EPI_STOP(bit)
 #endif
     typedef WaveLds<CountT> Lds_t;
     EPI_STAMP(10)  // entered
@@ -988,6 +998,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
     else
         correction_sweep(std::false_type{});
     EPI_STAMP(0)  // correction sweep
+    EPI_STOP(256u)
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
     const float thr_score = __fdiv_rn(__fmul_rn(nk_f, log_thr), k_f);  // :175 / :146-147
 
@@ -1043,8 +1054,14 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         best_score = unord_f32(top);
     }
     EPI_STAMP(1)  // tau
+    EPI_STOP(512u)
     const float ref_score = fmaxf(best_score, thr_score);
     const bool relative_sum = ref_score > -280.0f;  // wave-uniform
+    // Below 10^-325 a power is zero in double whatever computes it (a fiftieth of the smallest denormal): with the
+    // largest term there, sum_scores is 0 term by term and every reported row's power is 0 -- nothing to evaluate.
+    // (A protein read of 300 residues lives here: its threshold score alone is 294 * log10(threshold) / 7 = -374;
+    // the double-precision loop over every touched row was a quarter of such a read's instructions.)
+    const bool all_underflow = ref_score < -325.0f;  // wave-uniform
     if (touched != 0) {
         n_cand = 0;
         // every edge's score is finite, every other row holds -inf: one comparison tells a candidate
@@ -1132,6 +1149,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         }
     }
     EPI_STAMP(2)  // scan sweep
+    EPI_STOP(1024u)
     // ---- rank: <= 3 candidates per lane, rank = number of candidates with a larger key --------
     const uint32_t n_q = (n_cand + kWave - 1) / kWave;
     uint64_t my_key[kQ];
@@ -1166,6 +1184,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         }
     }
     EPI_STAMP(3)  // rank
+    EPI_STOP(2048u)
     if constexpr (Ctx::kTeam) {
         // ---- one slice of a team placement: ranked rows and partial sum to the merge area ----------
         double sum;
@@ -1173,7 +1192,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             sum = wave_sum_f64((double)rel_sum);
         } else {  // everything in double, term by term, as place.cpp:178-182
             sum = 0.0;
-            for (uint32_t i = lane; i < N; i += kWave) {
+            for (uint32_t i = lane; i < N && !all_underflow; i += kWave) {
                 const uint2 cv = lds.load(i);
                 if (cv.y != 0) sum += pow10_f64((double)__uint_as_float(cv.x));
             }
@@ -1213,7 +1232,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         my_power[q] = 0.0;
         if ((uint32_t)q < n_q) {
             const bool has_row = my_key[q] != 0 && my_rank[q] < n_sel;
-            if (has_row) my_power[q] = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));
+            if (has_row && !all_underflow) my_power[q] = pow10_f64((double)unord_f32((uint32_t)(my_key[q] >> 32)));
             const uint64_t first = __ballot(has_row && my_rank[q] == 0);
             if (first)
                 best_power = __longlong_as_double(
@@ -1233,12 +1252,14 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         } else {
             // everything in double, term by term, as place.cpp:174-183
             double sum_placed = 0.0;
-            for (uint32_t i = lane; i < N; i += kWave) {
-                const uint2 cv = lds.load(i);
-                if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
+            if (!all_underflow) {
+                for (uint32_t i = lane; i < N; i += kWave) {
+                    const uint2 cv = lds.load(i);
+                    if (cv.y != 0) sum_placed += pow10_f64((double)__uint_as_float(cv.x));
+                }
+                sum_placed = wave_sum_f64(sum_placed);
             }
-            sum_placed = wave_sum_f64(sum_placed);
-            score_sum = (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
+            score_sum = all_underflow ? 0.0 : (double)not_placed * pow10_f64((double)thr_score) + sum_placed;
         }
     }
     const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251

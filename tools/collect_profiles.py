@@ -37,6 +37,8 @@ FILES = {
     "shard_rate.txt": f"{ROUND}_shard_rate_place_sharded.txt",
     "sq_counters_headline.txt": f"{ROUND}_sq_counters.txt",
     "sq_counters_n9999_team.txt": f"{ROUND}_sq_counters_n9999_team.txt",
+    "sq_counters_k11.txt": f"{ROUND}_sq_counters_k11.txt",
+    "sq_counters_amino_k7.txt": f"{ROUND}_sq_counters_amino_k7_1g.txt",
     "team_instruction_counts.txt": f"{ROUND}_team_instruction_counts.txt",
     "team_stream_wave_timeline.txt": f"{ROUND}_team_stream_wave_timeline.txt",
     "sweep_tree_sizes_passes.txt": f"{ROUND}_sweep_tree_sizes_passes.txt",
@@ -50,6 +52,17 @@ def counters(path, kernel):
         if len(parts) >= 4 and parts[0] == "bench" and parts[1] == kernel:
             out[parts[2]] = float(parts[3].split("=")[1])
     return out
+
+
+def valu_busy(path, kernel):
+    """Share of the kernel's cycles in which a SIMD's vector ALU is executing: SQ_ACTIVE_INST_VALU counts quad-cycles
+    of VALU work summed over the 1024 SIMDs, SQ_BUSY_CYCLES the kernel's cycles summed over the 32 shader engines:
+    ACTIVE x 4 / 1024 / (BUSY / 32) = ACTIVE / (8 x BUSY)."""
+    try:
+        c = counters(path, kernel)
+        return c["SQ_ACTIVE_INST_VALU"] / (8.0 * c["SQ_BUSY_CYCLES"])
+    except (OSError, KeyError, ZeroDivisionError):
+        return None
 
 
 def main():
@@ -80,17 +93,19 @@ def main():
                    f"(MI355X_MICROARCH.md, HBM section) -> x2 x 1024 = {c['FETCH_SIZE'] * 2048:.4g} B; calibration streams of "
                    "tools/calib_fetch.hip in the same summary file"),
         "l2_hit_rate": c["TCC_HIT_sum"] / c["TCC_REQ_sum"],
+        "valu_busy": valu_busy(os.path.join(src, "sq_counters_headline.txt"), "place_reads_kernel"),
         "source": f"profiles/{ROUND}_pmc_summary.txt",
         "note": "bench.py reports these numbers only while kernel_source_sha equals the hash of the kernel sources it "
                 "runs (epik_amd/provenance.py); `workloads` is keyed by the exact config.workload string of the bench line",
         "workloads": {},
         "previous": dict(old.get("previous", {}), **{"r02 final (headline)": old.get("hbm_bytes_per_launch")}),
     }
-    for bench_file, kerns, f, out in (("bench_k11.json", ("place_reads_kernel",), "pmc_summary_k11.txt", f"{ROUND}_pmc_summary_k11.txt"),
-                                      ("bench_n9999.json", ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"),
-                                       "pmc_summary_n9999.txt", f"{ROUND}_pmc_summary_n9999_team.txt"),
-                                      ("bench_amino_k7.json", ("place_reads_kernel",), "pmc_summary_amino_k7.txt",
-                                       f"{ROUND}_pmc_summary_amino_k7_1g.txt")):
+    for bench_file, kerns, f, out, sq in (("bench_k11.json", ("place_reads_kernel",), "pmc_summary_k11.txt",
+                                           f"{ROUND}_pmc_summary_k11.txt", "sq_counters_k11.txt"),
+                                          ("bench_n9999.json", ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"),
+                                           "pmc_summary_n9999.txt", f"{ROUND}_pmc_summary_n9999_team.txt", "sq_counters_n9999_team.txt"),
+                                          ("bench_amino_k7.json", ("place_reads_kernel",), "pmc_summary_amino_k7.txt",
+                                           f"{ROUND}_pmc_summary_amino_k7_1g.txt", "sq_counters_amino_k7.txt")):
         try:
             line = json.loads(open(os.path.join(src, bench_file)).read().strip().splitlines()[-1])
             per_kernel = [counters(os.path.join(src, f), kern) for kern in kerns]
@@ -104,7 +119,9 @@ def main():
         doc["workloads"][line["config"]["workload"]] = {
             "hbm_bytes_per_launch": total("TCC_EA0_RDREQ_128B_sum") * 128.0 + total("TCC_EA0_RDREQ_64B_sum") * 64.0
                                     + total("TCC_EA0_RDREQ_32B_sum") * 32.0,
-            "l2_hit_rate": total("TCC_HIT_sum") / total("TCC_REQ_sum"), "kernels": list(kerns), "source": "profiles/" + out}
+            "l2_hit_rate": total("TCC_HIT_sum") / total("TCC_REQ_sum"), "kernels": list(kerns), "source": "profiles/" + out,
+            # (of the kernel that takes the time: the one-wavefront kernel, or the streaming kernel of the three)
+            "valu_busy": valu_busy(os.path.join(src, sq), kerns[0] if len(kerns) == 1 else "team_stream_kernel")}
     json.dump(doc, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("traffic:", doc["hbm_bytes_per_launch"], "sha", doc["kernel_source_sha"], "workloads", len(doc["workloads"]))
 

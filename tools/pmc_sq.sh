@@ -6,8 +6,10 @@ TAG=${1:-sq}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+# SQ_PASSES="sq1 sq2": only those passes (default: all)
 pass() { local name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/bench_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-extras $BENCH_ARGS > $OUT/bench_$name.log 2>&1 || echo "pass $name failed"
+  if [[ -n "$SQ_PASSES" && " $SQ_PASSES " != *" $name "* ]]; then return; fi
+  timeout -k 10 ${SQ_TIMEOUT:-300} rocprofv3 --pmc "$@" --output-format csv -d $OUT/bench_$name -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-extras $BENCH_ARGS > $OUT/bench_$name.log 2>&1 || echo "pass $name failed"
 }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS
 pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT

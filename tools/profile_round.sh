@@ -53,6 +53,13 @@ for cfg in "headline:" "n9999_team:--leaves 5000"; do
   (cd $R && BENCH_ARGS="$args" bash tools/pmc_sq.sh ${TAG}_sq_$name > $OUT/sq_$name.log 2>&1)
   cp $R/gpurun_out/pmc_${TAG}_sq_$name/summary.txt $OUT/sq_counters_$name.txt 2>/dev/null
 done
+# (how busy the vector ALUs are on the other two workloads: the instruction counters only)
+for cfg in "k11:--kmer-size 11" "amino_k7:--states amino --kmer-size 7 --read-length 300 --p-present 0.0133"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  log "SQ counter passes (sq1, sq2): $name"
+  (cd $R && BENCH_ARGS="$args" SQ_PASSES="sq1 sq2" SQ_TIMEOUT=500 bash tools/pmc_sq.sh ${TAG}_sq_$name > $OUT/sq_$name.log 2>&1)
+  cp $R/gpurun_out/pmc_${TAG}_sq_$name/summary.txt $OUT/sq_counters_$name.txt 2>/dev/null
+done
 log "instruction counts of the team kernels by phase (diagnostic build)"
 (cd $R && make -C epik_amd/csrc ablate > /dev/null 2>&1 && bash tools/pmc_insts_team.sh > $OUT/team_instruction_counts.txt 2>&1)
 log "timeline of one wave of the streaming kernel (diagnostic build)"
