@@ -100,7 +100,8 @@ def load_counters(workload: str) -> dict:
 
 
 # What random 128-byte line reads get from a working set far larger than the Infinity Cache (tools/probe_mall.hip:
-# 6.3 TB/s on 4 GB): the bound of a workload made of table lookups rather than of posting streams.
+# 6.3 TB/s on 4 GB with four consecutive lines per wave; tools/probe_lines.hip: 6.3 TB/s on 16 GB with a line per
+# LANE, the shape of a lookup): the bound of a workload made of table lookups rather than of posting streams.
 RANDOM_LINE_GBPS = 6300.0
 
 
@@ -567,6 +568,7 @@ def main():
                                        f"({shard_info['partials']} partials), overlapped with the next batch's accumulate"
                                        if kmer_shard else
                                        f"reads sharded over {world} GPU(s), DB replicated, no collective"),
+                       "collectives": (dist.get_backend() if dist is not None else None),
                        "launch": info, "mean_rows_per_read": float(n_rows_host.mean()),
                        **({"kmer_shard": shard_info} if shard_info else {})},
             "roofline": roofline_of(placer, plan, kernel_ms, workload),

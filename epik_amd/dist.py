@@ -45,10 +45,16 @@ def init_process_group(backend: str | None = None, device_index: int | None = No
     """Initialises torch.distributed from the environment; returns the module or None when
     WORLD_SIZE == 1.  backend None = "nccl" (RCCL) with a GPU, else "gloo"."""
     rank, local_rank, world = env_rank_world()
-    if world <= 1:
+    # EPIK_AMD_DIST_WORLD1=1: a process group of ONE rank, so that the collectives of the multi-GPU paths (their dtypes,
+    # split sizes, streams) run on the real backend -- RCCL -- on a box with a single device (tests, bench.py)
+    if world <= 1 and os.environ.get("EPIK_AMD_DIST_WORLD1") != "1":
         return None
     import torch
     import torch.distributed as dist
+    if world <= 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29577")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kwargs = {}
