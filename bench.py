@@ -532,7 +532,7 @@ def main():
             # what else bounds the kernel: the share of its cycles in which a SIMD's vector ALU is executing
             # (SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel cycles, the committed SQ counter pass of this workload)
             roof["valu_busy"] = measured["valu_busy"]
-        if traffic:
+        if traffic and working_set > 2 * MALL_BYTES:  # (a working set the Infinity Cache mostly holds is not priced against HBM's rate)
             # The SURVEY 8(d) formula charges 8 bytes per lookup; a lookup FETCHES a 128-byte line (of the table or
             # of the presence filter).  A workload that is mostly lookups -- a sparse protein database: 294 of them
             # per read against a few found lists -- is bound by how many random lines the memory system serves, so

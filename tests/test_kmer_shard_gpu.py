@@ -432,3 +432,38 @@ def test_the_collectives_run_on_rccl(gpu_available, mode):
     assert line["config"]["collectives"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
     if mode == "kmer-shard":
         assert line["config"]["kmer_shard"]["partials"] == "lists"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["reads", "kmer-shard"])
+def test_bench_with_two_ranks(gpu_available, mode):
+    """bench.py as the driver launches it for N = 2 -- torch.distributed.run, one process per rank, barrier + maximum
+    over ranks, one JSON line from rank 0 -- rehearsed on the one device (EPIK_AMD_BENCH_REHEARSAL=1: both ranks on
+    device 0, gloo in place of RCCL, which wants a device per rank)."""
+    assert gpu_available
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EPIK_AMD_BENCH_REHEARSAL="1", OMP_NUM_THREADS="1")
+    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_MAX_BLOCKS",
+                "EPIK_AMD_DIST_WORLD1"):
+        env.pop(var, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--reads-per-step", "16384", "--mode", mode]
+    if mode == "kmer-shard":
+        cmd += ["--leaves", "5000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [x for x in out.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["collectives"] == "gloo"
+    assert line["scaling"] == ("weak" if mode == "reads" else "strong")
+    assert "cpu_baseline" not in line or line["cpu_baseline"] is None  # N = 1 only
