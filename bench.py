@@ -70,6 +70,10 @@ def parse_args():
                     help="skip the HBM-resident second pass and the end-to-end driver run")
     ap.add_argument("--scattered", action="store_true",
                     help="non-contiguous branch sets in the synthetic posting lists")
+    ap.add_argument("--clades", action="store_true",
+                    help="a database shaped like one built from reference sequences (synth.make_clade_db: the k-mers of a "
+                         "reference carry lists over the reference's clade) and reads cut from the references: a read adds "
+                         "k-mer after k-mer into the same rows")
     ap.add_argument("--states", choices=["nucl", "amino"], default="nucl",
                     help="amino: the protein path (BASELINE configs[3]: --states amino --kmer-size 7 "
                          "--read-length 300 --p-present 0.0026); the default line is configs[1]")
@@ -300,7 +304,12 @@ def main():
     # (a key space too large to draw one number per code -- amino k = 7: 1.28 G codes -- gets its present codes drawn
     # directly, and goes to create() in the sparse form of the descriptor: keys[present] + offsets, ABI 3)
     big_key_space = alphabet.alphabet_size(args.states) ** args.kmer_size > (1 << 28)
-    if big_key_space and not kmer_shard:
+    clade_refs = None
+    if args.clades:
+        if kmer_shard or args.states != "nucl":
+            raise SystemExit("--clades: nucleotide databases, reads-sharded mode")
+        db, clade_refs, _ = synth.make_clade_db(tree.num_nodes, kmer_size=args.kmer_size, seed=47)
+    elif big_key_space and not kmer_shard:
         db = synth.make_sparse_db(tree.num_nodes, states=args.states, kmer_size=args.kmer_size, seed=43,
                                   p_present=args.p_present, dense=False)
         db.total_entries = db.num_entries
@@ -309,14 +318,19 @@ def main():
                            p_present=args.p_present, scattered=args.scattered,
                            shard=(rank, world) if kmer_shard else None)
     total_entries = db.total_entries
-    data, offs = synth.make_reads(args.reads_per_step, args.read_length, states=args.states,
-                                  seed=44 if kmer_shard else 44 + rank)
+    if clade_refs is not None:
+        data, offs = synth.make_clade_reads(clade_refs, args.reads_per_step, args.read_length, seed=48 + rank)
+    else:
+        data, offs = synth.make_reads(args.reads_per_step, args.read_length, states=args.states,
+                                      seed=44 if kmer_shard else 44 + rank)
     unit = "bp" if args.states == "nucl" else "aa"
     workload = (f"{args.states} k={args.kmer_size} omega=1.5 mu=1.0 synthetic DB, N={tree.num_nodes} branches, "
                 f"{total_entries} postings ({total_entries * 8 / 1e6:.0f} MB), "
                 f"{args.reads_per_step} x {args.read_length} {unit} reads per step per GPU"
                 + (", scattered branch sets" if args.scattered else "")
-                + (f", {args.p_present:g} of the codes present" if args.p_present != 0.6 else ""))
+                + (f", {args.p_present:g} of the codes present" if args.p_present != 0.6 and not args.clades else "")
+                + (", lists over the clades of 500 references of 1500 bp, reads cut from the references (1 % substitutions)"
+                   if args.clades else ""))
     if kmer_shard:  # every rank holds the same reads; --reads-per-step is the whole job's batch
         workload += f"; k-mer-space shard over {world} GPU(s), {args.reads_per_step} reads per step in total"
 

@@ -323,3 +323,72 @@ def reads_hitting(db: SynthDB, n_reads: int, length: int, hit_rate: float, seed:
             seqs[rows, rng.integers(0, length, size=rows.shape[0])] = d[rng.integers(0, d.shape[0], size=rows.shape[0])]
     offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(length)
     return seqs.reshape(-1).copy(), offsets
+
+
+def make_clade_db(num_branches: int, kmer_size: int = 10, omega: float = 1.5, n_refs: int = 500, ref_length: int = 1500,
+                  width=(3.4, 0.6), seed: int = 47):
+    """A database shaped like one built from reference sequences (what a real phylo-k-mer database is): `n_refs`
+    random nucleotide references, each at home in a clade of the tree -- a run of branches around a centre --, and
+    every k-mer of a reference carries a list over (most of) that clade: the lists of CONSECUTIVE k-mers of a
+    reference cover nearly the same branches, their scores highest at the clade's centre.  make_db() draws every
+    list's position independently, so the k-mers of a read land all over the tree; here a read cut from a reference
+    (make_clade_reads) adds k-mer after k-mer into the same few dozen rows -- consecutive chunks of the stream
+    update the SAME LDS rows, and a row's count climbs to the number of k-mers of the read.
+    Returns (SynthDB, refs uint8[n_refs, ref_length] of states 0..3, centres)."""
+    assert kmer_size <= 15
+    rng = np.random.default_rng(seed)
+    sigma = 4
+    num_keys = sigma ** kmer_size
+    threshold = alphabet.score_threshold(omega, kmer_size, sigma)
+    refs = rng.integers(0, sigma, size=(n_refs, ref_length), dtype=np.uint8)
+    centres = rng.integers(0, num_branches, size=n_refs)
+    n_pos = ref_length - kmer_size + 1
+    codes = np.zeros((n_refs, n_pos), dtype=np.int64)
+    for j in range(kmer_size):
+        codes = codes * sigma + refs[:, j:j + n_pos]
+    # a code met in several places keeps the first one (reference order)
+    flat = codes.reshape(-1)
+    uniq, first = np.unique(flat, return_index=True)
+    ref_of = first // n_pos
+    # the list of a k-mer: centre +- a few branches of jitter, a width of its own around the clade's
+    clade_w = np.maximum(2, rng.lognormal(width[0], width[1], size=n_refs)).astype(np.int64)
+    w = np.maximum(1, (clade_w[ref_of] * rng.uniform(0.6, 1.2, size=uniq.shape[0])).astype(np.int64))
+    w = np.minimum(w, num_branches)
+    mid = centres[ref_of] + rng.integers(-3, 4, size=uniq.shape[0])
+    start = np.clip(mid - w // 2, 0, num_branches - w)
+    offsets = np.zeros(num_keys + 1, dtype=np.uint64)
+    lens = np.zeros(num_keys, dtype=np.int64)
+    lens[uniq] = w
+    np.cumsum(lens, out=offsets[1:].view(np.int64))
+    total = int(offsets[-1])
+    values = np.empty(total, dtype=PKDB_VALUE)
+    list_id = np.repeat(np.arange(uniq.shape[0], dtype=np.int64), w)   # uniq is ascending: CSR order
+    list_start = np.cumsum(w) - w
+    within = np.arange(total, dtype=np.int64) - list_start[list_id]
+    br = start[list_id] + within
+    values["branch"] = br.astype(np.uint32)
+    # probability: near 1 at the clade's centre, falling towards the threshold at its edges (+ noise)
+    dist = np.abs(br - centres[ref_of][list_id]).astype(np.float64) / np.maximum(1, clade_w[ref_of][list_id])
+    closeness = np.clip(1.0 - dist + rng.normal(0.0, 0.15, size=total), 0.02, 1.0)
+    prob = float(threshold) + closeness * (0.9 - float(threshold))
+    values["score"] = np.log10(prob).astype(np.float32)
+    db = SynthDB(states="nucl", kmer_size=kmer_size, omega=omega, num_branches=num_branches, offsets=offsets,
+                 values=values, threshold=threshold)
+    db.total_entries = total
+    return db, refs, centres
+
+
+def make_clade_reads(refs: np.ndarray, n_reads: int, length: int, substitutions: float = 0.01, seed: int = 48):
+    """Reads cut from the references of make_clade_db at random places, `substitutions` of their letters replaced."""
+    rng = np.random.default_rng(seed)
+    n_refs, ref_length = refs.shape
+    chars = np.frombuffer(alphabet.state_chars("nucl").encode(), dtype=np.uint8)
+    which = rng.integers(0, n_refs, size=n_reads)
+    at = rng.integers(0, ref_length - length + 1, size=n_reads)
+    idx = at[:, None] + np.arange(length)[None, :]
+    states = refs[which[:, None], idx]
+    flip = rng.random(size=states.shape) < substitutions
+    states = np.where(flip, rng.integers(0, 4, size=states.shape, dtype=np.uint8), states)
+    seqs = chars[states]
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(length)
+    return np.ascontiguousarray(seqs.reshape(-1)), offsets

@@ -259,3 +259,29 @@ def test_place_widens_forced_counts_instead_of_marking_reads(placer_cls, oracle_
         assert int(got[1].max()) <= pl.keep_at_most and capi.ROWS_COUNTS_TOO_NARROW not in got[1]
         # ... while a device-pointer launch with counts the caller chose too narrow says so, per read
     assert_rows_match(*got, *ref)
+
+
+def test_reads_cut_from_references_land_in_the_same_rows(placer_cls, oracle_lib):
+    """A database built like a real one -- the k-mers of a reference all carry lists over the reference's clade
+    (synth.make_clade_db) -- and reads cut from the references: k-mer after k-mer adds into the SAME few dozen rows,
+    so consecutive chunks of the stream update the same LDS cells back to back (the order of a row's float32 adds is
+    what keeps the score bits; make_db spreads a read's lists over the tree and rarely produces that) and a row's
+    count reaches the number of k-mers of the read.  Reads of 150 and of 300 letters (8-bit counts hold 255 k-mers:
+    the longer reads take the 16-bit kernels), a few with ambiguous letters."""
+    db, refs, _ = synth.make_clade_db(999, n_refs=80, ref_length=700, seed=5)
+    d1, o1 = synth.make_clade_reads(refs, 1500, 150, seed=6)
+    d2, o2 = synth.make_clade_reads(refs, 500, 300, substitutions=0.03, seed=7)
+    reads = [bytes(d1[int(o1[i]):int(o1[i + 1])]) for i in range(1500)] + [bytes(d2[int(o2[i]):int(o2[i + 1])]) for i in range(500)]
+    for i in range(0, len(reads), 50):  # an ambiguous letter in the middle of every fiftieth read
+        r = bytearray(reads[i])
+        r[len(r) // 2] = ord("N") if i % 100 else ord("R")
+        reads[i] = bytes(r)
+    data, offs = synth.pack_reads(reads)
+    orc = oracle_lib.Oracle.from_synth(db)
+    ref = orc.place(data, offs, num_threads=0)
+    with placer_cls.from_synth(db) as pl:
+        got = pl.place_packed(data, offs)
+    assert_rows_match(*got, *ref)
+    # the workload is what it claims: the best row of a typical read was hit by most of its k-mers
+    top_counts = ref[2][:1500, 0]
+    assert np.median(top_counts) > 100, np.median(top_counts)
