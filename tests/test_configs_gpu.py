@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_rows_match, mixed_reads, select_kernel
-from epik_amd import synth
+from epik_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -22,6 +22,21 @@ def amino_k7(gpu_available):
     db = synth.make_sparse_db(tree.num_nodes, states="amino", kmer_size=7, p_present=0.0026, seed=43)
     data, offs = synth.reads_hitting(db, 3000, 300, hit_rate=0.25, seed=46, dirty="BZXJ*")
     return db, data, offs
+
+
+@pytest.fixture(scope="module")
+def amino_k7_placer(amino_k7):
+    """One placer on the protein database for the tests that take what create() chooses (the filtered layout): building
+    the 10 GB table again for each of them is most of their time."""
+    import os
+    from epik_amd.placer import Placer
+    saved = {v: os.environ.pop(v, None) for v in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_RUNS")}
+    try:
+        pl = Placer.from_synth(amino_k7[0])
+    finally:
+        os.environ.update({k: v for k, v in saved.items() if v is not None})
+    yield pl
+    pl.close()
 
 
 @pytest.mark.parametrize("layout", ["filtered", "packed"])
@@ -80,7 +95,7 @@ def test_amino_k7_sparse_descriptor_needs_no_array_per_code(amino_k7, oracle_lib
     assert_rows_match(*got, *oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
 
 
-def test_amino_k7_100k_reads(amino_k7, oracle_lib, monkeypatch):
+def test_amino_k7_100k_reads(amino_k7, amino_k7_placer, oracle_lib, monkeypatch):
     """configs[3] beyond a handful of reads: 100 000 protein reads of 300 residues (B / Z / X / J / * in a quarter of
     them) through the size-independent properties -- well-formed rows, idempotent, independent of the order of
     the batch -- and a random sample of them through the oracle, bit for bit (as test_fullsize_gpu does for DNA)."""
@@ -90,11 +105,11 @@ def test_amino_k7_100k_reads(amino_k7, oracle_lib, monkeypatch):
     monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)   # what create() chooses: the filtered layout
     n = 100_000
     data, offs = synth.reads_hitting(db, n, 300, hit_rate=0.25, seed=52, dirty="BZXJ*")
-    with Placer.from_synth(db) as pl:
-        first = pl.place_packed(data, offs)
-        again = pl.place_packed(data, offs)
-        perm = np.random.default_rng(6).permutation(n)
-        shuffled = pl.place_packed(data.reshape(n, 300)[perm].reshape(-1), offs)
+    pl = amino_k7_placer
+    first = pl.place_packed(data, offs)
+    again = pl.place_packed(data, offs)
+    perm = np.random.default_rng(6).permutation(n)
+    shuffled = pl.place_packed(data.reshape(n, 300)[perm].reshape(-1), offs)
     rows, n_rows, counts = first
     keep = rows.shape[1]
     assert n_rows.min() >= 1 and n_rows.max() <= keep
@@ -113,6 +128,30 @@ def test_amino_k7_100k_reads(amino_k7, oracle_lib, monkeypatch):
     sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
     ref = oracle_lib.Oracle.from_synth(db).place(sample, sample_offs, num_threads=0)
     assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
+
+
+def test_protein_reads_across_the_underflow_limits(amino_k7, amino_k7_placer, oracle_lib, monkeypatch):
+    """sum_scores has three regimes by the size of its largest term 10^ref: relative to it in float32 (ref > -280),
+    term by term in double (down to -325, where a double still holds a denormal), and nothing to add at all below that
+    (every term is 0 in double: the epilogue skips the loop).  Protein reads of 170 to 350 residues cross both limits
+    -- their threshold score is n_kmers * log10(threshold) / 7, from -209 to -438 -- and every one must come out as the
+    oracle's, like-weight ratios of 0 and denormal ratios included."""
+    from epik_amd.placer import Placer
+    db, _, _ = amino_k7
+    monkeypatch.delenv("EPIK_AMD_KERNEL", raising=False)
+    monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
+    lengths = np.repeat(np.arange(170, 351, 2), 12)
+    long_data, _ = synth.reads_hitting(db, len(lengths), 350, hit_rate=0.3, seed=1000, dirty="BX")  # (one draw: finding
+    long_data = long_data.reshape(len(lengths), 350)                                               # present codes is slow)
+    data, offs = synth.pack_reads([bytes(long_data[i, :n]) for i, n in enumerate(lengths)])
+    ref = oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0)
+    best = ref[0]["score"][:, 0]
+    assert (best > -280).sum() > 50 and ((best < -280) & (best > -325)).sum() > 50 and (best < -325).sum() > 50, \
+        "the reads must fall on all three sides of the two limits"
+    lwr0 = ref[0]["lwr"][:, 0]
+    assert (lwr0 == 0).any() and (lwr0 > 0).any()
+    got = amino_k7_placer.place_packed(data, offs)
+    assert_rows_match(*got, *ref)
 
 
 @pytest.fixture(scope="module")
@@ -210,3 +249,24 @@ def test_release_scratch_and_place_again(large_tree, monkeypatch):
         again = pl.place_packed(data, offs)
     for a, b in zip(first, again):
         assert a.tobytes() == b.tobytes()
+
+
+def test_long_reads_on_the_large_tree_across_the_underflow_limits(large_tree, oracle_lib, monkeypatch):
+    """The same three regimes of sum_scores (test_protein_reads_across_the_underflow_limits) through the team kernels,
+    where every slice hands the merge its share of the sum: nucleotide reads of 300 to 1 300 letters on the N = 9 999
+    tree (k = 8: the threshold score is n_kmers * -4.64 / 8, -170 to -750; the best row lies well above it)."""
+    from epik_amd.placer import Placer
+    _, db = large_tree
+    monkeypatch.delenv("EPIK_AMD_KERNEL", raising=False)   # what create() chooses for this tree: the team kernels
+    monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
+    rng = np.random.default_rng(77)
+    reads = ["".join(rng.choice(list("ACGT"), size=length)) for length in range(300, 1301, 8) for _ in range(4)]
+    data, offs = synth.pack_reads(reads)
+    ref = oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0)
+    best = ref[0]["score"][:, 0]
+    assert (best > -280).sum() > 50 and ((best < -280) & (best > -325)).sum() > 20 and (best < -325).sum() > 50, \
+        (int((best > -280).sum()), int(((best < -280) & (best > -325)).sum()), int((best < -325).sum()))
+    with Placer.from_synth(db) as pl:
+        got = pl.place_packed(data, offs)
+        assert pl.last_path() != capi.PATH_WAVE
+    assert_rows_match(*got, *ref)
