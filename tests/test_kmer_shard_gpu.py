@@ -398,72 +398,3 @@ def test_dense_partials_mark_reads_of_more_than_65535_kmers(gpu_available, db_la
         accumulate, finish = edist.kmer_sharded_gpu_fns(pl, data, offs, dev)
         rows, n_rows, _ = edist.place_kmer_sharded(accumulate, finish, 2, None)
     assert int(n_rows[0]) == capi.ROWS_COUNTS_TOO_NARROW and 1 <= int(n_rows[1]) <= 7
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["reads", "kmer-shard"])
-def test_the_collectives_run_on_rccl(gpu_available, mode):
-    """The multi-GPU paths of bench.py with a process group of ONE rank on the real backend (nccl = RCCL): the barrier and
-    the maximum over ranks of the reads-sharded mode; the gather of the part sizes, the all-to-all of the partial lists
-    with split sizes and of their index as byte views, on the communication stream, of the k-mer-space shard.  (Two ranks
-    need two devices: RCCL refuses two ranks on one.  What this pins is that every collective is called with dtypes,
-    shapes and streams RCCL accepts -- the exchange itself is rank 0 talking to rank 0.)"""
-    assert gpu_available
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, EPIK_AMD_DIST_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0")
-    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_MAX_BLOCKS"):
-        env.pop(var, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras",
-           "--cpu-baseline-seconds", "0", "--reads-per-step", "8192", "--mode", mode]
-    if mode == "kmer-shard":
-        cmd += ["--leaves", "5000"]  # the team kernels: partial lists
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["config"]["collectives"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
-    if mode == "kmer-shard":
-        assert line["config"]["kmer_shard"]["partials"] == "lists"
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["reads", "kmer-shard"])
-def test_bench_with_two_ranks(gpu_available, mode):
-    """bench.py as the driver launches it for N = 2 -- torch.distributed.run, one process per rank, barrier + maximum
-    over ranks, one JSON line from rank 0 -- rehearsed on the one device (EPIK_AMD_BENCH_REHEARSAL=1: both ranks on
-    device 0, gloo in place of RCCL, which wants a device per rank)."""
-    assert gpu_available
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, EPIK_AMD_BENCH_REHEARSAL="1", OMP_NUM_THREADS="1")
-    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_MAX_BLOCKS",
-                "EPIK_AMD_DIST_WORLD1"):
-        env.pop(var, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--reads-per-step", "16384", "--mode", mode]
-    if mode == "kmer-shard":
-        cmd += ["--leaves", "5000"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    lines = [x for x in out.stdout.strip().splitlines() if x.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["collectives"] == "gloo"
-    assert line["scaling"] == ("weak" if mode == "reads" else "strong")
-    assert "cpu_baseline" not in line or line["cpu_baseline"] is None  # N = 1 only
