@@ -260,7 +260,12 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
 
     // the sides of this set of handles: from the last call, or new
     ShardState *state = static_cast<ShardState *>(shards[0]->shard_state);
-    if (state && (state->handles.size() != G || !std::equal(state->handles.begin(), state->handles.end(), shards))) {
+    // (the same handles -- and still the same streams: a handle destroyed and another created at its address is not it)
+    bool same = state && state->handles.size() == G && std::equal(state->handles.begin(), state->handles.end(), shards);
+    for (uint32_t g = 0; same && state->ready && g < G; ++g)
+        same = state->sides[g].compute == shards[g]->stream && state->sides[g].copy == shards[g]->stream_in &&
+               state->sides[g].device == shards[g]->device;
+    if (state && !same) {
         delete state;
         state = nullptr;
         shards[0]->shard_state = nullptr;
