@@ -44,6 +44,17 @@ def kernels(lines):
 
 def lint_loop(name, body, events, problems):
     """One ring loop: `events` are its asm statements in program order."""
+    # The ring of a round that starts empty is filled by a first trip of loads alone (no stage, no wait): straight-line
+    # code in front of the loop, in which a slot's registers are in flight from its load on and free before it.
+    k = 0
+    while k < len(events) and events[k][1] == "load":
+        k += 1
+    if 2 <= k < len(events):
+        start = events[0][0]
+        while start > 0 and not body[start].strip().startswith(";;#ASMSTART"):
+            start -= 1
+        _walk(name, body, start, events[k][0] - 1, set(), problems)
+        events = events[k:]
     ring = set()
     for e in events:
         if e[1] == "load":
@@ -81,8 +92,19 @@ def lint_loop(name, body, events, problems):
 def _walk(name, body, lo, hi, inflight, problems):
     inflight = set(inflight)
     in_asm = False
+    skip_to = None  # behind an unconditional branch forwards: the walk goes on at its target (what lies between is
+                    # reached from elsewhere -- the path that skipped the loop, on which nothing is in flight)
     for n in range(lo, min(hi, len(body) - 1) + 1):
         s = body[n].strip()
+        if skip_to is not None:
+            if s.startswith(skip_to + ":"):
+                skip_to = None
+            continue
+        if not in_asm and s.startswith("s_branch "):
+            target = s.split()[1]
+            if any(body[m].strip().startswith(target + ":") for m in range(n + 1, min(n + 80, len(body)))):
+                skip_to = target  # (the target may lie behind `hi`: then the walk ends inside the skipped block)
+            continue
         if s.startswith(";;#ASMSTART"):
             in_asm = True
             continue

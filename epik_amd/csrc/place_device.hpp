@@ -605,10 +605,12 @@ __device__ __forceinline__ void preload_chunk(uint64_t d, uint32_t &cell, uint32
     }
 }
 
+// n_real (<= n_padded, 0: all of them): how many of the descriptors are chunks -- the rest is padding, and the slots of
+// the last trip that hold padding are not retired.
 template <typename Layout, typename CountT, int kDepth = kRing, bool kPreloaded = false>
 __device__ __forceinline__ void stream_round(const PlaceParams &p, const typename WaveLds<CountT>::u64_t *chunks,
                                                        uint32_t n_padded, uint32_t score_top, uint32_t count_top,
-                                                       const Preloaded<kDepth> *pre = nullptr)
+                                                       const Preloaded<kDepth> *pre = nullptr, uint32_t n_real = 0)
 {
     typedef __attribute__((address_space(3))) float lds_f32;
     typedef __attribute__((address_space(3))) CountT lds_count;
@@ -659,12 +661,30 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
         }
         refill();
     };
+    if (n_padded == 0) return;  // (no caller does; the first trip below would fetch whatever the list held before)
     uint32_t sa, ca;  // addresses of the slot the next stage works on
-    addresses(ring_c[0], std::integral_constant<int, 0>{}, sa, ca, score_top, count_top);
-    // (preloaded: the ring starts out holding chunks 0 .. kDepth-1, and the first trip fetches the next kDepth)
+    // (preloaded: the ring starts out holding chunks 0 .. kDepth-1, and the first trip of the loop fetches the next kDepth)
     constexpr uint32_t kFirst = kPreloaded ? (uint32_t)kDepth : 0u;
     uint64_t d_next = chunks[kFirst + (lane & (kDepth - 1))];  // descriptors of the first trip, lane i <-> stage i
-    for (uint32_t c0 = kFirst; c0 < n_padded; c0 += kDepth) {
+    if constexpr (kPreloaded) {
+        addresses(ring_c[0], std::integral_constant<int, 0>{}, sa, ca, score_top, count_top);
+    } else {
+        // The ring is empty: the first trip only puts its chunks in flight (a stage here would read, add 0 to and
+        // write the dummy row: kDepth LDS round trips for nothing -- a sixth of a short list's time in the ring).
+        uint32_t field[Layout::kFields];
+        Layout::prepare(p, d_next, field);
+        d_next = chunks[kDepth + (lane & (kDepth - 1))];
+#pragma unroll
+        for (int i = 0; i < kDepth; ++i) {
+            uint32_t f[Layout::kFields];
+#pragma unroll
+            for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
+            Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]);
+        }
+        // slot 0 is the oldest of the kDepth in flight
+        addresses(ring_c[0], std::integral_constant<int, Layout::kWaitLoads *(kDepth - 1)>{}, sa, ca, score_top, count_top);
+    }
+    for (uint32_t c0 = (uint32_t)kDepth; c0 < n_padded; c0 += kDepth) {
         uint32_t field[Layout::kFields];
         Layout::prepare(p, d_next, field);
         d_next = chunks[c0 + kDepth + (lane & (kDepth - 1))];  // next trip (spare entries behind the end)
@@ -684,17 +704,21 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
             sa = sa_next, ca = ca_next;
         }
     }
-    // tail: nothing more to issue; retire the ring (slot 0 has been waited for; the rest after one drain)
+    // tail: nothing more to issue; retire the ring (slot 0 has been waited for; the rest after one drain -- the first
+    // stage's, which always runs: nothing is in flight when the function returns).  Slots that hold padding are left.
+    const uint32_t last_real = n_real ? n_real - (n_padded - (uint32_t)kDepth) : (uint32_t)kDepth;  // chunks in the last trip: 1 .. kDepth
 #pragma unroll
     for (int i = 0; i < kDepth; ++i) {
-        uint32_t sa_next = 0, ca_next = 0;
-        stage(
-            sa, ca, ring_s[i],
-            [&]() {
-                if (i + 1 < kDepth) addresses(ring_c[i + 1], std::integral_constant<int, 0>{}, sa_next, ca_next, score_top, count_top);
-            },
-            []() {});
-        sa = sa_next, ca = ca_next;
+        if (i == 0 || (uint32_t)i < last_real) {  // wave-uniform
+            uint32_t sa_next = 0, ca_next = 0;
+            stage(
+                sa, ca, ring_s[i],
+                [&]() {
+                    if (i + 1 < kDepth) addresses(ring_c[i + 1], std::integral_constant<int, 0>{}, sa_next, ca_next, score_top, count_top);
+                },
+                []() {});
+            sa = sa_next, ca = ca_next;
+        }
     }
 }
 
@@ -1046,9 +1070,16 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             const uint32_t trial = top & ~((1u << shared) - 1u);
             if (bit == 31 && trial != 0 && (uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial, bit = shared - 1;
         }
-        for (; bit >= kTauStop; --bit) {
-            const uint32_t trial = prefix | (1u << bit);
-            if ((uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel) prefix = trial;
+        auto reached = [&](uint32_t trial) { return (uint32_t)__popcll(__ballot(lane_best >= trial)) >= n_sel; };
+        if (((bit - kTauStop + 1) & 1) != 0 && bit >= kTauStop) {  // an odd number of bits: one by itself
+            if (reached(prefix | (1u << bit))) prefix |= 1u << bit;
+            --bit;
+        }
+        // two bits per step: the three comparisons do not depend on one another, the chain is half as long
+        for (; bit > kTauStop; bit -= 2) {
+            const uint32_t t1 = prefix | (1u << (bit - 1)), t2 = prefix | (2u << (bit - 1)), t3 = prefix | (3u << (bit - 1));
+            const bool r1 = reached(t1), r2 = reached(t2), r3 = reached(t3);
+            prefix = r3 ? t3 : r2 ? t2 : r1 ? t1 : prefix;
         }
         tau = prefix ? prefix : 1u;
         best_score = unord_f32(top);
@@ -1164,7 +1195,20 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             my_key[q] = ((uint64_t)c.x << 32) | (uint64_t)(~c.y);
         }
     }
-    if (!ranked_in_place) {
+    if (!ranked_in_place && n_q == 1) {
+        // The usual case, a candidate per lane at most (a dozen of them): candidate j's key comes out of lane j with
+        // two v_readlane and is compared in all lanes at once -- no trip to the LDS per candidate.  Lanes without a
+        // candidate hold key 0, which outranks nothing; two candidates per turn.
+        uint32_t rank_b = 0;
+        uint32_t j = 0;
+        for (; j + 2 <= n_cand; j += 2) {
+            const uint64_t ka = readlane_u64(my_key[0], (int)j), kb = readlane_u64(my_key[0], (int)j + 1);
+            my_rank[0] += ka > my_key[0] ? 1u : 0u;
+            rank_b += kb > my_key[0] ? 1u : 0u;
+        }
+        if (j < n_cand) my_rank[0] += readlane_u64(my_key[0], (int)j) > my_key[0] ? 1u : 0u;
+        my_rank[0] += rank_b;
+    } else if (!ranked_in_place) {
         // cand[j] is read at the same address by every lane (LDS broadcast); four per trip.
         // Entries past n_cand are stale: their key is forced to 0, which outranks nothing.
         for (uint32_t j0 = 0; j0 < n_cand; j0 += kUnroll) {

@@ -145,12 +145,17 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
             // bottleneck of a scalar list-walking generator).
             uint32_t nch[kTilesPerPass], first[kTilesPerPass];
             uint32_t total = 0;
+            bool found_any[kTilesPerPass];  // wave-uniform: a sparse database leaves half the tiles of a read without a list
 #pragma unroll
             for (int t = 0; t < kTilesPerPass; ++t) {
                 nch[t] = (Layout::length(llen[t]) + (uint32_t)kWave - 1u) >> 6;
-                const uint32_t incl = wave_incl_scan_u32(nch[t]);
-                first[t] = total + incl - nch[t];
-                total += __builtin_amdgcn_readlane(incl, 63);
+                found_any[t] = __ballot(nch[t] != 0) != 0;
+                first[t] = total;
+                if (found_any[t]) {
+                    const uint32_t incl = wave_incl_scan_u32(nch[t]);
+                    first[t] = total + incl - nch[t];
+                    total += __builtin_amdgcn_readlane(incl, 63);
+                }
             }
 #ifdef EPIK_AMD_ABLATION
             if (p.ablate & 8u) total = 0;   // lookups done, nothing streamed
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                 constexpr uint32_t kOwnChunks = 3;
 #pragma unroll
                 for (int t = 0; t < kTilesPerPass; ++t) {
+                    if (!found_any[t]) continue;
 #pragma unroll
                     for (uint32_t c = 0; c < kOwnChunks; ++c) {
                         const uint32_t idx = first[t] + c - w0;  // wraps when in front of the window
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256, 5) void place_reads_kernel(PlaceParams p)
                 if ((uint32_t)lane < n_padded - n_round) chunks[n_round + lane] = Layout::null_descriptor(p);
 
                 // (3) stream the chunks through the ring of kRing in-flight loads (place_device.hpp)
-                stream_round<Layout, CountT>(p, chunks, n_padded, score_top, count_top);
+                stream_round<Layout, CountT, kRing, false>(p, chunks, n_padded, score_top, count_top, nullptr, n_round);
             }
         }
 

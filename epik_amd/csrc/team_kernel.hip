@@ -309,7 +309,7 @@ __global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(Team
                             const uint32_t n_round = min(my_total - w0, cap);
                             const uint32_t n_padded = (n_round + kTeamRing - 1u) & ~(kTeamRing - 1u);
                             if ((uint32_t)lane < n_padded - n_round) lds.desc[n_round + lane] = null_chunk(p);
-                            stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_padded, score_top, count_top);
+                            stream_round<TeamChunks, CountT, (int)kTeamRing, false>(p, lds.desc, n_padded, score_top, count_top, nullptr, n_round);
                         }
                         TEAM_STAMP(4)  // stream
                         __syncthreads();

@@ -142,6 +142,42 @@ def test_generated_isa_keeps_its_hands_off_the_load_ring():
     assert run.stdout.count("ring-asm lint: 0 problem(s)") == 3   # place_kernel.hip, team_kernel.hip, team_stream.hip
 
 
+def test_the_ring_lint_sees_a_copy_of_a_register_in_flight(tmp_path):
+    """The lint itself: a two-slot ring in the shape hipcc emits passes; the same loop with one compiler-made copy of
+    a slot register between its load and its wait is reported -- in the loop, and in the first trip of loads alone
+    that fills an empty ring."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lint_ring_asm", os.path.join(root, "epik_amd", "csrc", "lint_ring_asm.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+
+    def issue(score, cell):
+        return ["\t;;#ASMSTART", "\ts_nop 4", f"\tbuffer_load_dword v{score}, v1, s[4:7], 0 offen",
+                f"\tbuffer_load_ushort v{cell}, v2, s[4:7], s3 offen", "\t;;#ASMEND"]
+
+    def consume(cell, out, count):
+        return ["\t;;#ASMSTART", f"\ts_waitcnt vmcnt({count})", f"\tv_mad_i32_i24 v{out}, v{cell}, -4, s1", "\t;;#ASMEND"]
+
+    def kernel(in_first_trip="", in_loop=""):
+        lines = ["_ZN8epik_amd18place_reads_kernelIcEEvNS_11PlaceParamsE:", "\ts_load_dwordx2 s[0:1], s[4:5], 0x0"]
+        lines += issue(6, 4) + ([in_first_trip] if in_first_trip else []) + issue(7, 5)      # the first trip: loads alone
+        lines += consume(4, 10, 2) + [".LBB0_1:"]
+        lines += ["\tds_read_b32 v12, v10"] + consume(5, 11, 2)
+        lines += ["\tds_write_b32 v10, v12"] + issue(6, 4) + ([in_loop] if in_loop else [])
+        lines += ["\tds_read_b32 v12, v11"] + consume(4, 10, 2)
+        lines += ["\tds_write_b32 v11, v12"] + issue(7, 5) + ["\ts_cbranch_scc1 .LBB0_1"]
+        lines += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(0)", "\tv_mad_i32_i24 v11, v5, -4, s1", "\t;;#ASMEND", "\ts_endpgm"]
+        path = tmp_path / "k.s"
+        path.write_text("\n".join(lines) + "\n")
+        return lint.lint(str(path))
+
+    assert kernel() == []
+    assert len(kernel(in_loop="\tv_mov_b32_e32 v20, v4")) == 1          # slot 0 was refilled a moment ago
+    assert len(kernel(in_first_trip="\tv_mov_b32_e32 v20, v6")) == 1     # slot 0's score: its load has just been issued
+    assert kernel(in_first_trip="\tv_mov_b32_e32 v20, v7") == []         # slot 1's registers are still free there
+
+
 def test_release_scratch_rejects_null():
     lib = capi.load()
     assert lib.epik_amd_placer_release_scratch(None) == capi.ERR_INVALID
