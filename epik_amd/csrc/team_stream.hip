@@ -409,11 +409,12 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
         return (uint32_t)lane < kFrontHdrWords + n_slices ? hdr[lane] : 0u;
     };
     // where the descriptors of slice `slot - kFrontHdrWords` of the read with header `word` lie, and how many
-    auto slice_list = [&](uint32_t word, int slot, uint32_t &my_padded) {
+    auto slice_list = [&](uint32_t word, int slot, uint32_t &my_padded, uint32_t *my_chunks = nullptr) {
         const bool is_count = (uint32_t)lane >= kFrontHdrWords && (uint32_t)lane < kFrontHdrWords + n_slices;
         const uint32_t padded = is_count ? (word + kTeamRing - 1u) & ~(kTeamRing - 1u) : 0u;
         const uint32_t first_of_slice = wave_incl_scan_u32(padded) - padded;
         my_padded = __builtin_amdgcn_readlane(padded, slot);
+        if (my_chunks) *my_chunks = __builtin_amdgcn_readlane(word, slot);  // ... of which this many are chunks, the rest padding
         const uint64_t first_desc = (uint64_t)__builtin_amdgcn_readlane(word, 0) << 3;
         return (const uint64_t *)(tp.front_pool + first_desc + __builtin_amdgcn_readlane(first_of_slice, slot));
     };
@@ -430,12 +431,19 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     };
     uint32_t word_cur = 0, word_next = 0;
     uint64_t desc_cur = null_desc;
-    // ... and the postings of its first chunks (the ring's first fill) are asked for behind this read's stream, in
-    // front of its epilogue: a trip to HBM that the wave would otherwise sit out at the start of every read
+    // ... and, in the accumulate halves, the postings of its first chunks (the ring's first fill) are asked for behind
+    // this read's stream: a trip to HBM that the wave would otherwise sit out at the start of every read
     Preloaded<(int)kTeamRing> pre;
+    // (the accumulate halves only: there the wave's next read would otherwise start on an idle memory system behind a
+    // list emission that asks nothing of it; in a placement the ring of the next read starts under the epilogue's LDS
+    // work anyway, and since an empty ring's first trip only issues loads the fetch ahead costs more instructions
+    // than it hides: 64.1 M reads/s without against 62.6 M with, same box, N = 9 999)
+    constexpr bool kFetchAhead = kMode == kTeamModeAccumulate || kMode == kTeamModeAccumulateLists;
     auto preload = [&](uint64_t descs) {
+        if constexpr (kFetchAhead) {
 #pragma unroll
-        for (int i = 0; i < (int)kTeamRing; ++i) preload_chunk<TeamChunks>(readlane_u64(descs, i), pre.cell[i], pre.score[i]);
+            for (int i = 0; i < (int)kTeamRing; ++i) preload_chunk<TeamChunks>(readlane_u64(descs, i), pre.cell[i], pre.score[i]);
+        }
     };
     // partial lists in (finish): the walk over the shards' lists of this item and of the one behind it
     [[maybe_unused]] ListWalk<CountT> walk, walk_next;
@@ -559,10 +567,11 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 }
             } else {
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
-            uint32_t my_padded;
-            const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded);
+            uint32_t my_padded, my_chunks;
+            const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded, &my_chunks);
             for (uint32_t r0 = 0; r0 < my_padded; r0 += cap) {
                 const uint32_t n_round = min(my_padded - r0, cap);  // a multiple of the ring
+                const uint32_t n_chunks = min(my_chunks - r0, n_round);  // (r0 < my_chunks: the padding is less than a trip)
                 // all 64 entries: the round's descriptors, then null chunks (the ring reads one trip ahead)
                 uint64_t d = my_desc;
                 if (pass != 0 || r0 != 0) d = (uint32_t)lane < n_round ? my_list[r0 + (uint32_t)lane] : null_desc;
@@ -571,10 +580,10 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
 #ifdef EPIK_AMD_ABLATION
                 if (p.ablate & 8u) continue;  // (timing experiments: nothing streamed)
 #endif
-                if (pass == 0 && r0 == 0)
-                    stream_round<TeamChunks, CountT, (int)kTeamRing, true>(p, lds.desc, n_round, score_top, count_top, &pre);
+                if (kFetchAhead && pass == 0 && r0 == 0)
+                    stream_round<TeamChunks, CountT, (int)kTeamRing, true>(p, lds.desc, n_round, score_top, count_top, &pre, n_chunks);
                 else
-                    stream_round<TeamChunks, CountT, (int)kTeamRing>(p, lds.desc, n_round, score_top, count_top);
+                    stream_round<TeamChunks, CountT, (int)kTeamRing, false>(p, lds.desc, n_round, score_top, count_top, nullptr, n_chunks);
                 STREAM_STAMP(1)  // stream
             }
             // the wave's next read: its first chunks' postings, on their way under what follows
