@@ -427,6 +427,14 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
                                      hipHostMallocDefault));
             p->h_front_cursor[0] = p->h_front_cursor[1] = p->h_front_cursor[2] = 0;
             if (const char *e = std::getenv("EPIK_AMD_TEAM_POOL")) p->front_pool_forced = std::strtoull(e, nullptr, 10);
+            p->sparse_quads = epik_amd::team_sparse_quads(plan.team_rows_pad);
+            p->sparse_chunks = epik_amd::team_sparse_chunks(plan.team_rows_pad);
+            if (const char *e = std::getenv("EPIK_AMD_TEAM_SPARSE")) {
+                if (std::strcmp(e, "always") == 0)
+                    p->sparse_quads = 256u, p->sparse_chunks = 0xfffffffeu;
+                else
+                    p->sparse_chunks = (uint32_t)std::strtoul(e, nullptr, 10), p->sparse_quads = p->sparse_chunks ? p->sparse_quads : 0u;
+            }
             // Grids of the front kernel (workgroups of one wave, 32 resident per CU) and of the merge kernel (four
             // waves, 5 resident): several times what the device holds at once -- see kReadsPerWave in launch().
             // (Front: 32 / 64 / 128 per CU = 2.08 / 1.95 / 1.87 ms per million reads; every wave takes the pool
@@ -819,6 +827,8 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             tp.slow_list = p->d_slow_list;
             tp.slice_rows_out = p->d_slice_rows;
             tp.slice_sums_out = p->d_slice_sums;
+            tp.sparse_chunks = p->sparse_quads ? p->sparse_chunks : 0u;
+            tp.sparse_quads = p->sparse_quads;
             if (mode == kAccumulateLists) {
                 tp.sparse_cap = p->d_sparse_cap;
                 tp.sparse_index = shard.index;

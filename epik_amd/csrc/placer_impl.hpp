@@ -45,6 +45,9 @@ struct epik_amd_placer {
     size_t slice_out_reads = 0;
     uint64_t *d_front_pool = nullptr;
     uint64_t front_pool_cap = 0;                  // descriptors
+    // the slice epilogue over the touched quads (team_epilogue.hpp): see TeamParams; EPIK_AMD_TEAM_SPARSE=0 (never) |
+    // always (whatever was streamed, up to the list's capacity: tests on small trees) | <chunks> (that threshold)
+    uint32_t sparse_chunks = 0, sparse_quads = 0;
     uint64_t front_pool_forced = 0;               // EPIK_AMD_TEAM_POOL: that many, whatever the batch (tests)
     unsigned long long *d_front_cursor = nullptr; // [0] descriptors asked for, [1] reads on the slow list, [2] reads of the launch
     unsigned long long *h_front_cursor = nullptr; // pinned: the same of the last launch that has finished

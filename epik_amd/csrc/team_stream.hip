@@ -29,7 +29,7 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "team_device.hpp"
+#include "team_epilogue.hpp"
 
 namespace epik_amd {
 
@@ -306,12 +306,7 @@ __global__ __launch_bounds__(64, W == 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1)
 // line, and then with at most 16 argument registers: a larger set of arguments goes through the stack --
 // scratch memory --, a round trip to the caches at every call.  Without that callee the kernel takes 96
 // vector registers with the epilogue inline, and no scratch.)
-struct SliceArgs {
-    uint32_t rows_pad, rows, base, kmer_size, keep;
-    float log_threshold;
-    uint32_t slice_at;  // read * slices + slice: where the slice's results go
-    uint32_t trace_at;  // diagnostic builds
-};
+// (the dense epilogue of place_device.hpp; an item that touched few rows takes team_epilogue.hpp's instead)
 template <int W, typename CountT>
 __device__ __forceinline__ void slice_epilogue(const TeamParams *__restrict__ ktp, WaveLds<CountT> lds,
                                                          uint32_t n_kmers, SliceArgs a)
@@ -362,6 +357,9 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave_in_block * tp.slice_bytes);
     lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave_in_block * tp.slice_bytes + (size_t)rows_pad * 4);
     lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave_in_block * tp.desc_bytes);
+    // items that touched few rows take the epilogue over their touched quads (team_epilogue.hpp); 32-bit counts
+    // (reads of 32 768 k-mers or more) always the dense one
+    constexpr bool kSparseCounts = sizeof(CountT) <= 2;
     const uint32_t n_slices = W * tp.passes;
     const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
     const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
@@ -516,6 +514,10 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             const uint64_t slice_at = read * n_slices + pass * W + wave;
             ctx.cand = rows_out + slice_at * keep;
             ctx.partial = sums_out + slice_at;
+            // nothing reached this slice's rows: they are as the last reset left them (wave-uniform)
+            [[maybe_unused]] bool slice_untouched = false;
+            // ... or an estimate of how much did, in chunks of 64 postings (0xffffffff: no idea -- the dense epilogue)
+            [[maybe_unused]] uint32_t sparse_hint = 0xffffffffu, my_chunks = 0;
             if constexpr (kMode == kTeamModeFinish) {
                 // second half of a k-mer-space-sharded placement: the slice's totals come back from HBM, with
                 // the read's ambiguous record (the average of the first ambiguous key that reached the branch
@@ -556,6 +558,11 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 if (next_item != ~0ull) walk_next.request(lists, next_item);
                 walk.run(lists, lds, rows_pad - 1u);
                 if (next_item != ~0ull) walk_next.start(lists, rows_pad - 1u);
+                {   // (lanes without a shard hold 0; an overflowed list counts as a long one)
+                    const uint32_t entries = wave_sum_u32(walk.count > 0xffffu ? 0xffffu : walk.count);
+                    slice_untouched = slot < 0 && entries == 0;
+                    sparse_hint = slot < 0 ? (entries + 31u) >> 5 : 0xffffffffu;  // (a chunk streams about 32 postings)
+                }
                 if (slot >= 0) {
                     for (uint32_t i = lane; i < ctx.rows_; i += kWave) {
                         const float avg = p.amb_avg[(uint64_t)slot * p.num_branches + ctx.base_ + i];
@@ -567,8 +574,10 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 }
             } else {
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
-            uint32_t my_padded, my_chunks;
+            uint32_t my_padded;
             const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded, &my_chunks);
+            slice_untouched = my_chunks == 0;
+            sparse_hint = my_chunks;
             for (uint32_t r0 = 0; r0 < my_padded; r0 += cap) {
                 const uint32_t n_round = min(my_padded - r0, cap);  // a multiple of the ring
                 const uint32_t n_chunks = min(my_chunks - r0, n_round);  // (r0 < my_chunks: the padding is less than a trip)
@@ -609,14 +618,33 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 const uint32_t part = (uint32_t)(read / tp.sparse_part_reads);
                 const uint64_t first = readlane_u64(part_first, (int)part) + (uint32_t)__builtin_amdgcn_readlane(my_first, (int)pass);
                 const bool fits = first + room <= tp.sparse_entries_cap;
-                const uint32_t n_out = emit_partial_list<CountT>(lds, rows_pad, ctx.rows_,
-                                                                 tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
-                                                                 fits ? room : 0u, p.ablate);
+                uint32_t n_out = 0;
+                bool done = false;
+                if constexpr (kSparseCounts) {
+                    // (a shard's lists reach a small part of a slice: nothing, or a few dozen quads)
+                    done = slice_untouched;
+                    if (!done && my_chunks <= tp.sparse_chunks) {
+                        if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
+                        done = emit_partial_list_sparse<CountT>(lds, rows_pad, tp.sparse_quads, tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
+                                                                fits ? room : 0u, &n_out);
+                    }
+                }
+                if (!done)
+                    n_out = emit_partial_list<CountT>(lds, rows_pad, ctx.rows_, tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
+                                                      fits ? room : 0u, p.ablate);
                 if (lane == 0) tp.sparse_index[slice_at].y = fits ? n_out : kSparseOverflow;
                 continue;
             }
             // ---- correction, the slice's best rows and share of sum_scores (to HBM: team_merge_kernel),
             //      reset of the rows
+            if constexpr (kSparseCounts) {
+                // On a database built from reference sequences a read's lists fall into one slice of the four
+                // (bench.py --clades): the other three items are done here.
+                if (slice_untouched) {
+                    publish_empty_slice(ctx, (uint32_t)n_kmers, k, p.log_threshold, keep);
+                    continue;
+                }
+            }
             if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
 #ifdef EPIK_AMD_ABLATION
             if (p.ablate & 2u) {  // (timing experiments: no slice epilogue)
@@ -636,6 +664,14 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
 #ifdef EPIK_AMD_ABLATION
             if (traced) args.trace_at = trace_at, trace_at += 10;  // the epilogue's entries
 #endif
+            if constexpr (kSparseCounts) {
+                // (what was streamed says how many rows may hold a count: with few, the touched quads are listed)
+                if (sparse_hint <= tp.sparse_chunks &&
+                    slice_epilogue_sparse<W, CountT>(reinterpret_cast<const TeamParams *>(kp), lds, (uint32_t)n_kmers, args, tp.sparse_quads)) {
+                    STREAM_STAMP(3)
+                    continue;
+                }
+            }
             slice_epilogue<W, CountT>(reinterpret_cast<const TeamParams *>(kp), lds, (uint32_t)n_kmers, args);
             STREAM_STAMP(3)  // slice epilogue
         }

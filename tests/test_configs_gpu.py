@@ -163,7 +163,7 @@ def large_tree(gpu_available):
 
 
 @pytest.mark.parametrize("counts", ["auto", "0", "1", "2"])
-@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team8", "team4-classic", "team4-smallpool"])
+@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team4-sparse", "team4-dense", "team8", "team4-classic", "team4-smallpool"])
 def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     """150 bp reads (141 k-mers: the 8-bit counts apply), with ambiguous and invalid characters in a
     third of them; `auto` lets place() choose, 0 / 1 / 2 force 16- / 32- / 8-bit counts."""
@@ -183,7 +183,7 @@ def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     assert_rows_match(*got, *ref)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "team4", "team8", "team4-classic", "team4-smallpool"])
+@pytest.mark.parametrize("kernel", ["wave", "team4", "team4-sparse", "team8", "team4-classic", "team4-smallpool"])
 def test_n9999_long_reads_leave_the_8_bit_counts(large_tree, oracle_lib, kernel, monkeypatch):
     """One read of more than 255 k-mers in the batch: place() must not pick the 8-bit counts; and
     reads long enough for several passes over the tiles."""

@@ -51,6 +51,9 @@ def main():
             os.environ["EPIK_AMD_KERNEL"] = kv["kernel"]
         os.environ["EPIK_AMD_TEAM_FRONT"] = kv.get("front", "1")
         os.environ["EPIK_AMD_GRID_PERCENT"] = kv.get("grid", "0")
+        os.environ.pop("EPIK_AMD_TEAM_SPARSE", None)
+        if "sparse" in kv:  # 0 | always | <chunks>: the slice epilogue over the touched quads (team_epilogue.hpp)
+            os.environ["EPIK_AMD_TEAM_SPARSE"] = kv["sparse"]
         os.environ["EPIK_AMD_FRONT_PER_CU"] = kv.get("fb", "0")  # workgroups per CU of the front / merge kernel (0: as queried)
         os.environ["EPIK_AMD_MERGE_PER_CU"] = kv.get("mb", "0")
         lib = ctypes.CDLL(os.path.join(ROOT, "epik_amd", f"libepik_amd{kv.get('lib', '')}.so"))

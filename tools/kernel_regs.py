@@ -1,22 +1,20 @@
 #!/usr/bin/env python3
-"""Registers, spills and scratch of every kernel in a hipcc -S listing (make -C epik_amd/csrc asm)."""
+"""Registers, scratch and size of every kernel in an ISA listing (hipcc -S --cuda-device-only)."""
 import re
-import subprocess
 import sys
 
+txt = open(sys.argv[1]).read()
+pat = sys.argv[2] if len(sys.argv) > 2 else ""
+for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+    name, body = m.group(1), m.group(2)
+    if pat not in name:
+        continue
 
-def main(paths):
-    for f in paths:
-        txt = open(f).read()
-        for b in txt.split("  - .agpr_count:")[1:]:
-            nm = re.search(r"\.name:\s+(\S+)", b).group(1)
-            vg = re.search(r"\.vgpr_count:\s+(\d+)", b).group(1)
-            sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", b).group(1)
-            sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1)
-            dn = subprocess.run(["c++filt", nm], capture_output=True, text=True).stdout.strip()
-            dn = dn.replace("epik_amd::", "").replace("(anonymous namespace)::", "")
-            print(f"{vg:>4} vgpr {sp:>3} spill {sc:>5} scratch  {dn[:120]}")
+    def g(k):
+        r = re.search(r"\.amdhsa_" + k + r"\s+(\S+)", body)
+        return r.group(1) if r else "?"
 
-
-if __name__ == "__main__":
-    main(sys.argv[1:] or ["gpurun_out/team_stream.s", "gpurun_out/team_kernel.s", "gpurun_out/place_kernel.s"])
+    i = txt.find(name + ":")
+    j = txt.find(".end_amdhsa_kernel", i)
+    lines = sum(1 for l in txt[i:j].split("\n") if l.startswith("\t") and not l.startswith("\t."))
+    print(f"{name[:100]:100s} vgpr {g('next_free_vgpr'):>4s} sgpr {g('next_free_sgpr'):>4s} scratch {g('private_segment_fixed_size'):>5s} insts {lines}")
