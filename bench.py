@@ -78,6 +78,10 @@ def parse_args():
                     help="amino: the protein path (BASELINE configs[3]: --states amino --kmer-size 7 "
                          "--read-length 300 --p-present 0.0026); the default line is configs[1]")
     ap.add_argument("--p-present", type=float, default=0.6, help="fraction of k-mer codes that have a posting list")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="G",
+                    help="--mode kmer-shard on ONE GPU: the database holds shard 0 of G only (the lists of the codes with "
+                         "code %% G == 0) -- what one of G GPUs accumulates per batch; the rows that come out are those of "
+                         "that shard alone (a timing experiment: DESIGN.md 6)")
     ap.add_argument("--mode", choices=["reads", "kmer-shard"], default="reads",
                     help="reads (default): reads sharded over the GPUs, database replicated, no collective.  "
                          "kmer-shard (BASELINE configs[4]: --leaves 5000 --reads-per-step 4096): rank g builds and "
@@ -316,7 +320,7 @@ def main():
     else:
         db = synth.make_db(tree.num_nodes, states=args.states, kmer_size=args.kmer_size, seed=43,
                            p_present=args.p_present, scattered=args.scattered,
-                           shard=(rank, world) if kmer_shard else None)
+                           shard=((0, args.shard_of) if args.shard_of else (rank, world)) if kmer_shard else None)
     total_entries = db.total_entries
     if clade_refs is not None:
         data, offs = synth.make_clade_reads(clade_refs, args.reads_per_step, args.read_length, seed=48 + rank)
@@ -328,6 +332,7 @@ def main():
                 f"{total_entries} postings ({total_entries * 8 / 1e6:.0f} MB), "
                 f"{args.reads_per_step} x {args.read_length} {unit} reads per step per GPU"
                 + (", scattered branch sets" if args.scattered else "")
+                + (f", shard 0 of {args.shard_of} only" if args.shard_of and kmer_shard else "")
                 + (f", {args.p_present:g} of the codes present" if args.p_present != 0.6 and not args.clades else "")
                 + (", lists over the clades of 500 references of 1500 bp, reads cut from the references (1 % substitutions)"
                    if args.clades else ""))

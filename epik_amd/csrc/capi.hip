@@ -428,10 +428,12 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
             p->h_front_cursor[0] = p->h_front_cursor[1] = p->h_front_cursor[2] = 0;
             if (const char *e = std::getenv("EPIK_AMD_TEAM_POOL")) p->front_pool_forced = std::strtoull(e, nullptr, 10);
             p->sparse_quads = epik_amd::team_sparse_quads(plan.team_rows_pad);
-            p->sparse_chunks = epik_amd::team_sparse_chunks(plan.team_rows_pad);
+            // (every item is asked: on a database built from reference sequences the item that streams ALL of a read's
+            // chunks touches a clade of a few dozen rows)
+            p->sparse_chunks = 0xffffffffu;
             if (const char *e = std::getenv("EPIK_AMD_TEAM_SPARSE")) {
                 if (std::strcmp(e, "always") == 0)
-                    p->sparse_quads = 256u, p->sparse_chunks = 0xfffffffeu;
+                    p->sparse_quads = 256u, p->sparse_chunks = 0xffffffffu;
                 else
                     p->sparse_chunks = (uint32_t)std::strtoul(e, nullptr, 10), p->sparse_quads = p->sparse_chunks ? p->sparse_quads : 0u;
             }
@@ -757,6 +759,11 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
     pp.rows = static_cast<epik_amd_placement *>(d_rows);
     pp.n_rows = static_cast<uint32_t *>(d_n_rows);
     pp.kmer_counts = static_cast<uint32_t *>(d_counts);
+#ifdef EPIK_AMD_ABLATION
+    // (the timeline of one wave holds the LAST launch's: EPIK_AMD_TRACE_HALF=accumulate | finish keeps the other half out)
+    if (const char *half = std::getenv("EPIK_AMD_TRACE_HALF"))
+        if ((std::strcmp(half, "accumulate") == 0 && is_finish(mode)) || (std::strcmp(half, "finish") == 0 && is_accumulate(mode))) pp.dbg = nullptr;
+#endif
     const auto &g = p->geo[p->counts];
     if (g.max_blocks == 0) return fail(EPIK_AMD_ERR_UNSUPPORTED, "no kernel of this count width for this tree size");
     if (lists && !(p->team && p->team_front))

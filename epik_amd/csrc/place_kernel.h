@@ -107,18 +107,18 @@ struct TeamParams {
     uint64_t sparse_entries_cap;          // entries
     unsigned long long *sparse_part_total;  // [n_parts]
     uint32_t sparse_parts, sparse_part_reads;
-    // The slice epilogue over the touched quads (team_epilogue.hpp): an item that streamed at most sparse_chunks chunks
-    // has its touched quads listed, and takes that epilogue when there are at most sparse_quads of them (0: never).
+    // The slice epilogue over the touched quads (team_epilogue.hpp): an item's touched quads are counted, and it takes
+    // that epilogue when there are at most sparse_quads of them (0: never).  sparse_chunks: an item that streamed more
+    // chunks than that is not even asked (0xffffffff: every item is).
     uint32_t sparse_chunks, sparse_quads;
 };
 // sparse_quads for a slice of rows_pad rows: up to four trips of 64 quads, and at most half the slice's trips (a
-// list of more saves less than it costs); sparse_chunks: a chunk of the benchmark database touches seven quads
+// list of more saves less than it costs)
 constexpr uint32_t team_sparse_quads(uint32_t rows_pad)
 {
     const uint32_t dense_trips = (rows_pad / 4u + 63u) / 64u;
     return 64u * (dense_trips / 2u < 4u ? dense_trips / 2u : 4u);
 }
-constexpr uint32_t team_sparse_chunks(uint32_t rows_pad) { return team_sparse_quads(rows_pad) / 7u; }
 // An entry of a partial list: {f32 sum, u32 row | count << 16} with 8- and 16-bit counts, {f32 sum, u32 row,
 // u32 count, 0} with 32-bit counts (reads of 32768 k-mers or more); row = branch - first branch of the slice.
 constexpr uint32_t sparse_entry_bytes(int counts) { return counts == kCounts32 ? 16u : 8u; }

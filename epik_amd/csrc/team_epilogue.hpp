@@ -90,30 +90,55 @@ struct QuadCounts {
     }
 };
 
-// Step 2: the numbers of the quads that hold a count, ascending, 16 bits each, into `list_addr` (the wave's descriptor
-// list).  Returns how many (wave-uniform); more than `cap`: the list is worthless, and nothing else has been changed.
+// Step 2: the numbers of the quads that hold a count, 16 bits each, into `list_addr` (the wave's descriptor list), when
+// there are at most `cap` of them.  Returns how many there are (wave-uniform); more than `cap`: nothing was written.
+// The slice's counts are read once, 16 bytes per lane and trip (16 rows of 8-bit counts: 4 quads; 8 of 16-bit ones:
+// 2), all trips out together: ONE round trip to LDS -- with twelve waves of a CU streaming, a round trip is ~400
+// cycles, and an epilogue is a chain of them -- then a comparison and a ballot per quad of a lane (what a slice that
+// turns out to be dense has paid for nothing), and the listing from the same registers.
 template <typename CountT>
 __device__ __forceinline__ uint32_t list_touched_quads(uint32_t count_addr, uint32_t rows_pad, uint32_t list_addr, uint32_t cap)
 {
-    typedef QuadCounts<CountT> Counts;
+    static_assert(sizeof(CountT) <= 2, "8- and 16-bit counts");
+    constexpr int kPerLane = sizeof(CountT) == 1 ? 4 : 2;  // quads in the 16 bytes of a lane
+    constexpr int kTrips = sizeof(CountT) == 1 ? 4 : 8;    // slices of up to 4 096 rows
+    constexpr uint32_t kFlags = sizeof(CountT) == 1 ? 0xffffffffu : 0x7fff7fffu;  // (without the ambiguous sweep's flags)
     const uint32_t lane = here_lane();
-    const uint32_t quads = rows_pad >> 2;  // rows_pad is a multiple of 16
-    uint32_t total = 0;
-    // two trips of 64 quads per turn, their loads out together
-    for (uint32_t q0 = 0; q0 < quads && total <= cap; q0 += 128u) {
-        const uint32_t qa = q0 + lane, qb = q0 + 64u + lane;
-        Counts a, b;
+    const uint32_t n_vec = rows_pad * (uint32_t)sizeof(CountT) / 16u;  // rows_pad is a multiple of 16
+    if (n_vec > 64u * (uint32_t)kTrips) return cap + 1u;  // (a slice nobody gets unasked: the dense epilogue)
+    // the quad j of a lane's 16 bytes holds a count
+    auto touched = [&](const v4u &v, int j) {
+        if constexpr (sizeof(CountT) == 1)
+            return v[j] != 0u;
+        else
+            return ((v[2 * j] | v[2 * j + 1]) & kFlags) != 0u;
+    };
+    v4u v[kTrips];
 #pragma unroll
-        for (int i = 0; i < Counts::kWords; ++i) a.w[i] = b.w[i] = 0u;
-        if (qa < quads) a.load(count_addr + qa * Counts::kBytes);
-        if (qb < quads) b.load(count_addr + qb * Counts::kBytes);
-        const bool ta = a.any(), tb = b.any();
-        const uint64_t ma = __ballot(ta), mb = __ballot(tb);
-        const uint32_t na = (uint32_t)__popcll(ma);
-        const uint32_t at_a = total + lanes_below(ma), at_b = total + na + lanes_below(mb);
-        if (ta && at_a < cap) *(lds_u16 *)(uintptr_t)(list_addr + 2u * at_a) = (uint16_t)qa;
-        if (tb && at_b < cap) *(lds_u16 *)(uintptr_t)(list_addr + 2u * at_b) = (uint16_t)qb;
-        total += na + (uint32_t)__popcll(mb);
+    for (int t = 0; t < kTrips; ++t) {
+        const uint32_t i = (uint32_t)t * 64u + lane;
+        v[t] = v4u{0u, 0u, 0u, 0u};
+        if (i < n_vec) v[t] = *(lds_u32x4 *)(uintptr_t)(count_addr + 16u * i);
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (int t = 0; t < kTrips; ++t) {
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) total += (uint32_t)__popcll(__ballot(touched(v[t], j)));
+    }
+    if (total == 0 || total > cap) return total;
+    uint32_t at = 0;
+#pragma unroll
+    for (int t = 0; t < kTrips; ++t) {
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            const bool mine = touched(v[t], j);
+            const uint64_t m = __ballot(mine);
+            if (m) {
+                if (mine) *(lds_u16 *)(uintptr_t)(list_addr + 2u * (at + lanes_below(m))) = (uint16_t)(((uint32_t)t * 64u + lane) * (uint32_t)kPerLane + (uint32_t)j);
+                at += (uint32_t)__popcll(m);
+            }
+        }
     }
     return total;
 }

@@ -516,8 +516,8 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             ctx.partial = sums_out + slice_at;
             // nothing reached this slice's rows: they are as the last reset left them (wave-uniform)
             [[maybe_unused]] bool slice_untouched = false;
-            // ... or an estimate of how much did, in chunks of 64 postings (0xffffffff: no idea -- the dense epilogue)
-            [[maybe_unused]] uint32_t sparse_hint = 0xffffffffu, my_chunks = 0;
+            // ... or an estimate of how much did, in chunks of 64 postings (0: no idea)
+            [[maybe_unused]] uint32_t sparse_hint = 0u, my_chunks = 0;
             if constexpr (kMode == kTeamModeFinish) {
                 // second half of a k-mer-space-sharded placement: the slice's totals come back from HBM, with
                 // the read's ambiguous record (the average of the first ambiguous key that reached the branch
@@ -558,10 +558,11 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 if (next_item != ~0ull) walk_next.request(lists, next_item);
                 walk.run(lists, lds, rows_pad - 1u);
                 if (next_item != ~0ull) walk_next.start(lists, rows_pad - 1u);
+                STREAM_STAMP(5)  // lists added
                 {   // (lanes without a shard hold 0; an overflowed list counts as a long one)
                     const uint32_t entries = wave_sum_u32(walk.count > 0xffffu ? 0xffffu : walk.count);
                     slice_untouched = slot < 0 && entries == 0;
-                    sparse_hint = slot < 0 ? (entries + 31u) >> 5 : 0xffffffffu;  // (a chunk streams about 32 postings)
+                    sparse_hint = (entries + 31u) >> 5;  // (a chunk streams about 32 postings)
                 }
                 if (slot >= 0) {
                     for (uint32_t i = lane; i < ctx.rows_; i += kWave) {
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                     n_out = emit_partial_list<CountT>(lds, rows_pad, ctx.rows_, tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
                                                       fits ? room : 0u, p.ablate);
                 if (lane == 0) tp.sparse_index[slice_at].y = fits ? n_out : kSparseOverflow;
+                STREAM_STAMP(4)  // list emitted
                 continue;
             }
             // ---- correction, the slice's best rows and share of sum_scores (to HBM: team_merge_kernel),

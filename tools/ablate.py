@@ -7,7 +7,7 @@ comma-separated list of key=value:
     lib=<suffix>     epik_amd/libepik_amd<suffix>.so   (e.g. lib=_ablate, lib=_exp1; default: the product lib)
     layout=compact|packed|paired, kernel=wave|team4|team8, wide=0|1|2, front=0|1 (team placement as one kernel | front + streaming + merge kernels), grid=<percent of the resident workgroups>,
     ablate=<bitmask>, stamps=1   (env read at placer creation)
-LEAVES=<n> sets the tree (N = 2n - 1), N_READS the batch.
+LEAVES=<n> sets the tree (N = 2n - 1), N_READS the batch, CLADES=1 the workload of bench.py --clades.
 Example: tools/ablate.py lib=_ablate,layout=compact lib=_exp,layout=compact
 """
 import ctypes
@@ -28,8 +28,12 @@ def main():
     n = int(os.environ.get("N_READS", 1_000_000))
     rounds = int(os.environ.get("ROUNDS", 3))
     tree = synth.make_tree(int(os.environ.get("LEAVES", 500)), seed=42)
-    db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
-    data, offs = synth.make_reads(n, 150, seed=44)
+    if os.environ.get("CLADES"):  # bench.py --clades: lists over the clades of references, reads cut from them
+        db, refs, _ = synth.make_clade_db(tree.num_nodes, kmer_size=10, seed=47)
+        data, offs = synth.make_clade_reads(refs, n, 150, seed=48)
+    else:
+        db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
+        data, offs = synth.make_reads(n, 150, seed=44)
     dev = torch.device("cuda", 0)
     d_seqs = torch.from_numpy(data).to(dev)
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)

@@ -9,11 +9,11 @@ import collections
 import sys
 
 NAMES = {109: "loop top (headers, prefetch of the next read's descriptors)", 100: "descriptors -> LDS", 101: "stream (a round)",
-         102: "ambiguous k-mers", 103: "epilogue return", 10: "epilogue entered", 0: "correction sweep", 1: "tau",
+         102: "ambiguous k-mers", 103: "epilogue return", 104: "partial list emitted", 105: "shards' lists added", 10: "epilogue entered", 0: "correction sweep", 1: "tau",
          2: "scan sweep", 3: "rank", 4: "partial sum", 5: "(empty)", 6: "publish", 7: "clear",
          # the epilogue over the touched quads (team_epilogue.hpp)
-         20: "touched quads: counts, list", 21: "scores in, correction", 22: "tau (quads)", 23: "terms, candidates",
-         24: "rank (quads)", 25: "reset, partial sum, publish", 26: "empty slice"}
+         21: "touched quads listed; quads, counts, scores in", 22: "correction (quads)", 23: "tau (quads)",
+         24: "terms, candidates (quads)", 25: "rank, partial sum, publish (quads)", 26: "empty slice"}
 
 
 def main():
@@ -33,7 +33,7 @@ def main():
     n = len(reads)
     per_read = sum(total.values()) / n
     print(f"{n} reads of one wave (one slice of each); {per_read:.0f} cycles per read with the stamps")
-    for code in (109, 100, 101, 102, 10, 0, 1, 2, 3, 4, 5, 6, 7, 20, 21, 22, 23, 24, 25, 26, 103):
+    for code in (109, 100, 101, 102, 104, 105, 10, 0, 1, 2, 3, 4, 5, 6, 7, 20, 21, 22, 23, 24, 25, 26, 103):
         if count[code]:
             print(f"  {NAMES[code]:62s} {total[code] / n:8.0f} cycles per read ({100 * total[code] / n / per_read:4.1f} %), "
                   f"{count[code] / n:4.2f} per read, {total[code] / count[code]:7.0f} each")
