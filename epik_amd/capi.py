@@ -128,6 +128,32 @@ class EpikAmdError(RuntimeError):
 _lib = None
 
 
+def hip_runtimes(maps_text: str | None = None) -> list:
+    """The HIP runtimes (libamdhip64) mapped into this process, from /proc/self/maps (or `maps_text`)."""
+    import re
+    if maps_text is None:
+        try:
+            with open("/proc/self/maps") as fh:
+                maps_text = fh.read()
+        except OSError:
+            return []
+    found = {os.path.realpath(m.group(1)) for m in re.finditer(r"(/\S*libamdhip64\S*)", maps_text)}
+    return sorted(found)
+
+
+def check_hip_runtime(runtimes: list | None = None) -> None:
+    """libepik_amd.so links the system's HIP runtime by SONAME; PyTorch-ROCm ships one of its own.  When torch is
+    imported FIRST its runtime satisfies the SONAME and the process holds one runtime (what bench.py, the tests and
+    every caller that hands torch tensors to this library do).  The other way round the process ends up with TWO
+    runtimes -- two device contexts, and torch reports "No HIP GPUs" at some later point.  Said here, by name."""
+    runtimes = hip_runtimes() if runtimes is None else runtimes
+    if len(runtimes) > 1:
+        raise ImportError(
+            "two HIP runtimes are mapped into this process (" + ", ".join(runtimes) + "): libepik_amd.so was loaded "
+            "before torch, whose own libamdhip64 then came on top of the system's.  Import torch BEFORE epik_amd.capi.load() "
+            "(`import torch` at the top of the program), or use a torch built against the system's ROCm.")
+
+
 def load() -> ctypes.CDLL:
     """Loads libepik_amd.so (once) and declares the prototypes."""
     global _lib
@@ -138,6 +164,7 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C epik_amd/csrc` (hipcc, gfx950).  epik_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    check_hip_runtime()
     vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
     lib.epik_amd_device_count.restype = i32
     lib.epik_amd_device_count.argtypes = []
@@ -201,4 +228,6 @@ def check(code: int) -> None:
 
 
 def device_count() -> int:
-    return int(load().epik_amd_device_count())
+    lib = load()
+    check_hip_runtime()  # (torch may have been imported since load())
+    return int(lib.epik_amd_device_count())

@@ -216,6 +216,19 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     // the same count width everywhere (it is the format of the entries): what the longest read needs
     for (uint32_t g = 0; g < G; ++g)
         if (const int rc = epik_amd_placer_choose_counts(shards[g], longest); rc != EPIK_AMD_OK) return rc;
+    // (every handle chooses by its own geometry and occupancy: handles that ended up apart -- devices of two kinds, a
+    // width forced on one of them -- all take the widest, or the finisher would read 8-byte entries as 16-byte ones)
+    {
+        int widest = shards[0]->counts;
+        bool same = true;
+        for (uint32_t g = 1; g < G; ++g) same = same && shards[g]->counts == widest, widest = std::max(widest, shards[g]->counts);
+        if (!same)
+            for (uint32_t g = 0; g < G; ++g) {
+                if (shards[g]->geo[widest].max_blocks == 0)
+                    return fail_with(EPIK_AMD_ERR_UNSUPPORTED, "the shards chose different count widths and one of them has no kernel of the widest");
+                shards[g]->counts = widest;
+            }
+    }
     uint32_t entry_bytes = 8;
     {
         epik_amd_partial_info info{};

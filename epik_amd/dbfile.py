@@ -11,10 +11,14 @@ Layout (little endian):
     char[8] "EPIKAMD1" | u32 version | u32 sequence_type (0 DNA, 1 Proteins) | u32 k | f32 omega
     u64 num_kmers | u64 num_entries_total | u64 newick_len | char newick[newick_len]
     num_kmers x { u32 key (dense k-mer code) | u32 n | n x { u32 branch, f32 score } }
+    version >= 2, the last 32 bytes of the file -- a converter that died half way, or a copy cut short, is caught at
+    load, not at the first wrong placement:
+    char[8] "EPIKEND1" | u64 num_kmers | u64 num_entries | u32 crc32 of the record bytes (zlib's polynomial) | u32 0
 """
 from __future__ import annotations
 
 import struct
+import zlib
 
 import numpy as np
 
@@ -22,7 +26,9 @@ from . import alphabet
 from .synth import PKDB_VALUE, SynthDB
 
 MAGIC = b"EPIKAMD1"
-VERSION = 1
+END_MAGIC = b"EPIKEND1"
+VERSION = 2
+TRAILER_BYTES = 32
 
 
 def informativeness_order(offsets: np.ndarray, values: np.ndarray) -> np.ndarray:
@@ -46,10 +52,39 @@ def write_db(path: str, db: SynthDB, newick: str) -> None:
         fh.write(struct.pack("<QQQ", len(order), db.num_entries, len(tree)))
         fh.write(tree)
         offs = db.offsets.astype(np.int64)
+        crc = 0
         for key in order:
             b, e = int(offs[key]), int(offs[key + 1])
-            fh.write(struct.pack("<II", int(key), e - b))
-            fh.write(db.values[b:e].tobytes())
+            record = struct.pack("<II", int(key), e - b) + db.values[b:e].tobytes()
+            crc = zlib.crc32(record, crc)
+            fh.write(record)
+        fh.write(END_MAGIC + struct.pack("<QQII", len(order), db.num_entries, crc & 0xFFFFFFFF, 0))
+
+
+def check_trailer(fh, path: str, num_kmers: int, total: int) -> None:
+    """The trailer of a version-2 file against its header and its record bytes (the file position is kept)."""
+    at = fh.tell()
+    fh.seek(0, 2)
+    size = fh.tell()
+    if size < at + TRAILER_BYTES:
+        raise RuntimeError(f"{path} is truncated: no room for the EPIKEND1 trailer")
+    fh.seek(size - TRAILER_BYTES)
+    tail = fh.read(TRAILER_BYTES)
+    if tail[:8] != END_MAGIC:
+        raise RuntimeError(f"{path} is truncated or was not finished: the EPIKEND1 trailer is missing")
+    kmers_written, entries_written, crc, _ = struct.unpack("<QQII", tail[8:])
+    if kmers_written != num_kmers or entries_written != total:
+        raise RuntimeError(f"{path}: the trailer counts {kmers_written} k-mers / {entries_written} phylo-k-mers, the header "
+                           f"{num_kmers} / {total}")
+    fh.seek(at)
+    got, left = 0, size - TRAILER_BYTES - at
+    while left > 0:
+        block = fh.read(min(left, 1 << 24))
+        got = zlib.crc32(block, got)
+        left -= len(block)
+    if (got & 0xFFFFFFFF) != crc:
+        raise RuntimeError(f"{path}: the records do not match their checksum (crc32 {got & 0xFFFFFFFF:08x}, trailer {crc:08x})")
+    fh.seek(at)
 
 
 def read_db(path: str, mu: float = 1.0, omega: float = 1.5, max_entries: int | None = None):
@@ -60,6 +95,8 @@ def read_db(path: str, mu: float = 1.0, omega: float = 1.5, max_entries: int | N
         version, seq_type, k, built_omega = struct.unpack("<IIIf", fh.read(16))
         num_kmers, total, newick_len = struct.unpack("<QQQ", fh.read(24))
         newick = fh.read(newick_len).decode()
+        if version >= 2:
+            check_trailer(fh, path, num_kmers, total)
         states = "nucl" if seq_type == 0 else "amino"
         sigma = alphabet.alphabet_size(states)
         eff_omega = max(float(np.float32(omega)), float(np.float32(built_omega)))

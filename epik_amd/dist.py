@@ -281,9 +281,12 @@ class Partials:
     how many entries each part takes in `entries`), the ambiguous records (or None), the capacity of
     `entries` in entries, and the event after which all of it is there (None: already)."""
 
-    def __init__(self, entries, index, part_entries, amb_order, amb_avg, cap, done=None):
+    def __init__(self, entries, index, part_entries, amb_order, amb_avg, cap, done=None, entry_bytes=None):
         self.entries, self.index, self.part_entries = entries, index, part_entries
         self.amb_order, self.amb_avg, self.cap, self.done = amb_order, amb_avg, cap, done
+        # bytes per entry of THESE lists (8, or 16 with 32-bit counts): the width is chosen per batch, and the next
+        # batch's accumulate has chosen again by the time this one crosses and finishes (None: the engine's)
+        self.entry_bytes = entry_bytes
 
 
 class ListsGpuEngine:
@@ -341,12 +344,15 @@ class ListsGpuEngine:
                 d_amb_avg=avg.data_ptr() if amb_rows else 0)
             done = self.compute_stream.record_event()
         batch["_keep"] = (d_slot,)  # (alive until the kernels have run)
-        return Partials(entries, index, part_entries, order, avg, cap, done)
+        return Partials(entries, index, part_entries, order, avg, cap, done, entry_bytes=self.entry_bytes)
 
     def finish(self, batch, begin: int, end: int, entries, index, amb_slot, amb_avg):
         import torch
         from . import capi
         m, keep, dev = end - begin, self.keep, self.device
+        # the count width (and entry format) this batch was accumulated with: a later batch's accumulate may have
+        # chosen another one in between (a short-read batch in front of a batch with a read of more than 255 k-mers)
+        self.placer.choose_counts(batch["longest"])
         rows = np.zeros((m, keep), dtype=capi.PLACEMENT)
         n_rows = np.zeros(m, dtype=np.uint32)
         kmer_counts = np.zeros((m, keep), dtype=np.uint32)
@@ -380,15 +386,22 @@ def _exchange_lists(engine, parts: Partials, n_reads: int, dist, rank: int, worl
     index (equal splits) -- one link per peer.  Returns (entries[g], index[g]) in shard order for the
     reads this rank owns, and the total this rank's parts took (for the overflow check)."""
     import torch
-    eb, S = engine.entry_bytes, engine.slices
+    eb = parts.entry_bytes if getattr(parts, "entry_bytes", None) else engine.entry_bytes
+    S = engine.slices
     per = -(-n_reads // world) if n_reads else 0
     staged = getattr(engine, "host_staging", False)
     sizes_mine = parts.part_entries.cpu() if staged else parts.part_entries
-    sizes = torch.empty(world * world, dtype=torch.int64, device=sizes_mine.device)
-    dist.all_gather_into_tensor(sizes, sizes_mine.contiguous())
-    sizes = sizes.cpu().view(world, world)            # [g][r]: entries shard g holds for the reads of rank r
+    # the part sizes AND the room this rank had: every rank must know whether ANY rank's lists found no room before
+    # the first data collective -- a rank that overflowed alone and left here by itself would meet the others'
+    # all-to-all with another collective (capacities differ per shard: so does what overflows)
+    mine = torch.cat([sizes_mine.to(torch.int64).reshape(-1),
+                      torch.tensor([int(parts.cap)], dtype=torch.int64, device=sizes_mine.device)]).contiguous()
+    gathered = torch.empty(world * (world + 1), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine)
+    gathered = gathered.cpu().view(world, world + 1)
+    sizes, caps = gathered[:, :world], gathered[:, world]   # sizes[g][r]: entries shard g holds for the reads of rank r
     mine_total = int(sizes[rank].sum())
-    if mine_total > parts.cap:                        # the caller repeats the accumulate with more room
+    if bool((sizes.sum(dim=1) > caps).any()):         # every rank leaves together; the caller repeats the accumulate
         return None, None, mine_total
     send_split = [int(x) * eb for x in sizes[rank]]
     recv_split = [int(sizes[g][rank]) * eb for g in range(world)]
@@ -464,11 +477,7 @@ def place_kmer_sharded_lists(engine, batches, dist, char_class=None, gather_to: 
                     else:
                         parts.done.synchronize()
                 entries, index, total = _exchange_lists(engine, parts, n, dist, rank, world)
-                # every rank repeats together: one that overflowed tells the others
-                flag = torch.tensor([1 if entries is None else 0], dtype=torch.int32,
-                                    device=parts.part_entries.device if not getattr(engine, "host_staging", False) else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                again = bool(flag.cpu().item())
+                again = entries is None   # (the same on every rank: decided from the gathered sizes and capacities)
                 if not again and per_owner:
                     def cross(x):
                         x = x.cpu() if getattr(engine, "host_staging", False) else x
@@ -483,7 +492,8 @@ def place_kmer_sharded_lists(engine, batches, dist, char_class=None, gather_to: 
             if not again:
                 break
             engine.margin *= 1.5
-            parts = engine.accumulate(batch, world, slot, per_owner * world, min_entries=total or 0)
+            # (a rank whose own lists had room keeps its capacity: only what overflowed grows)
+            parts = engine.accumulate(batch, world, slot, per_owner * world, min_entries=max(total or 0, 1))
         if done is not None and compute is not None:
             compute.wait_event(done)
         mine = engine.finish(batch, begin, end, entries, [x[:max(end - begin, 0)] for x in index], my_slot, my_avg)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <limits>
 #include <iostream>
 #include <sstream>
 
@@ -26,6 +27,18 @@ static int failures = 0;
 int main(int argc, char** argv)
 {
     using namespace epik_amd;
+    // host_test load <file>: epik_amd::load by itself (tests/test_host_cpu.py hands it damaged containers; the driver
+    // asks for its devices first)
+    if (argc == 3 && std::string(argv[1]) == "load") {
+        try {
+            const auto db = load(argv[2], 1.0f, 1.5f, std::numeric_limits<size_t>::max());
+            std::cout << "loaded " << db.get_num_entries_loaded() << " phylo-k-mers, version " << db.version() << std::endl;
+            return 0;
+        } catch (const std::exception& e) {
+            std::cerr << "Error: " << e.what() << std::endl;
+            return 255;
+        }
+    }
     const std::string tmp = argc > 1 ? argv[1] : "/tmp";
 
     // --- FASTA batches (main.cpp:332-340) ---

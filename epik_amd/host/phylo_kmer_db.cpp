@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <cstddef>
 #include <stdexcept>
@@ -121,6 +122,35 @@ struct cursor {
     }
 };
 
+// crc32 (zlib's polynomial, reflected), a byte at a time over eight tables: ~1 GB/s, once per load of a whole file
+uint32_t crc32_of(const unsigned char* p, size_t n, uint32_t crc = 0)
+{
+    static uint32_t table[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xffu];
+        ready = true;
+    }
+    crc = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        std::memcpy(&lo, p, 4);
+        std::memcpy(&hi, p + 4, 4);
+        lo ^= crc;
+        crc = table[7][lo & 0xffu] ^ table[6][(lo >> 8) & 0xffu] ^ table[5][(lo >> 16) & 0xffu] ^ table[4][lo >> 24] ^
+              table[3][hi & 0xffu] ^ table[2][(hi >> 8) & 0xffu] ^ table[1][(hi >> 16) & 0xffu] ^ table[0][hi >> 24];
+        p += 8, n -= 8;
+    }
+    while (n--) crc = table[0][(crc ^ *p++) & 0xffu] ^ (crc >> 8);
+    return ~crc;
+}
+
 struct kmer_record {
     uint32_t key;
     uint32_t kept;               // postings of the record at or above the threshold
@@ -149,8 +179,11 @@ phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t ma
         // Boost archives start with "22 serialization::archive"; zlib streams with 0x78
         throw std::runtime_error(
             "Unsupported database container: " + filename +
-            " is not an EPIKAMD1 file.  IPK's .ipk files (Boost.Serialization inside i2l) cannot be "
-            "read by this build; convert the database with tools/ipk2ekdb.cpp (needs i2l) or epik_amd/dbfile.py");
+            " is not an EPIKAMD1 file.  IPK's .ipk files (Boost.Serialization inside i2l) cannot be read by this "
+            "build.  Convert the database once with tools/ipk2ekdb.cpp, next to a checkout of EPIK that has its i2l "
+            "submodule:\n  g++ -std=c++17 -O2 -I<EPIK>/i2l/include tools/ipk2ekdb.cpp -o ipk2ekdb -L<EPIK>/build/i2l "
+            "-li2l_dna -lboost_serialization -lboost_iostreams -lboost_filesystem -lz   (proteins: -DSEQ_TYPE_AA -li2l_aa)\n"
+            "  ./ipk2ekdb " + filename + " out.ekdb\n(epik_amd/dbfile.py writes the same container from Python)");
     }
     phylo_kmer_db db;
     db._shard_index = shard_index;
@@ -165,6 +198,32 @@ phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t ma
     const uint64_t newick_len = in.pod<uint64_t>();
     const unsigned char* newick = in.bytes(newick_len, "tree");
     db._tree.assign(reinterpret_cast<const char*>(newick), newick_len);
+    if (db._version >= 2) {
+        // The trailer (epik_amd/dbfile.py): a conversion that died half way, or a copy cut short, is caught here and
+        // not at the first wrong placement.  The counts always; the checksum of the records when the whole file is
+        // about to be walked anyway (mu = 1; a smaller mu exists to NOT read the file to its end) or when
+        // EPIK_AMD_DB_VERIFY=1 asks for it.
+        constexpr size_t kTrailer = 32;
+        if ((size_t)(in.end - in.at) < kTrailer || std::memcmp(in.end - kTrailer, "EPIKEND1", 8) != 0)
+            throw std::runtime_error("The database file is truncated or was not finished (no EPIKEND1 trailer): " + filename);
+        uint64_t kmers_written, entries_written;
+        uint32_t crc;
+        std::memcpy(&kmers_written, in.end - kTrailer + 8, 8);
+        std::memcpy(&entries_written, in.end - kTrailer + 16, 8);
+        std::memcpy(&crc, in.end - kTrailer + 24, 4);
+        if (kmers_written != num_kmers || entries_written != db._num_entries_total)
+            throw std::runtime_error("The database file's trailer counts " + std::to_string(kmers_written) + " k-mers / " +
+                                     std::to_string(entries_written) + " phylo-k-mers, its header " + std::to_string(num_kmers) +
+                                     " / " + std::to_string(db._num_entries_total) + ": " + filename);
+        in.end -= kTrailer;
+        const char* verify = std::getenv("EPIK_AMD_DB_VERIFY");
+        const bool whole_file = mu >= 1.0f && shard_index == 0;  // (every shard walks the same records: once is enough)
+        if ((verify && verify[0] == '1') || (whole_file && !(verify && verify[0] == '0'))) {
+            const uint32_t got = crc32_of(in.at, (size_t)(in.end - in.at));
+            if (got != crc)
+                throw std::runtime_error("The database file's records do not match their checksum (a damaged copy or an unfinished conversion): " + filename);
+        }
+    }
 
     const unsigned int sigma = alphabet_size(db._sequence_type);
     // The user's omega replaces the stored one when it is stricter (README.md:125)

@@ -82,6 +82,18 @@ placer::placer(const phylo_kmer_db& db, const phylo_tree& original_tree, size_t 
             throw std::runtime_error("GPU placer: " + message);
         }
         _handles.push_back(handle);
+        if (_sharded && g == 0) {
+            // A tree of the one-wavefront kernels leaves dense partial vectors, which place_sharded does not take:
+            // said now, before the other shards are loaded and uploaded, not at the first batch.
+            epik_amd_partial_info info{};
+            if (epik_amd_placer_partial_info(handle, &info) == EPIK_AMD_OK && !info.lists) {
+                for (auto* h : _handles) epik_amd_placer_destroy(h);
+                _handles.clear();
+                throw std::runtime_error("GPU placer: --db-shard needs the kernels of a large tree (this one has " +
+                                         std::to_string(desc.num_branches) +
+                                         " branches and fits one wavefront per read): replicate the database with --devices / --gpus instead");
+            }
+        }
     }
 }
 

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # sizes their grids; shard_place.hip -- the host side of place_sharded and its one element-wise kernel -- is not among
 # them: no counter pass runs it)
 KERNEL_SOURCES = ("place_kernel.hip", "place_device.hpp", "team_kernel.hip", "team_stream.hip", "team_device.hpp",
-                  "place_kernel.h", "db_layout.h", "db_image.cpp", "capi.hip", "placer_impl.hpp")
+                  "team_epilogue.hpp", "place_kernel.h", "db_layout.h", "db_image.cpp", "capi.hip", "placer_impl.hpp")
 
 
 def kernel_source_hash() -> str:
@@ -20,3 +20,37 @@ def kernel_source_hash() -> str:
         with open(os.path.join(ROOT, "epik_amd", "csrc", name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
+
+
+def built_with() -> dict:
+    """What `make -C epik_amd/csrc` recorded next to the library it built (epik_amd/libepik_amd.build.json): the
+    compiler (`hipcc --version`: the hot loop's registers are invisible to hipcc and csrc/lint_ring_asm.py checks the
+    ISA a given compiler made of it), the hash of the kernel sources at that time and whether the lint passed.
+    {} when the record is missing (a library built by hand)."""
+    import json
+    try:
+        with open(os.path.join(ROOT, "epik_amd", "libepik_amd.build.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def lint_record() -> dict:
+    """epik_amd/csrc/lint_passed.json: the compiler and sources csrc/lint_ring_asm.py last accepted the ISA of."""
+    import json
+    try:
+        with open(os.path.join(ROOT, "epik_amd", "csrc", "lint_passed.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def summary() -> dict:
+    """For bench.py's line: the compiler the library was built with, the sources it was built from against the
+    sources now, and whether the ISA lint passed on that compiler and those sources."""
+    built, lint, now = built_with(), lint_record(), kernel_source_hash()
+    return {"hipcc": built.get("hipcc"), "built_from": built.get("kernel_source_hash"), "kernel_source_hash": now,
+            "library_is_current": built.get("kernel_source_hash") == now,
+            "lint_passed_on": {"hipcc": lint.get("hipcc"), "kernel_source_hash": lint.get("kernel_source_hash")},
+            "lint_covers_this_build": bool(lint) and lint.get("hipcc") == built.get("hipcc") and
+            lint.get("kernel_source_hash") == built.get("kernel_source_hash")}

@@ -181,3 +181,48 @@ def test_the_ring_lint_sees_a_copy_of_a_register_in_flight(tmp_path):
 def test_release_scratch_rejects_null():
     lib = capi.load()
     assert lib.epik_amd_placer_release_scratch(None) == capi.ERR_INVALID
+
+
+def test_two_hip_runtimes_are_named_not_left_to_fail_later():
+    """libepik_amd.so links the system's libamdhip64 by SONAME, torch ships its own: loaded in the wrong order the
+    process holds two runtimes and torch says "No HIP GPUs" much later.  capi.load() / device_count() say so."""
+    import subprocess
+    import sys
+    from epik_amd import capi
+    maps = ("7f00-7f01 r-xp 0 00:00 1 /opt/rocm-7.2.0/lib/libamdhip64.so.7.2.70200\n"
+            "7f02-7f03 r--p 0 00:00 2 /opt/rocm-7.2.0/lib/libamdhip64.so.7.2.70200\n"
+            "7f04-7f05 r-xp 0 00:00 3 /usr/lib/python3/dist-packages/torch/lib/libamdhip64.so\n"
+            "7f06-7f07 r-xp 0 00:00 4 /usr/lib/libc.so.6\n")
+    found = capi.hip_runtimes(maps)
+    assert len(found) == 2 and all("libamdhip64" in f for f in found)
+    with pytest.raises(ImportError, match="Import torch BEFORE"):
+        capi.check_hip_runtime(found)
+    capi.check_hip_runtime(found[:1])
+    capi.check_hip_runtime([])
+    # the real thing, in a process of its own: our library first, torch second
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from epik_amd import capi\n"
+            "capi.load()\n"
+            "import torch\n"
+            "try:\n"
+            "    capi.device_count()\n"
+            "except ImportError as err:\n"
+            "    print('REFUSED', err)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    if len(capi.hip_runtimes()) <= 1 and "REFUSED" not in out.stdout:
+        # (a torch built against the system's ROCm brings no runtime of its own: nothing to refuse)
+        assert out.returncode == 0, out.stderr[-2000:]
+    else:
+        assert "REFUSED" in out.stdout and "two HIP runtimes" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_build_record_names_the_compiler_and_the_sources():
+    from epik_amd import provenance
+    summary = provenance.summary()
+    assert summary["kernel_source_hash"] == provenance.kernel_source_hash()
+    built = provenance.built_with()
+    assert built, "make -C epik_amd/csrc writes epik_amd/libepik_amd.build.json"
+    assert "clang" in built["hipcc"] or "HIP version" in built["hipcc"], built
+    assert summary["library_is_current"], "the library in the tree was not built from the sources in the tree"
+    lint = provenance.lint_record()
+    assert lint and lint["hipcc"] == built["hipcc"], "csrc/lint_passed.json: `make -C epik_amd/csrc asm` with this compiler"

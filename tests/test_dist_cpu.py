@@ -71,3 +71,18 @@ def test_gloo_kmer_sharded_placement_matches_oracle(world, oracle_lib):
     # ... and with partial lists: three batches through the pipelined exchange, an overflow round among them
     for b in range(3):
         assert f"kmer-shard lists batch {b} ok: world={world}" in out.stdout, out.stdout[-2000:]
+
+
+def test_gloo_kmer_sharded_lists_when_one_rank_overflows_alone(oracle_lib):
+    """A rank whose lists found no room must not leave the exchange by itself (the others would go on to the
+    all-to-all while it waits in another collective): the part sizes cross together with every rank's capacity,
+    and all ranks repeat the accumulate together."""
+    world = 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker_kmer.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1", EPIK_AMD_TEST_ONE_RANK_OVERFLOWS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    for b in range(3):
+        assert f"kmer-shard lists batch {b} ok: world={world}" in out.stdout, out.stdout[-2000:]

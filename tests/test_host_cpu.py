@@ -101,6 +101,62 @@ def test_dbfile_roundtrip_and_filters(tmp_path):
     assert (stricter.values["score"] >= float(stricter.log_threshold)).all()
 
 
+def test_loader_refuses_damaged_and_foreign_containers(host_bins, tmp_path):
+    """main.cpp:277-283 loads and checks the version; here the container has a trailer (record count, posting count,
+    crc32 of the records: a conversion that died half way is caught at load), and a file that is not this build's
+    container is answered with the converter and its build line."""
+    tree = synth.make_tree(8, seed=1)
+    db = synth.make_db(tree.num_nodes, kmer_size=4, p_present=0.7, seed=5, lognormal=(1.0, 1.0))
+    good = tmp_path / "db.ekdb"
+    dbfile.write_db(str(good), db, tree.newick())
+    raw = good.read_bytes()
+    assert raw[-dbfile.TRAILER_BYTES:][:8] == dbfile.END_MAGIC
+
+    def driver(path):   # epik_amd::load as the driver calls it (the driver itself asks for its devices first)
+        return subprocess.run([os.path.join(host_bins, "host_test"), "load", str(path)], capture_output=True, text=True)
+
+    cut = tmp_path / "cut.ekdb"
+    cut.write_bytes(raw[:-40])
+    out = driver(cut)
+    assert out.returncode == 255 and "truncated or was not finished" in out.stderr, out.stderr
+    with pytest.raises(RuntimeError, match="trailer is missing"):
+        dbfile.read_db(str(cut))
+
+    flipped = bytearray(raw)
+    flipped[len(raw) - dbfile.TRAILER_BYTES - 5] ^= 0x40    # inside the last record
+    bad = tmp_path / "bad.ekdb"
+    bad.write_bytes(bytes(flipped))
+    out = driver(bad)
+    assert out.returncode == 255 and "do not match their checksum" in out.stderr, out.stderr
+    with pytest.raises(RuntimeError, match="checksum"):
+        dbfile.read_db(str(bad))
+
+    fewer = bytearray(raw)
+    fewer[-24:-16] = (int.from_bytes(raw[-24:-16], "little") - 1).to_bytes(8, "little")   # the trailer's k-mer count
+    short = tmp_path / "short.ekdb"
+    short.write_bytes(bytes(fewer))
+    out = driver(short)
+    assert out.returncode == 255 and "trailer counts" in out.stderr, out.stderr
+
+    ipk = tmp_path / "db.ipk"
+    ipk.write_bytes(b"22 serialization::archive 17 0 0" + b"\0" * 64)
+    out = driver(ipk)
+    assert out.returncode == 255, out.stderr
+    for needle in ("not an EPIKAMD1 file", "tools/ipk2ekdb.cpp", "g++ -std=c++17", "-li2l_dna", "./ipk2ekdb"):
+        assert needle in out.stderr, (needle, out.stderr)
+
+    # a version-1 file (no trailer) still loads: the good file with its version set back and its trailer cut off
+    v1 = bytearray(raw[:-dbfile.TRAILER_BYTES])
+    v1[8:12] = (1).to_bytes(4, "little")
+    old = tmp_path / "v1.ekdb"
+    old.write_bytes(bytes(v1))
+    back, _ = dbfile.read_db(str(old))
+    assert np.array_equal(back.values, db.values)
+    out = driver(old)
+    assert out.returncode == 0 and "version 1" in out.stdout, out.stderr
+    assert driver(good).returncode == 0
+
+
 def test_pendant_lengths_formula():
     """place.cpp:110-123: distal = len/2; pendant = subtree mean (if > 1 node) + distal."""
     distal, pendant = pendant_lengths(np.array([0.2, 0.4, 1.0]), np.array([1, 1, 3]),

@@ -382,6 +382,34 @@ def test_place_sharded_native_n9999(gpu_available, oracle_lib, db_layout, monkey
     _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
 
 
+def test_pipelined_batches_of_different_count_widths(gpu_available, oracle_lib, db_layout):
+    """place_kmer_sharded_lists starts batch b + 1 before batch b has crossed and finished, and the count width --
+    with it the entry format -- is chosen per batch: a batch of short reads (8-bit counts where that kernel exists),
+    one with a read of more than 255 k-mers (16-bit) and one with a read of more than 32 767 (32-bit counts,
+    16-byte entries) must each be exchanged and finished with the width they were accumulated with."""
+    assert gpu_available
+    if not db_layout.startswith("team") or "classic" in db_layout:
+        pytest.skip("dense partial vectors only on this kernel")
+    import torch
+    from epik_amd.placer import Placer
+    db, _ = _case()
+    rng = np.random.default_rng(77)
+    short = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(db.kmer_size, 120, size=150)]
+    mid = short[:40] + ["".join(rng.choice(list("ACGT"), size=700))]
+    long_ = short[40:70] + ["".join(rng.choice(list("ACGT"), size=40_000))]
+    batches = [synth.pack_reads(b) for b in (short, mid, long_, short)]
+    with Placer.from_synth(db) as pl:
+        engine = edist.ListsGpuEngine(pl, torch.device("cuda", 0))
+        widths = []
+        accumulate = engine.accumulate
+        engine.accumulate = lambda *a, **kw: (lambda parts: (widths.append(parts.entry_bytes), parts)[1])(accumulate(*a, **kw))
+        results = list(edist.place_kmer_sharded_lists(engine, batches, None))
+    assert widths == [8, 8, 16, 8], widths
+    orc = oracle_lib.Oracle.from_synth(db)
+    for (data, offs), got in zip(batches, results):
+        assert_rows_match(*got, *orc.place(data, offs, num_threads=0))
+
+
 def test_dense_partials_mark_reads_of_more_than_65535_kmers(gpu_available, db_layout):
     """The dense partial vectors count in uint16: a read of more k-mers must come back marked
     (EPIK_AMD_ROWS_COUNTS_TOO_NARROW), never with wrapped counts -- whatever the LDS counts of the launch hold

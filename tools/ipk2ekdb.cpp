@@ -53,6 +53,18 @@ struct posting {
 template <typename T>
 void put(std::ofstream& out, T v) { out.write(reinterpret_cast<const char*>(&v), sizeof v); }
 
+// crc32 (zlib's polynomial) of the record bytes, for the container's trailer
+uint32_t crc32_more(uint32_t crc, const void* data, size_t n)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; ++k) crc = (crc & 1u) ? 0xEDB88320u ^ (crc >> 1) : crc >> 1;
+    }
+    return ~crc;
+}
+
 // A2: the code of a k-mer in this container, from its letters
 uint32_t code_of(const std::string& letters, bool amino)
 {
@@ -108,12 +120,12 @@ int main(int argc, char** argv)
             return a.best != b.best ? a.best > b.best : a.code < b.code;
         });
         // EPIKAMD1 (epik_amd/dbfile.py): magic | u32 version | u32 sequence type | u32 k | f32 omega |
-        // u64 k-mers | u64 postings | u64 tree length | tree | per k-mer { u32 code | u32 n | n x {u32 branch, f32 score} }
+        // u64 k-mers | u64 postings | u64 tree length | tree | per k-mer { u32 code | u32 n | n x {u32 branch, f32 score} } | trailer
         std::ofstream out(argv[2], std::ios::binary);
         if (!out) throw std::runtime_error(std::string("cannot create ") + argv[2]);
         const std::string tree = db.tree();                                                  // main.cpp:294
         out.write("EPIKAMD1", 8);
-        put<uint32_t>(out, 1);
+        put<uint32_t>(out, 2);  // version 2: the trailer below
         put<uint32_t>(out, amino ? 1u : 0u);
         put<uint32_t>(out, (uint32_t)k);
         put<float>(out, argc == 4 ? std::stof(argv[3]) : (float)db.omega());               // main.cpp:288, A3
@@ -121,11 +133,20 @@ int main(int argc, char** argv)
         put<uint64_t>(out, total);
         put<uint64_t>(out, tree.size());
         out.write(tree.data(), (std::streamsize)tree.size());
+        uint32_t crc = 0;
         for (const auto& r : records) {
-            put<uint32_t>(out, r.code);
-            put<uint32_t>(out, (uint32_t)r.list.size());
+            const uint32_t head[2] = {r.code, (uint32_t)r.list.size()};
+            out.write(reinterpret_cast<const char*>(head), sizeof head);
             out.write(reinterpret_cast<const char*>(r.list.data()), (std::streamsize)(r.list.size() * sizeof(posting)));
+            crc = crc32_more(crc32_more(crc, head, sizeof head), r.list.data(), r.list.size() * sizeof(posting));
         }
+        // the trailer: "EPIKEND1" | u64 k-mers | u64 postings | u32 crc32 of the records | u32 0 -- the loader refuses
+        // a file without it (a conversion that died half way)
+        out.write("EPIKEND1", 8);
+        put<uint64_t>(out, records.size());
+        put<uint64_t>(out, total);
+        put<uint32_t>(out, crc);
+        put<uint32_t>(out, 0u);
         if (!out) throw std::runtime_error(std::string("cannot write ") + argv[2]);
         std::cout << "wrote " << records.size() << " k-mers, " << total << " phylo-k-mers, k = " << k << ", "
                   << (amino ? "Proteins" : "DNA") << std::endl;
