@@ -29,7 +29,20 @@ Rank 0 prints ONE JSON line.  Extra objects (rank 0, N=1 where they cost time):
                            direct-index variant beside it.  A reported baseline, not the target;
   cpu_baseline_1thread  -- the same on one thread;
   e2e                   -- FASTA in -> jplace closed through the native driver epik-dna, the
-                           reference's own "Placement time" quantity (main.cpp:322,378-381).
+                           reference's own "Placement time" quantity (main.cpp:322,378-381), on the step's
+                           million reads, timed in microseconds;
+  roofline_large_tree, roofline_large_tree_clades
+                        -- the tree of BASELINE configs[4] (N = 9 999) placed in one pass by the front / streaming /
+                           merge kernels, three steps: SURVEY 8d's random lists, and lists over the clades of
+                           reference sequences with reads cut from them (synth.make_clade_db);
+  kmer_shard_1gpu, kmer_shard_0of8_1gpu
+                        -- the two halves of the k-mer-space-sharded placement of that tree on this one GPU
+                           (65 536 reads per step, a process of its own): the whole database as one shard,
+                           and shard 0 of 8 alone -- what one of eight GPUs accumulates per batch;
+  build                 -- compiler, kernel-source hash and ISA-lint record of the library (epik_amd/provenance.py).
+config.world_size is what the process group reports; config.ranks lists every rank's device ordinal, PCI bus id,
+host and own ms_per_step (the k-mer-space shard: the bytes it sent per step) -- a SCALE record says by itself
+whether N ranks on N devices took part.
 """
 from __future__ import annotations
 
@@ -39,6 +52,7 @@ import json
 import os
 import re
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -59,8 +73,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-step", type=int, default=1_000_000,
-                    help="reads per step per GPU (BASELINE configs[1]: 1M)")
+    ap.add_argument("--reads-per-step", type=int, default=None,
+                    help="reads per step per GPU (default: BASELINE configs[1]'s 1M; --mode kmer-shard: 65536 -- the whole "
+                         "job's batch, which every rank accumulates in full, its partial lists inside 32-bit offsets)")
     ap.add_argument("--read-length", type=int, default=150)
     ap.add_argument("--leaves", type=int, default=500, help="tree leaves; N = 2*leaves - 1")
     ap.add_argument("--kmer-size", type=int, default=10)
@@ -87,7 +102,10 @@ def parse_args():
                          "kmer-shard (BASELINE configs[4]: --leaves 5000 --reads-per-step 4096): rank g builds and "
                          "holds only the lists of the codes with code %% G == g, every rank accumulates ALL reads of "
                          "the step, one all-to-all + sum of the per-read branch vectors, then each rank finishes its reads")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.reads_per_step is None:
+        args.reads_per_step = 65536 if args.mode == "kmer-shard" else 1_000_000
+    return args
 
 
 def load_counters(workload: str) -> dict:
@@ -202,8 +220,10 @@ def end_to_end(db, tree, data, read_length: int, n_reads: int, jobs: int):
         if run.returncode != 0 or not m:
             return {"reads_per_s": None, "note": (run.stdout + run.stderr)[-400:]}
         ms = max(int(m.group(1)), 1)
+        us = re.search(r"placement_time_us (\d+)", run.stdout)   # (the reference's line is in whole milliseconds)
+        us = int(us.group(1)) if us else ms * 1000
         jplace = os.path.join(out_dir, "placements_reads.fasta.jplace")
-        result = {"reads_per_s": n_reads / (ms / 1e3), "reads": n_reads, "placement_time_ms": ms, "jobs": jobs,
+        result = {"reads_per_s": n_reads / (us / 1e6), "reads": n_reads, "placement_time_ms": ms, "placement_time_us": us, "jobs": jobs,
                   "batch_size": 2000, "jplace_mb": os.path.getsize(jplace) / 1e6,
                   "what": "epik-dna: FASTA parse -> per-batch dedup -> GPU placement -> jplace written and closed "
                           "(database load excluded, as the reference's timer)"}
@@ -248,6 +268,45 @@ def end_to_end_cpu(db, tree, tmp, fasta, n_reads: int, threads: int):
         return {"value": None, "note": repr(e)[:300]}
 
 
+def pci_bus_id(device: int) -> str | None:
+    """PCI bus id of a HIP device ("0000:c1:00.0"), from torch's device properties where they carry it, else from the
+    HIP runtime this process holds."""
+    import ctypes
+    import torch
+    try:
+        props = torch.cuda.get_device_properties(device)
+        if hasattr(props, "pci_bus_id"):
+            return "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+    except Exception:  # noqa: BLE001 -- evidence only
+        pass
+    try:
+        from epik_amd import capi
+        runtimes = capi.hip_runtimes()
+        if runtimes:
+            hip = ctypes.CDLL(runtimes[0])
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+                return buf.value.decode()
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def sub_bench(extra_args, timeout=600):
+    """Another bench.py line in a process of its own (the k-mer-space shard on this GPU): the parsed JSON, or a note."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
+    try:
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-seconds", "0", "--no-extras"]
+                             + list(extra_args), capture_output=True, text=True, timeout=timeout, env=env)
+        lines = [line for line in run.stdout.splitlines() if line.startswith("{")]
+        if run.returncode != 0 or not lines:
+            return {"value": None, "note": (run.stdout + run.stderr)[-400:]}
+        return json.loads(lines[-1])
+    except (OSError, ValueError, subprocess.SubprocessError) as err:
+        return {"value": None, "note": repr(err)[:400]}
+
+
 def image_bytes(plan) -> int:
     return int(plan.table_bytes + plan.filter_bytes + plan.posting_bytes)
 
@@ -281,7 +340,7 @@ def main():
 
     import torch
 
-    from epik_amd import alphabet, capi, dist as edist, placer as eplacer, synth
+    from epik_amd import alphabet, capi, dist as edist, placer as eplacer, provenance, synth
     from epik_amd.placer import Placer
 
     if not torch.cuda.is_available() or capi.device_count() == 0:
@@ -387,7 +446,12 @@ def main():
             buf["done"] = stream.record_event()
 
         # one untimed pass says how much room the parts take (the same batch every step)
-        probe = alloc(int(n * max(args.read_length - args.kmer_size + 1, 1) * pinfo["postings_per_kmer"] * 2) + 65536)
+        want = int(n * max(args.read_length - args.kmer_size + 1, 1) * pinfo["postings_per_kmer"] * 2) + 65536
+        if want >= (1 << 32):
+            raise SystemExit(f"--reads-per-step {n}: the partial lists of one step would take {want} entries, and offsets inside "
+                             f"a part are 32-bit (include/epik_amd.h); at most {int(n * ((1 << 32) - 65536) / want)} reads per step "
+                             "with this database (the default of this mode is 65536)")
+        probe = alloc(want)
         accumulate(probe)
         torch.cuda.synchronize()
         need = int(probe["part_entries"].sum().item())
@@ -423,6 +487,9 @@ def main():
                 send_split = [int(x) * eb for x in sizes[rank]]
                 recv_split = [int(sizes[g][rank]) * eb for g in range(world)]
                 send, send_index = buf["entries"][:total * eb], buf["index"]
+                # what leaves this rank per step: the parts of the other ranks' reads and their index
+                shard_info["sent_bytes_per_step"] = (sum(send_split) - send_split[rank]
+                                                     + send_index.numel() * send_index.element_size() * (world - 1) // world)
                 if staged:
                     send, send_index = send.cpu(), send_index.cpu()
                 recv = torch.empty(sum(recv_split), dtype=torch.uint8, device=send.device)
@@ -532,10 +599,21 @@ def main():
         # (a pipelined step: the halves of consecutive batches run side by side on two streams -- the events around a
         # step on the launch stream see one of them; the step's share of the timed region is the launch time)
         kernel_ms = elapsed / args.steps * 1e3
+    # ---- what a reader of the line needs to see that N ranks on N devices really took part -------------------
+    evidence = {"rank": rank, "local_rank": local_rank, "device": int(torch.cuda.current_device()),
+                "pci_bus_id": pci_bus_id(int(torch.cuda.current_device())), "host": socket.gethostname(),
+                "ms_per_step": elapsed / args.steps * 1e3}
+    if shard_info and "sent_bytes_per_step" in shard_info:
+        evidence["sent_bytes_per_step"] = int(shard_info["sent_bytes_per_step"])
+    ranks = [evidence]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, evidence)
     elapsed = edist.max_over_ranks(elapsed, dist, device=None if rehearsal else dev)
 
-    def roofline_of(pl, pl_plan, ms, workload_name):
-        alg_bytes = pl.algorithmic_bytes(d_seqs.data_ptr(), d_offs.data_ptr(), n, d_nrows.data_ptr(), stream.cuda_stream)
+    def roofline_of(pl, pl_plan, ms, workload_name, seqs=None, offs=None):
+        seqs, offs = (d_seqs, d_offs) if seqs is None else (seqs, offs)
+        alg_bytes = pl.algorithmic_bytes(seqs.data_ptr(), offs.data_ptr(), n, d_nrows.data_ptr(), stream.cuda_stream)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         working_set = image_bytes(pl_plan)
         measured = load_counters(workload_name)
@@ -588,9 +666,14 @@ def main():
                                        if kmer_shard else
                                        f"reads sharded over {world} GPU(s), DB replicated, no collective"),
                        "collectives": (dist.get_backend() if dist is not None else None),
+                       # (as the process group reports it, not as the command line asked)
+                       "world_size": (dist.get_world_size() if dist is not None else 1), "ranks": ranks,
                        "launch": info, "mean_rows_per_read": float(n_rows_host.mean()),
                        **({"kmer_shard": shard_info} if shard_info else {})},
             "roofline": roofline_of(placer, plan, kernel_ms, workload),
+            # the compiler the library was built with, the kernel sources it was built from, and whether the ISA
+            # lint of the streaming loop passed on both (epik_amd/provenance.py)
+            "build": provenance.summary(),
         }
     placer.close()
 
@@ -618,6 +701,58 @@ def main():
         roof["reads_per_s"] = n / (big_ms * 1e-3)
         result["roofline_hbm_resident"] = roof
         del big
+    default_workload = (args.leaves == 500 and args.kmer_size == 10 and not args.clades and not args.scattered
+                        and args.p_present == 0.6 and args.read_length == 150)
+    if extras and not args.no_extras and args.states == "nucl" and default_workload:
+        # ---- the weakest product paths, in the driver's record: the large tree of configs[4] placed
+        # in one pass on this GPU -- SURVEY.md 8d's random lists, and lists over the clades of references -- and the
+        # two halves of its k-mer-space-sharded placement.  Three steps each.
+        def large_tree(clades):
+            big_tree = synth.make_tree(5000, seed=42)
+            seqs, offs = d_seqs, d_offs
+            if clades:
+                big_db, refs, _ = synth.make_clade_db(big_tree.num_nodes, kmer_size=args.kmer_size, seed=47)
+                c_data, c_offs = synth.make_clade_reads(refs, n, args.read_length, seed=48)
+                seqs, offs = torch.from_numpy(c_data).to(dev), torch.from_numpy(c_offs.view(np.int64)).to(dev)
+            else:
+                big_db = synth.make_db(big_tree.num_nodes, states="nucl", kmer_size=args.kmer_size, seed=43)
+            big_plan = eplacer.plan(big_db)
+            total = big_db.total_entries
+            name = (f"nucl k={args.kmer_size} omega=1.5 mu=1.0 synthetic DB, N={big_tree.num_nodes} branches, {total} postings "
+                    f"({total * 8 / 1e6:.0f} MB), {n} x {args.read_length} bp reads per step per GPU"
+                    + (", lists over the clades of 500 references of 1500 bp, reads cut from the references (1 % substitutions)"
+                       if clades else ""))
+            with Placer.from_synth(big_db, device=local_rank) as pl:
+                pl.choose_counts(args.read_length)
+
+                def one():
+                    pl.place_device(seqs.data_ptr(), offs.data_ptr(), n, d_rows.data_ptr(), d_nrows.data_ptr(), 0, stream.cuda_stream)
+                _, ms = timed_steps(one, 3, 1)
+                roof = roofline_of(pl, big_plan, ms, name, seqs, offs)
+            keep_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_read", "valu_busy")
+            out = {k: roof[k] for k in keep_keys if k in roof}
+            out["reads_per_s"] = n / (ms * 1e-3)
+            out["traffic_over_algorithmic"] = (roof["traffic"] / roof["algorithmic_bytes_per_launch"]) if roof.get("traffic") else None
+            out["workload"] = name + "; 3 steps after 1 warm-up"
+            return out
+        log("large tree (N = 9999), one pass ...")
+        result["roofline_large_tree"] = large_tree(False)
+        log("large tree (N = 9999), lists over clades ...")
+        result["roofline_large_tree_clades"] = large_tree(True)
+
+        def shard_line(extra):
+            doc = sub_bench(["--mode", "kmer-shard", "--leaves", "5000", "--steps", "5", "--warmup", "2"] + extra)
+            if doc.get("value") is None:
+                return doc
+            shard = doc["config"].get("kmer_shard", {})
+            return {"reads_per_s": doc["value"], "ms_per_step": doc["ms_per_step"], "reads_per_step": doc["config"]["reads_per_step_per_gpu"],
+                    "ms_per_million_reads": doc["ms_per_step"] / doc["config"]["reads_per_step_per_gpu"] * 1e6,
+                    "frac": doc["roofline"]["frac"], "achieved": doc["roofline"]["achieved"], "unit": doc["roofline"]["unit"],
+                    "kernel": doc["roofline"]["kernel"], "entries_per_read": shard.get("entries_per_read"),
+                    "partial_bytes_per_read": shard.get("partial_bytes_per_read"), "workload": doc["config"]["workload"]}
+        log("k-mer-space shard (N = 9999) on this GPU: the whole database, then shard 0 of 8 ...")
+        result["kmer_shard_1gpu"] = shard_line([])
+        result["kmer_shard_0of8_1gpu"] = shard_line(["--shard-of", "8"])
     if extras and args.cpu_baseline_seconds > 0:
         log("CPU baseline (oracle) ...")
         result["cpu_baseline"], result["cpu_baseline_1thread"] = cpu_baseline(db, data, offs, args.cpu_baseline_seconds)
@@ -625,7 +760,7 @@ def main():
         result["cpu_baseline"] = None
     if extras and not args.no_extras:
         log("end to end through the native driver ...")
-        result["e2e"] = end_to_end(db, tree, data, args.read_length, min(n, 250_000), host_cores())
+        result["e2e"] = end_to_end(db, tree, data, args.read_length, min(n, 1_000_000), host_cores())
         result["e2e_reads_per_s"] = result["e2e"].get("reads_per_s")
     if rank == 0:
         print(json.dumps(result), flush=True)

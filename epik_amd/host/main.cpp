@@ -431,8 +431,11 @@ int main(int argc, char** argv)
                   << "Placed " << num_seq_placed << " sequences.\nAverage speed: " << epik_amd::human_count(average_speed, false)
                   << " seq/s.\n";
         std::cout << "Output: " << jplace_filename << std::endl;
-        const auto placement_time =
-            (size_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - begin).count();
+        const auto placement_end = std::chrono::steady_clock::now();
+        const auto placement_time = (size_t)std::chrono::duration_cast<std::chrono::milliseconds>(placement_end - begin).count();
+        if (std::getenv("EPIK_AMD_STAGE_TIMES"))  // (the reference's line below is in whole milliseconds)
+            std::cout << "placement_time_us " << std::chrono::duration_cast<std::chrono::microseconds>(placement_end - begin).count()
+                      << std::endl;
         std::cout << "Placement time: " << epik_amd::human_duration(placement_time) << " (" << placement_time << " ms)"
                   << std::endl;
         std::cout << "Done." << '\n' << std::flush;

@@ -35,6 +35,7 @@ def test_the_collectives_run_on_rccl(gpu_available, mode):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["collectives"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["world_size"] == 1 and line["config"]["ranks"][0]["pci_bus_id"]
     if mode == "kmer-shard":
         assert line["config"]["kmer_shard"]["partials"] == "lists"
 
@@ -72,3 +73,12 @@ def test_bench_with_two_ranks(gpu_available, mode):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["collectives"] == "gloo"
     assert line["scaling"] == ("weak" if mode == "reads" else "strong")
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None  # N = 1 only
+    # the line says by itself that two ranks took part, on which devices, and what each of them measured
+    config = line["config"]
+    assert config["world_size"] == 2 and [r["rank"] for r in config["ranks"]] == [0, 1]
+    for r in config["ranks"]:
+        assert r["device"] == 0 and r["ms_per_step"] > 0 and r["host"]
+        assert r["pci_bus_id"] is None or ":" in r["pci_bus_id"]
+        if mode == "kmer-shard":
+            assert r["sent_bytes_per_step"] > 0
+    assert line["build"]["hipcc"] and line["build"]["kernel_source_hash"]
