@@ -414,7 +414,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
                 // the workgroups that share a read
                 g.stream_lds_bytes = (uint32_t)epik_amd::stream_lds_bytes(g.lds_wave_bytes, desc_bytes);
                 uint32_t stream_per_cu = epik_amd::stream_resident_blocks(plan.team_waves, g.stream_lds_bytes);
-                CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts));
+                CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts, g.stream_lds_bytes));
                 CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, g.stream_lds_bytes, &by_query));
                 stream_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(stream_per_cu, (uint32_t)std::max(by_query, 1)));
                 const uint32_t parts = (uint32_t)plan.team_waves / (uint32_t)epik_amd::kStreamWaves;

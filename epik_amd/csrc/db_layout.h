@@ -92,16 +92,32 @@ constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes
 // wave's registers go to the front and merge kernels, which run beside it) and 5 with 8 (the slice epilogue
 // needs 70 VGPRs, the streaming loop fewer; only the cold ambiguous sweep spills).
 constexpr int kStreamWaves = 4;
+constexpr size_t stream_lds_bytes(uint32_t slice_bytes, uint32_t desc_bytes) { return (size_t)kStreamWaves * (slice_bytes + desc_bytes); }
+constexpr uint32_t stream_blocks_by_lds(size_t lds_bytes)
+{
+    if (lds_bytes > kLdsPerCu) return 0;
+    const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
+    return 128u / (units ? units : 1u);
+}
+// The streaming kernel comes in two builds.  WIDE (4 slices per pass, slices so large that LDS holds three workgroups
+// of it on a CU at most -- twelve waves, three per SIMD, whatever the registers): 168 vector registers, which the slice
+// epilogue over the touched quads (team_epilogue.hpp) holds its rows in.  LEAN (everything else): the 96 registers of
+// five waves per SIMD -- the hardware fills a CU with as many workgroups as registers and LDS allow, whatever the
+// kernel was compiled for, and on the small slices of a mid-size tree that is twenty waves (measured, round 4: the
+// wide build on slices of 1 000 rows places 74 M reads/s, the lean one 100 M).
+constexpr bool stream_wide(int slices_per_pass, size_t lds_bytes)
+{
+    return slices_per_pass == 4 && stream_blocks_by_lds(lds_bytes) != 0 && stream_blocks_by_lds(lds_bytes) <= 3u;
+}
+// (what the builds are COMPILED for -- the lean build of 4 slices for three waves per SIMD like the wide one: held to the
+// 96 registers of five it spills seven of them, left alone it takes 96 and no scratch -- and what a CU then holds)
 constexpr uint32_t stream_waves_per_simd(int slices_per_pass)
 {
     return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : slices_per_pass == 4 ? 3u : 5u;
 }
-constexpr size_t stream_lds_bytes(uint32_t slice_bytes, uint32_t desc_bytes) { return (size_t)kStreamWaves * (slice_bytes + desc_bytes); }
 constexpr uint32_t stream_resident_blocks(int slices_per_pass, size_t lds_bytes)
 {
-    if (lds_bytes > kLdsPerCu) return 0;
-    const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
-    const uint32_t by_lds = 128u / (units ? units : 1u), by_regs = stream_waves_per_simd(slices_per_pass);
+    const uint32_t by_lds = stream_blocks_by_lds(lds_bytes), by_regs = stream_wide(slices_per_pass, lds_bytes) ? 3u : 5u;
     return by_lds < by_regs ? by_lds : by_regs;
 }
 constexpr uint32_t team_resident_blocks(int waves, size_t lds_bytes)

@@ -736,6 +736,7 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
 struct WaveCtx {
     static constexpr bool kTeam = false;
     static constexpr uint32_t kCandCap = kChunkCap;  // top-k candidates: as many as chunk descriptors fit
+    __device__ __forceinline__ bool untouched() const { return false; }  // (a team context may know that no row holds a count)
     template <typename Params>
     __device__ __forceinline__ uint32_t rows_pad(const Params &p) const { return p.n_pad; }
     template <typename Params>
@@ -1017,10 +1018,14 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
         }
         if (base < n_rows_pad) correct_rows(std::false_type{}, fast, base, load_trip(std::false_type{}, base));
     };
-    if (fast_div)
+    // (a slice nothing was streamed into: every row is zero as the last reset left it -- touched stays 0)
+    const bool untouched = __builtin_amdgcn_readfirstlane((int)ctx.untouched()) != 0;
+    if (untouched) {
+    } else if (fast_div) {
         correction_sweep(std::true_type{});
-    else
+    } else {
         correction_sweep(std::false_type{});
+    }
     EPI_STAMP(0)  // correction sweep
     EPI_STOP(256u)
     const uint32_t lane_best = lane_best_f == -INFINITY ? 0u : ord_f32(lane_best_f);  // 0 = none
@@ -1261,7 +1266,7 @@ __device__ __forceinline__ void place_epilogue_body(const PlaceParams *__restric
             ctx.partial->sum = sum;
         }
         EPI_STAMP(6)  // publish
-        lds.clear(n_rows_pad);
+        if (!untouched) lds.clear(n_rows_pad);
         EPI_STAMP(7)  // clear
         (void)read;
         return;

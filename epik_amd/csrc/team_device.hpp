@@ -90,6 +90,8 @@ struct TeamCtx {
     std::conditional_t<kGlobalOut, v4u *, lds_u32x4 *> cand;             // [keep_at_most] ranked rows of this slice for the merge
     std::conditional_t<kGlobalOut, TeamPartial *, lds_partial *> partial;  // this slice's share of sum_scores
     uint32_t trace_at_ = 0xffffffffu;  // diagnostic builds: the wave whose timeline is recorded writes its next entries here
+    bool untouched_ = false;  // no row of the slice holds a count (the caller knows: nothing streamed): no sweep over them
+    __device__ __forceinline__ bool untouched() const { return untouched_; }
     __device__ __forceinline__ void before_publish() const {}
     template <typename Params>
     __device__ __forceinline__ uint32_t rows_pad(const Params &) const { return rows_pad_; }

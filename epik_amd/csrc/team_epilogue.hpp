@@ -200,6 +200,7 @@ struct SliceArgs {
     float log_threshold;
     uint32_t slice_at;  // read * slices + slice: where the slice's results go
     uint32_t trace_at;  // diagnostic builds
+    uint32_t untouched; // nothing reached the slice's rows (the dense epilogue: no sweep over them)
 };
 
 // The slice epilogue over kTrips trips of touched quads (`n_quads` of them, their numbers in the wave's descriptor

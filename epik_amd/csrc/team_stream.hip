@@ -322,6 +322,7 @@ __device__ __forceinline__ void slice_epilogue(const TeamParams *__restrict__ kt
     ctx.cand = static_cast<v4u *>(ktp->slice_rows_out) + (uint64_t)a.slice_at * a.keep;
     ctx.partial = static_cast<TeamPartial *>(ktp->slice_sums_out) + a.slice_at;
     ctx.trace_at_ = a.trace_at;
+    ctx.untouched_ = a.untouched != 0;
     place_epilogue_body<TeamChunks, CountT>(&ktp->base, lds, 0ull, (uint64_t)n_kmers, ctx);
 }
 
@@ -338,7 +339,9 @@ __device__ __forceinline__ void slice_epilogue(const TeamParams *__restrict__ kt
 // kTeamModeAccumulateLists / kTeamModeFinishLists: the same halves with partial LISTS in place of the dense
 // vectors -- the rows a slice really touched, compacted (emit_partial_list), and the shards' lists of a slice
 // added back in shard order (merge_partial_lists; `src` says where they lie).
-template <int W, typename CountT, int kMode>
+// kWide: the build for slices so large that LDS keeps a CU to twelve waves (db_layout.h: stream_wide) -- 168 vector
+// registers, and with them the slice epilogue over the touched quads.
+template <int W, typename CountT, int kMode, bool kWide>
 __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp, SparseSources src)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave_in_block * tp.desc_bytes);
     // items that touched few rows take the epilogue over their touched quads (team_epilogue.hpp); 32-bit counts
     // (reads of 32 768 k-mers or more) always the dense one
-    constexpr bool kSparseCounts = sizeof(CountT) <= 2;
+    constexpr bool kSparseCounts = kWide && sizeof(CountT) <= 2;
     const uint32_t n_slices = W * tp.passes;
     const uint32_t score_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.score + (rows_pad - 1u) * 4u);
     const uint32_t count_top = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds.count +
@@ -620,10 +623,8 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 const uint64_t first = readlane_u64(part_first, (int)part) + (uint32_t)__builtin_amdgcn_readlane(my_first, (int)pass);
                 const bool fits = first + room <= tp.sparse_entries_cap;
                 uint32_t n_out = 0;
-                bool done = false;
+                bool done = slice_untouched;  // (a shard's lists reach a small part of a slice: nothing, or a few dozen quads)
                 if constexpr (kSparseCounts) {
-                    // (a shard's lists reach a small part of a slice: nothing, or a few dozen quads)
-                    done = slice_untouched;
                     if (!done && my_chunks <= tp.sparse_chunks) {
                         if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
                         done = emit_partial_list_sparse<CountT>(lds, rows_pad, tp.sparse_quads, tp.sparse_entries + first * PartialEntry<CountT>::kBytes,
@@ -639,15 +640,17 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             }
             // ---- correction, the slice's best rows and share of sum_scores (to HBM: team_merge_kernel),
             //      reset of the rows
-            if constexpr (kSparseCounts) {
+            if constexpr (kWide) {
                 // On a database built from reference sequences a read's lists fall into one slice of the four
-                // (bench.py --clades): the other three items are done here.
+                // (bench.py --clades): the other three items are done here.  (The lean build says so to its dense
+                // epilogue instead, args.untouched: a second way out of the loop here costs it 13 registers -- 109
+                // instead of the 96 of five waves per SIMD.)
                 if (slice_untouched) {
                     publish_empty_slice(ctx, (uint32_t)n_kmers, k, p.log_threshold, keep);
                     continue;
                 }
             }
-            if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
+            if (lane == 0 && !slice_untouched) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
 #ifdef EPIK_AMD_ABLATION
             if (p.ablate & 2u) {  // (timing experiments: no slice epilogue)
                 lds.clear(rows_pad);
@@ -663,6 +666,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             args.log_threshold = p.log_threshold;
             args.slice_at = (uint32_t)slice_at;  // (the host keeps reads * slices below 2^32 for this kernel)
             args.trace_at = 0xffffffffu;
+            args.untouched = slice_untouched ? 1u : 0u;
 #ifdef EPIK_AMD_ABLATION
             if (traced) args.trace_at = trace_at, trace_at += 10;  // the epilogue's entries
 #endif
@@ -837,15 +841,16 @@ __global__ __launch_bounds__(256) void team_merge_kernel(TeamParams tp, uint32_t
 namespace {
 
 template <typename F>
-hipError_t stream_dispatch(int waves, int counts, int mode, F &&f)
+hipError_t stream_dispatch(int waves, int counts, int mode, bool wide, F &&f)
 {
-#define EPIK_STREAM_CASE(W, C, M) \
-    if (waves == W && counts == C && mode == M) \
-        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M>();
-#define EPIK_STREAM_MODES(W, C) EPIK_STREAM_CASE(W, C, kTeamModePlace) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate) EPIK_STREAM_CASE(W, C, kTeamModeFinish) \
-    EPIK_STREAM_CASE(W, C, kTeamModeAccumulateLists) EPIK_STREAM_CASE(W, C, kTeamModeFinishLists)
-    EPIK_STREAM_MODES(4, kCounts8) EPIK_STREAM_MODES(4, kCounts16) EPIK_STREAM_MODES(4, kCounts32)
-    EPIK_STREAM_MODES(8, kCounts8) EPIK_STREAM_MODES(8, kCounts16) EPIK_STREAM_MODES(8, kCounts32)
+#define EPIK_STREAM_CASE(W, C, M, WIDE) \
+    if (waves == W && counts == C && mode == M && wide == WIDE) \
+        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M, WIDE>();
+#define EPIK_STREAM_MODES(W, C, WIDE) EPIK_STREAM_CASE(W, C, kTeamModePlace, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate, WIDE) \
+    EPIK_STREAM_CASE(W, C, kTeamModeFinish, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeAccumulateLists, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeFinishLists, WIDE)
+    EPIK_STREAM_MODES(4, kCounts8, false) EPIK_STREAM_MODES(4, kCounts16, false) EPIK_STREAM_MODES(4, kCounts32, false)
+    EPIK_STREAM_MODES(4, kCounts8, true) EPIK_STREAM_MODES(4, kCounts16, true) EPIK_STREAM_MODES(4, kCounts32, true)
+    EPIK_STREAM_MODES(8, kCounts8, false) EPIK_STREAM_MODES(8, kCounts16, false) EPIK_STREAM_MODES(8, kCounts32, false)
 #undef EPIK_STREAM_MODES
 #undef EPIK_STREAM_CASE
     return hipErrorInvalidValue;
@@ -915,8 +920,8 @@ hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int m
                               hipStream_t stream, const SparseSources *sources)
 {
     const SparseSources src = sources ? *sources : SparseSources{};
-    return stream_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
-        hipLaunchKernelGGL((team_stream_kernel<W, C, M>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp, src);
+    return stream_dispatch(waves, counts, mode, stream_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
+        hipLaunchKernelGGL((team_stream_kernel<W, C, M, kWide>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp, src);
         return hipGetLastError();
     });
 }
@@ -927,12 +932,12 @@ hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStre
     return hipGetLastError();
 }
 
-hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whole CU: see place_kernel.hip)
+hipError_t set_team_stream_lds_limit(int waves, int counts, size_t lds_bytes)  // (always the whole CU: see place_kernel.hip)
 {
     hipError_t err = hipSuccess;
     for (int mode = 0; mode < 5 && err == hipSuccess; ++mode)
-        err = stream_dispatch(waves, counts, mode, [&]<int W, typename C, int M>() {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M>),
+        err = stream_dispatch(waves, counts, mode, stream_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M, kWide>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
         });
     return err;
@@ -940,8 +945,8 @@ hipError_t set_team_stream_lds_limit(int waves, int counts)  // (always the whol
 
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
 {
-    return stream_dispatch(waves, counts, kTeamModePlace, [&]<int W, typename C, int M>() {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C, M>, kStreamWaves * 64,
+    return stream_dispatch(waves, counts, kTeamModePlace, stream_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C, M, kWide>, kStreamWaves * 64,
                                                             lds_bytes);
     });
 }

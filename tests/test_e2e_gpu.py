@@ -34,7 +34,8 @@ def _oracle_jplace(path, oracle_lib, db, tree, records):
     jplace.write_jplace(path, PlacedCollection(seq_map, placed), "oracle", tree.newick(jplace=True))
 
 
-@pytest.mark.parametrize("devices,kernel", [("0", None), ("0,0", None), ("0", "team4"), ("0,0", "team4x2")])
+@pytest.mark.parametrize("devices,kernel", [("0", None), ("0,0", None), ("0", "team4"), ("0,0", "team4x2"),
+                                            ("0,0,0,0,0,0,0,0", None)])  # the eight placer threads of a node, on one device
 def test_epik_py_place_matches_oracle(tmp_path, oracle_lib, devices, kernel, monkeypatch):
     """kernel: None = what create() chooses for this tree (one wavefront per read); team4 / team4x2 = the driver
     and the host-buffer entry point over the kernels of large trees (front + streaming + merge; the reads with
@@ -117,7 +118,7 @@ def test_epik_aa_places_proteins(tmp_path, oracle_lib):
     assert wrong.returncode == 255 and "Proteins" in wrong.stderr
 
 
-@pytest.mark.parametrize("shards,devices", [("2", "0,0"), ("3", "0")])
+@pytest.mark.parametrize("shards,devices", [("2", "0,0"), ("3", "0"), ("8", "0")])  # (8: configs[4]'s eight shards, one device)
 def test_db_shard_through_the_driver(tmp_path, oracle_lib, shards, devices, monkeypatch):
     """`epik.py place --db-shard G` / epik-dna --db-shard G: the database cut in G by k-mer code, every shard loaded
     on its own (the process never holds two), a handle per shard -- here on the one device --, every batch placed
