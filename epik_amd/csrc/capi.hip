@@ -417,7 +417,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
                 CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts, g.stream_lds_bytes));
                 CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, g.stream_lds_bytes, &by_query));
                 stream_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(stream_per_cu, (uint32_t)std::max(by_query, 1)));
-                const uint32_t parts = (uint32_t)plan.team_waves / (uint32_t)epik_amd::kStreamWaves;
+                const uint32_t parts = epik_amd::stream_parts(plan.team_waves);
                 g.stream_blocks = std::max(parts, (uint32_t)prop.multiProcessorCount * stream_per_cu / parts * parts);
             }
         }
@@ -854,14 +854,16 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
                                                     dim3((unsigned)front_blocks), stream));
                 if (mode == kAccumulateLists) HIP_TRY(epik_amd::launch_team_sparse_scan(tp, p->team_waves, p->d_scan_tiles, stream));
             }
-            const uint32_t parts = (uint32_t)p->team_waves / (uint32_t)epik_amd::kStreamWaves;
-            uint64_t stream_blocks = n * parts;
+            // (workgroups of four waves: W / 4 of them share a read, or -- two slices per pass -- one holds two reads)
+            const uint32_t parts = epik_amd::stream_parts(p->team_waves), per_block = epik_amd::stream_reads_per_block(p->team_waves);
+            const uint64_t n_units = (n + per_block - 1) / per_block;  // reads, or pairs of them
+            uint64_t stream_blocks = n_units * parts;
             const uint64_t stream_resident = p->max_blocks_cap ? std::min<uint64_t>(g.stream_blocks, (uint64_t)p->max_blocks_cap * parts) : g.stream_blocks;
             // (the dense halves are bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s on the
             // resident grid against 15.1 spread)
             if (stream_blocks > stream_resident && (mode == kAccumulate || mode == kFinish)) stream_blocks = stream_resident;
             if (stream_blocks > stream_resident) {  // as for `blocks` above (N = 9 999: resident x 1 / 4 / 16 / 32 / 64 = 20.2 / 19.9 / 19.4 / 19.4 / 19.6 ms)
-                stream_blocks = spread_grid(n, stream_resident / parts, kMinReadsPerStreamBlock) * parts;
+                stream_blocks = spread_grid(n_units, stream_resident / parts, kMinReadsPerStreamBlock) * parts;
 #ifdef EPIK_AMD_ABLATION
                 if (p->grid_percent) stream_blocks = std::max<uint64_t>(parts, stream_resident * p->grid_percent / 100u / parts * parts);
 #endif

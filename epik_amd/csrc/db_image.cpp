@@ -103,12 +103,16 @@ struct TeamChoice {
 // geometry that places most reads per second is the one with most resident workgroups per unit
 // of that time -- e.g. two passes of half-size slices at N = 20 000 (3 workgroups per CU) beat one
 // pass (1 workgroup) 1.8 x.  4 waves always beat 8 (fewer slices to merge, fewer idle waves in the
-// front end): 8 only when forced.  The 32-bit-count kernel must fit a CU.
+// front end): 8 only when forced; 2 -- half the items per read, each with twice the rows -- for trees of up to
+// 3 500 branches.  The 32-bit-count kernel must fit a CU.
 TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
 {
     TeamChoice best;
     double best_score = 0.0;
-    const int waves = forced_waves ? forced_waves : 4;
+    // (measured, round 4, 150 bp reads, million-read batches, M reads/s with one wavefront per read / 2 / 4 slices:
+    // N = 1 999: 125 / 130 / 107; 2 499: 103 / 127 / 103; 2 999: 93 / 114 / 103; 3 999: 71 / 92 / 100; 4 999: 58 / 88 / 97;
+    // 9 999: 25 / 63 / 67 -- an item's fixed cost against the slice epilogue's sweeps and the waves LDS leaves room for)
+    const int waves = forced_waves ? forced_waves : (n <= 3500u ? 2 : 4);
     for (uint32_t passes = forced_passes ? forced_passes : 1; passes <= 4096; ++passes) {
         const uint32_t slices = (uint32_t)waves * passes;
         const uint32_t rows = (n + slices - 1) / slices;
@@ -220,11 +224,10 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     const bool wave_fits = wave_lds_bytes(plan.n_pad, kCounts32) <= kLdsPerCu;
     for (int c = 0; c < 3; ++c) plan.wave_resident[c] = wave_fits ? wave_kernel_resident_waves(plan.n_pad, c) : 0;
 
-    // ---- kernel: one wavefront per read while enough of them fit a CU, else a workgroup per read ----
-    // (measured, r02: with the team placement as front + streaming + merge kernels it wins where fewer than 8
-    // waves of the other fit a CU with 16-bit counts, N >~ 3 100: 86 against 82 M reads/s at N = 3 499, 86
-    // against 71 at N = 3 999; 89 against 92 at N = 2 999)
-    bool team = !wave_fits || plan.wave_resident[kCounts16] < 8;
+    // ---- kernel: one wavefront per read while enough of them fit a CU, else the branch range in slices ----
+    // (measured, round 4 -- choose_team: with two slices per pass the front + streaming + merge kernels win where fewer
+    // than 12 waves of the other fit a CU with 16-bit counts, i.e. from 2 048 LDS rows per wave on, N >= 1 984)
+    bool team = !wave_fits || plan.wave_resident[kCounts16] < 12;
     int forced_waves = 0;
     uint32_t forced_passes = 0;
     if (forced_kernel && forced_kernel[0]) {
@@ -233,14 +236,15 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
             team = false;
         } else if (std::strcmp(forced_kernel, "team") == 0) {
             team = true;
-        } else if (std::strncmp(forced_kernel, "team4", 5) == 0 || std::strncmp(forced_kernel, "team8", 5) == 0) {
+        } else if (std::strncmp(forced_kernel, "team2", 5) == 0 || std::strncmp(forced_kernel, "team4", 5) == 0 ||
+                   std::strncmp(forced_kernel, "team8", 5) == 0) {
             team = true;  // teamW or teamWxP: W waves, (tests) at least P passes
             forced_waves = forced_kernel[4] - '0';
             if (forced_kernel[5] == 'x') forced_passes = (uint32_t)std::strtoul(forced_kernel + 6, nullptr, 10);
             if (forced_kernel[5] != 0 && (forced_kernel[5] != 'x' || forced_passes == 0 || forced_passes > 64))
-                return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team4[xP] or team8[xP]");
+                return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team2[xP], team4[xP] or team8[xP]");
         } else {
-            return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team4[xP] or team8[xP]");
+            return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team2[xP], team4[xP] or team8[xP]");
         }
     }
     if (forced_layout && forced_layout[0] && std::strcmp(forced_layout, "compact") != 0 &&

@@ -41,7 +41,7 @@ constexpr uint32_t kWaveKernelWavesPerCu = 20u;  // place_reads_kernel: __launch
 #ifndef EPIK_AMD_STREAM_OCC
 #define EPIK_AMD_STREAM_OCC 0  // experiments: waves per SIMD the team kernels are compiled for (0: 3 with 4-wave teams, 4 with 8)
 #endif
-constexpr uint32_t team_waves_per_simd(int waves) { return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : waves == 4 ? 3u : 4u; }
+constexpr uint32_t team_waves_per_simd(int waves) { return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : waves <= 4 ? 3u : 4u; }
 constexpr uint32_t team_kernel_waves_per_cu(int waves) { return 4u * team_waves_per_simd(waves); }
 
 constexpr uint32_t kWaveDescBytes = (EPIK_AMD_TILES_PER_PASS * 64u + EPIK_AMD_RING) * 8u;
@@ -92,6 +92,10 @@ constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes
 // wave's registers go to the front and merge kernels, which run beside it) and 5 with 8 (the slice epilogue
 // needs 70 VGPRs, the streaming loop fewer; only the cold ambiguous sweep spills).
 constexpr int kStreamWaves = 4;
+// ... each with one slice of some read: with W >= 4 slices per pass W / 4 consecutive workgroups share a read, with
+// W = 2 a workgroup holds the two slices of two reads
+constexpr uint32_t stream_parts(int slices_per_pass) { return slices_per_pass >= kStreamWaves ? (uint32_t)(slices_per_pass / kStreamWaves) : 1u; }
+constexpr uint32_t stream_reads_per_block(int slices_per_pass) { return slices_per_pass >= kStreamWaves ? 1u : (uint32_t)(kStreamWaves / slices_per_pass); }
 constexpr size_t stream_lds_bytes(uint32_t slice_bytes, uint32_t desc_bytes) { return (size_t)kStreamWaves * (slice_bytes + desc_bytes); }
 constexpr uint32_t stream_blocks_by_lds(size_t lds_bytes)
 {
@@ -99,7 +103,7 @@ constexpr uint32_t stream_blocks_by_lds(size_t lds_bytes)
     const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
     return 128u / (units ? units : 1u);
 }
-// The streaming kernel comes in two builds.  WIDE (4 slices per pass, slices so large that LDS holds three workgroups
+// The streaming kernel comes in two builds.  WIDE (2 or 4 slices per pass, slices so large that LDS holds three workgroups
 // of it on a CU at most -- twelve waves, three per SIMD, whatever the registers): 168 vector registers, which the slice
 // epilogue over the touched quads (team_epilogue.hpp) holds its rows in.  LEAN (everything else): the 96 registers of
 // five waves per SIMD -- the hardware fills a CU with as many workgroups as registers and LDS allow, whatever the
@@ -107,13 +111,13 @@ constexpr uint32_t stream_blocks_by_lds(size_t lds_bytes)
 // wide build on slices of 1 000 rows places 74 M reads/s, the lean one 100 M).
 constexpr bool stream_wide(int slices_per_pass, size_t lds_bytes)
 {
-    return slices_per_pass == 4 && stream_blocks_by_lds(lds_bytes) != 0 && stream_blocks_by_lds(lds_bytes) <= 3u;
+    return slices_per_pass <= 4 && stream_blocks_by_lds(lds_bytes) != 0 && stream_blocks_by_lds(lds_bytes) <= 3u;
 }
 // (what the builds are COMPILED for -- the lean build of 4 slices for three waves per SIMD like the wide one: held to the
 // 96 registers of five it spills seven of them, left alone it takes 96 and no scratch -- and what a CU then holds)
 constexpr uint32_t stream_waves_per_simd(int slices_per_pass)
 {
-    return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : slices_per_pass == 4 ? 3u : 5u;
+    return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : slices_per_pass <= 4 ? 3u : 5u;
 }
 constexpr uint32_t stream_resident_blocks(int slices_per_pass, size_t lds_bytes)
 {

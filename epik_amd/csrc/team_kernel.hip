@@ -39,7 +39,7 @@ enum : int { kTeamPlace = kTeamModePlace, kTeamAccumulate = kTeamModeAccumulate,
              kTeamAccumulateLists = kTeamModeAccumulateLists };  // (lists: the reads the front kernel left to this kernel)
 
 template <int W, typename CountT, int kMode>
-__global__ __launch_bounds__(W * 64, W == 4 ? 3 : 4) void team_place_kernel(TeamParams tp)
+__global__ __launch_bounds__(W * 64, team_waves_per_simd(W)) void team_place_kernel(TeamParams tp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef WaveLds<CountT> Lds;
@@ -411,6 +411,7 @@ hipError_t team_dispatch(int waves, int counts, int mode, F &&f)
 #define EPIK_TEAM_MODES(W, C) EPIK_TEAM_CASE(W, C, kTeamPlace) EPIK_TEAM_CASE(W, C, kTeamAccumulate) EPIK_TEAM_CASE(W, C, kTeamFinish) \
     EPIK_TEAM_CASE(W, C, kTeamAccumulateLists)
 #define EPIK_TEAM_COUNTS(W) EPIK_TEAM_MODES(W, kCounts8) EPIK_TEAM_MODES(W, kCounts16) EPIK_TEAM_MODES(W, kCounts32)
+    EPIK_TEAM_COUNTS(2)
     EPIK_TEAM_COUNTS(4)
     EPIK_TEAM_COUNTS(8)
 #undef EPIK_TEAM_COUNTS
@@ -451,7 +452,9 @@ hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_p
 hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream)
 {
     const dim3 block(256), grid((unsigned)((tp.base.n_reads + 255) / 256));
-    if (waves == 4)
+    if (waves == 2)
+        hipLaunchKernelGGL((team_algorithmic_bytes_kernel<2>), grid, block, 0, stream, tp, d_total);
+    else if (waves == 4)
         hipLaunchKernelGGL((team_algorithmic_bytes_kernel<4>), grid, block, 0, stream, tp, d_total);
     else if (waves == 8)
         hipLaunchKernelGGL((team_algorithmic_bytes_kernel<8>), grid, block, 0, stream, tp, d_total);

@@ -52,7 +52,7 @@ namespace epik_amd {
 // the slice's rows -- into tp.sparse_cap; team_sparse_scan_kernel lays the lists out from that.
 template <int W, bool kLists>
 // (kLists: the four extra sums do not fit the 64 registers of eight waves per SIMD: six)
-__global__ __launch_bounds__(64, W == 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
+__global__ __launch_bounds__(64, W <= 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1) void team_front_kernel(TeamParams tp, uint64_t max_kmers, uint32_t held_passes)
 {
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
@@ -349,11 +349,15 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     const PlaceParams &p = tp.base;
     const int lane = lane_id();
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // W slices per pass, kStreamWaves waves per workgroup: W / kStreamWaves consecutive workgroups share a read
-    constexpr uint32_t kParts = W / kStreamWaves;
-    static_assert(W % kStreamWaves == 0, "slices per pass: a multiple of the workgroup's waves");
-    const uint32_t wave = (blockIdx.x % kParts) * kStreamWaves + wave_in_block;  // this wave's slice of a pass
-    const uint64_t first_read = blockIdx.x / kParts, read_stride = gridDim.x / kParts;  // (the grid is a multiple of kParts)
+    // W slices per pass, kStreamWaves waves per workgroup: W / kStreamWaves consecutive workgroups share a read -- or,
+    // with two slices per pass, a workgroup holds two reads
+    constexpr uint32_t kParts = stream_parts(W), kReadsPerBlock = stream_reads_per_block(W);
+    static_assert(W % kStreamWaves == 0 || kStreamWaves % W == 0, "slices per pass: a multiple or a divisor of the workgroup's waves");
+    const uint32_t wave = kReadsPerBlock > 1 ? wave_in_block % (uint32_t)W
+                                             : (blockIdx.x % kParts) * kStreamWaves + wave_in_block;  // this wave's slice of a pass
+    // (the grid is a multiple of kParts)
+    const uint64_t first_read = kReadsPerBlock > 1 ? (uint64_t)blockIdx.x * kReadsPerBlock + wave_in_block / (uint32_t)W : blockIdx.x / kParts;
+    const uint64_t read_stride = kReadsPerBlock > 1 ? (uint64_t)gridDim.x * kReadsPerBlock : gridDim.x / kParts;
     const uint32_t rows_pad = tp.rows_pad;
     Lds lds;
     unsigned char *desc_base = lds_raw + (size_t)kStreamWaves * tp.slice_bytes;
@@ -848,6 +852,8 @@ hipError_t stream_dispatch(int waves, int counts, int mode, bool wide, F &&f)
         return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M, WIDE>();
 #define EPIK_STREAM_MODES(W, C, WIDE) EPIK_STREAM_CASE(W, C, kTeamModePlace, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate, WIDE) \
     EPIK_STREAM_CASE(W, C, kTeamModeFinish, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeAccumulateLists, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeFinishLists, WIDE)
+    EPIK_STREAM_MODES(2, kCounts8, false) EPIK_STREAM_MODES(2, kCounts16, false) EPIK_STREAM_MODES(2, kCounts32, false)
+    EPIK_STREAM_MODES(2, kCounts8, true) EPIK_STREAM_MODES(2, kCounts16, true) EPIK_STREAM_MODES(2, kCounts32, true)
     EPIK_STREAM_MODES(4, kCounts8, false) EPIK_STREAM_MODES(4, kCounts16, false) EPIK_STREAM_MODES(4, kCounts32, false)
     EPIK_STREAM_MODES(4, kCounts8, true) EPIK_STREAM_MODES(4, kCounts16, true) EPIK_STREAM_MODES(4, kCounts32, true)
     EPIK_STREAM_MODES(8, kCounts8, false) EPIK_STREAM_MODES(8, kCounts16, false) EPIK_STREAM_MODES(8, kCounts32, false)
@@ -883,7 +889,11 @@ hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, bool l
     const uint32_t held_passes = front_held_passes(waves, tp.passes, &lds);
     uint64_t max_kmers = max_kmers_of(counts);
     if (tp.base.max_kmers_cap) max_kmers = std::min<uint64_t>(max_kmers, tp.base.max_kmers_cap);
-    if (waves == 4 && !lists)
+    if (waves == 2 && !lists)
+        hipLaunchKernelGGL((team_front_kernel<2, false>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
+    else if (waves == 2)
+        hipLaunchKernelGGL((team_front_kernel<2, true>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
+    else if (waves == 4 && !lists)
         hipLaunchKernelGGL((team_front_kernel<4, false>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);
     else if (waves == 4)
         hipLaunchKernelGGL((team_front_kernel<4, true>), grid, dim3(64), lds, stream, tp, max_kmers, held_passes);

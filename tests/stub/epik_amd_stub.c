@@ -56,6 +56,17 @@ int epik_amd_placer_create_sharded(const epik_amd_placer_desc *desc, uint32_t sh
     return epik_amd_placer_create(desc, out);
 }
 
+/* (the driver asks, right after creating shard 0, whether the tree's kernels leave partial lists) */
+int epik_amd_placer_partial_info(const epik_amd_placer *p, epik_amd_partial_info *out)
+{
+    (void)p;
+    memset(out, 0, sizeof *out);
+    out->lists = 1;
+    out->slices = 4;
+    out->entry_bytes = 8;
+    return EPIK_AMD_OK;
+}
+
 int epik_amd_placer_place_sharded(epik_amd_placer *const *shards, uint32_t n_shards, const char *seqs,
                                   const uint64_t *seq_offsets, uint64_t n, epik_amd_placement *rows, uint32_t *n_rows,
                                   uint32_t *kmer_counts)

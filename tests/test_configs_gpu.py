@@ -163,7 +163,7 @@ def large_tree(gpu_available):
 
 
 @pytest.mark.parametrize("counts", ["auto", "0", "1", "2"])
-@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team4-sparse", "team4-dense", "team8", "team4-classic", "team4-smallpool"])
+@pytest.mark.parametrize("layout", ["default", "paired", "compact", "team4", "team2x2", "team4-sparse", "team4-dense", "team8", "team4-classic", "team4-smallpool"])
 def test_n9999_one_pass(large_tree, oracle_lib, counts, layout, monkeypatch):
     """150 bp reads (141 k-mers: the 8-bit counts apply), with ambiguous and invalid characters in a
     third of them; `auto` lets place() choose, 0 / 1 / 2 force 16- / 32- / 8-bit counts."""

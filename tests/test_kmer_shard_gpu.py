@@ -13,7 +13,7 @@ from epik_amd import alphabet, dist as edist, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["paired", "compact", "team4", "team8", "team4-sparse", "team4-classic", "team4-smallpool", "paired-fewblocks", "team4-fewblocks"])
+@pytest.fixture(autouse=True, params=["paired", "compact", "team4", "team8", "team2", "team4-sparse", "team4-classic", "team4-smallpool", "paired-fewblocks", "team4-fewblocks"])
 def db_layout(request, monkeypatch):
     """The halves of a sharded placement on the one-wavefront kernels, and on the team kernels as front +
     streaming (+ merge) kernels, as team_place_kernel alone (-classic), and mixed (-smallpool)."""

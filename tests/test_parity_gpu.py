@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact", "paired-runs", "filtered-runs", "packed-runs",
-                                      "team4", "team8", "team4x3", "team4-sparse", "team8x2-sparse", "team4-dense",
+                                      "team4", "team8", "team4x3", "team2", "team2x3", "team2-classic", "team2-smallpool", "team2-sparse", "team4-sparse", "team8x2-sparse", "team4-dense",
                                       "team4-classic", "team4x3-classic", "team4-smallpool", "team8x2-smallpool",
                                       "paired-fewblocks", "team4-fewblocks", "team8x2-fewblocks", "team4-classic-fewblocks"])
 def db_layout(request, monkeypatch):

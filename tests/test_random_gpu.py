@@ -48,7 +48,7 @@ def _random_case(seed):
     return db, synth.pack_reads(reads)
 
 
-@pytest.mark.parametrize("layout", ["paired", "packed", "compact", "team4", "team4-sparse", "team8x2", "team4x2-classic", "team4-smallpool", "paired-fewblocks", "team4x2-fewblocks"])
+@pytest.mark.parametrize("layout", ["paired", "packed", "compact", "team4", "team2", "team4-sparse", "team8x2", "team4x2-classic", "team4-smallpool", "paired-fewblocks", "team4x2-fewblocks"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EPIK_AMD_RANDOM_SEEDS", "16"))))
 def test_random_database_and_reads(gpu_available, oracle_lib, seed, layout, monkeypatch):
     assert gpu_available
