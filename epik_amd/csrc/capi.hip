@@ -356,6 +356,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
     pp.n_pad = plan.n_pad;
     pp.table = p->d_table;
     pp.filter = p->d_filter;
+    pp.filter_rec_bytes = plan.filter_rec_bytes;
     pp.postings = p->d_postings;
     pp.char_class = p->d_char_class;
     pp.sigma_pow_km1 = (uint32_t)(d->num_keys / d->alphabet_size);

@@ -105,6 +105,8 @@ struct TeamChoice {
 // pass (1 workgroup) 1.8 x.  4 waves always beat 8 (fewer slices to merge, fewer idle waves in the
 // front end): 8 only when forced; 2 -- half the items per read, each with twice the rows -- for trees of up to
 // 3 500 branches.  The 32-bit-count kernel must fit a CU.
+constexpr bool kNarrowFilterByDefault = true;  // (protein k = 7, 998 M postings: 245.9 M reads/s against 237.9 M with 64-bit words)
+
 TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
 {
     TeamChoice best;
@@ -364,7 +366,17 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
     plan.posting_bytes = lines * 128u + 512u;
     plan.table_bytes = d->num_keys * (paired ? 16u : 8u) + 8u;
-    plan.filter_bytes = filtered ? (d->num_keys / d->alphabet_size) * 8u : 0;
+    // A presence record holds 2 x sigma bits.  In 64-bit words the filter of a protein database with k = 7 takes 512 MB,
+    // twice the Infinity Cache; its 40 bits packed into 5 bytes (read as two dwords at any byte) 320 MB, and a record
+    // straddles a 128-byte line once in 32.  EPIK_AMD_FILTER=wide|narrow forces one.
+    plan.filter_rec_bytes = 8;
+    if (filtered && 2u * d->alphabet_size <= 40u) {
+        const char *forced_filter = std::getenv("EPIK_AMD_FILTER");
+        const bool narrow = forced_filter ? std::strcmp(forced_filter, "narrow") == 0 : kNarrowFilterByDefault;
+        if (narrow) plan.filter_rec_bytes = 5;
+    }
+    // (+ 8: a record's second dword may lie behind the last record)
+    plan.filter_bytes = filtered ? (d->num_keys / d->alphabet_size) * plan.filter_rec_bytes + (plan.filter_rec_bytes == 8 ? 0u : 8u) : 0;
     return EPIK_AMD_OK;
 }
 
@@ -564,7 +576,8 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
             }
             // filter[X], X a (k-1)-mer: bit a <=> code a.X has a list, bit sigma + b <=> code X.b has one
             const uint64_t sigma = d->alphabet_size, blocks = num_keys / sigma;  // sigma^(k-1)
-            RecordWriter out(*filter, 8, blocks);
+            const uint32_t rec = plan.filter_rec_bytes;
+            RecordWriter out(*filter, rec, blocks);
             std::vector<Cursor> first_at(sigma, Cursor(src));  // a.X, a fixed, X rising: one walk per first letter
             Cursor seq_at(src);                                 // X.b: the key space front to back
             for (uint64_t x = 0; x < blocks; ++x) {
@@ -573,7 +586,12 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
                     if (first_at[a].list(a * blocks + x) != 0) word |= 1ull << a;
                 for (uint64_t b = 0; b < sigma; ++b)
                     if (seq_at.list(x * sigma + b) != 0) word |= 1ull << (sigma + b);
-                std::memcpy(out.next(), &word, 8);
+                std::memcpy(out.next(), &word, rec);  // (little endian: the low 2 sigma bits)
+            }
+            if (rec != 8) {  // the padding behind the last record
+                RecordWriter pad(*filter, 8, 1);
+                const uint64_t zero = 0;
+                std::memcpy(pad.next(), &zero, 8);
             }
         }
         return EPIK_AMD_OK;

@@ -99,6 +99,7 @@ struct Plan {
     std::vector<uint64_t> team_quarter_lines;  // paired: [pass][4] posting lines of the pass in front of each quarter of the key space
     // device image
     uint64_t table_bytes = 0, filter_bytes = 0, posting_bytes = 0;
+    uint32_t filter_rec_bytes = 8;  // bytes of a presence record of the filtered layout: 8, or 5 (the 2 x 20 bits of a protein database, packed)
     uint64_t kept_entries = 0, present_codes = 0;
     bool runs = false;  // packed layouts: run-coded lists (place_device.hpp, kRuns)
     uint64_t quarter_lines[4] = {0, 0, 0, 0};  // paired table: posting lines in front of each quarter of the key space

@@ -318,7 +318,15 @@ struct PackedLayout {
             const bool as_prefix = (position & 1u) != 0;
             const uint32_t shared = as_prefix ? t.prefix : t.key - t.first * p.sigma_pow_km1;  // X
             const uint32_t bit = as_prefix ? p.alphabet_size + t.last : t.first;
-            const uint64_t word = wanted ? p.filter[shared] : 0ull;
+            uint64_t word = 0ull;
+            if (p.filter_rec_bytes == 8) {  // (wave-uniform)
+                if (wanted) word = p.filter[shared];
+            } else if (wanted) {
+                // 40-bit records, 5 bytes apart: the two dwords that hold one, shifted down to its first byte
+                const uint64_t at = (uint64_t)shared * 5u;
+                const uint32_t *dwords = reinterpret_cast<const uint32_t *>(p.filter) + (at >> 2);
+                word = (((uint64_t)dwords[1] << 32) | dwords[0]) >> (8u * ((uint32_t)at & 3u));
+            }
             wanted = ((word >> bit) & 1ull) != 0;
         }
         if (wanted) lookup(p, t.key, position, addr, len);

@@ -17,8 +17,9 @@ namespace epik_amd {
 struct PlaceParams {
     const void *table;           // compact: OffT offsets[num_keys + 1]; packed: uint2 {len, line}[num_keys];
                                  // paired: uint2 {len, line}[num_keys / 4][8]
-    const uint64_t *filter;      // filtered: [alphabet_size^(kmer_size-1)] presence words
+    const uint64_t *filter;      // filtered: [alphabet_size^(kmer_size-1)] presence records of filter_rec_bytes each
     uint32_t sigma_pow_km1;      // alphabet_size^(kmer_size-1)
+    uint32_t filter_rec_bytes;   // 8: 64-bit words; 5: 40 bits packed (any byte: read as two dwords)
     const uint8_t *postings;     // scores + cells, cell = n_pad - 1 - branch
     const uint32_t *char_class;  // [256]
     const uint8_t *seqs;

@@ -101,6 +101,11 @@ struct ShardSide {
     DevBuf entries[2], index[2], part_entries[2], amb_slot[2], amb_order[2], amb_avg[2];
     uint64_t entries_cap[2] = {0, 0};
     unsigned long long *h_part[2] = {nullptr, nullptr};  // pinned: part sizes of the chunk
+    // pinned: the chunk's slot arrays (reads that may hold an ambiguous k-mer) on their way to the device -- a copy
+    // from pageable memory would hold the calling thread behind everything queued on the compute stream, once per
+    // shard and chunk, and with it the overlap of a chunk's copies with the next chunk's kernels
+    int32_t *h_slots[2] = {nullptr, nullptr};
+    size_t h_slots_cap[2] = {0, 0};  // in int32
     hipEvent_t accumulated[2] = {nullptr, nullptr};
     // as a finisher: the parts it received, its rows
     DevBuf recv_entries[2][EPIK_AMD_MAX_SHARDS], recv_index[2][EPIK_AMD_MAX_SHARDS];
@@ -150,6 +155,7 @@ struct ShardState {
                     s.recv_entries[b][g].release(), s.recv_index[b][g].release(), s.recv_order[b][g].release(), s.recv_avg[b][g].release();
                 s.h_rows[b].release(), s.h_n_rows[b].release(), s.h_counts[b].release();
                 if (s.h_part[b]) (void)hipHostFree(s.h_part[b]);
+                if (s.h_slots[b]) (void)hipHostFree(s.h_slots[b]);
                 if (s.accumulated[b]) (void)hipEventDestroy(s.accumulated[b]);
                 if (s.arrived[b]) (void)hipEventDestroy(s.arrived[b]);
                 if (s.finished[b]) (void)hipEventDestroy(s.finished[b]);
@@ -406,8 +412,17 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
                 SHARD_TRY(s.amb_order[b].reserve(cells * 4u));
                 SHARD_TRY(s.amb_avg[b].reserve(cells * 4u));
                 SHARD_TRY(s.my_slot[b].reserve(ch.count * sizeof(int32_t)));
-                SHARD_TRY(hipMemcpyAsync(s.amb_slot[b].p, ch.slot.data(), ch.count * sizeof(int32_t), hipMemcpyHostToDevice, s.compute));
-                SHARD_TRY(hipMemcpyAsync(s.my_slot[b].p, ch.slot_in_part.data(), ch.count * sizeof(int32_t), hipMemcpyHostToDevice, s.compute));
+                if (s.h_slots_cap[b] < 2 * ch.count) {
+                    if (s.h_slots[b]) (void)hipHostFree(s.h_slots[b]);
+                    s.h_slots[b] = nullptr, s.h_slots_cap[b] = 0;
+                    SHARD_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.h_slots[b]), 2 * ch.count * sizeof(int32_t), hipHostMallocDefault));
+                    s.h_slots_cap[b] = 2 * ch.count;
+                }
+                // (set b's copies of two chunks ago have been waited for in complete(), like its device buffers)
+                std::memcpy(s.h_slots[b], ch.slot.data(), ch.count * sizeof(int32_t));
+                std::memcpy(s.h_slots[b] + ch.count, ch.slot_in_part.data(), ch.count * sizeof(int32_t));
+                SHARD_TRY(hipMemcpyAsync(s.amb_slot[b].p, s.h_slots[b], ch.count * sizeof(int32_t), hipMemcpyHostToDevice, s.compute));
+                SHARD_TRY(hipMemcpyAsync(s.my_slot[b].p, s.h_slots[b] + ch.count, ch.count * sizeof(int32_t), hipMemcpyHostToDevice, s.compute));
                 SHARD_TRY(hipMemsetAsync(s.amb_order[b].p, 0xff, cells * 4u, s.compute));
                 SHARD_TRY(hipMemsetAsync(s.amb_avg[b].p, 0, cells * 4u, s.compute));
                 d_slot = s.amb_slot[b].p, d_order = s.amb_order[b].p, d_avg = s.amb_avg[b].p;

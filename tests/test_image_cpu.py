@@ -102,10 +102,13 @@ def test_packed_and_paired_tables(db, scattered_db, which, runs, monkeypatch):
             assert blocks[x, 4 + a].tolist() == [lens[x * 4 + a], lines[x * 4 + a]]
 
 
-def test_filtered_layout_and_shard(amino_db, monkeypatch):
+@pytest.mark.parametrize("records", ["wide", "narrow"])
+def test_filtered_layout_and_shard(amino_db, monkeypatch, records):
+    """records: the presence filter in 64-bit words, or its 2 x 20 bits packed into 5 bytes (EPIK_AMD_FILTER)."""
     db = amino_db
     monkeypatch.setenv("EPIK_AMD_KERNEL", "wave")
     monkeypatch.setenv("EPIK_AMD_LAYOUT", "filtered")
+    monkeypatch.setenv("EPIK_AMD_FILTER", records)
     sigma, blocks = 20, db.num_keys // 20
     for shard_index, shard_count in [(0, 1), (1, 3)]:
         plan, table, filt, postings = eplacer.build_image(db, shard_index=shard_index, shard_count=shard_count)
@@ -114,7 +117,13 @@ def test_filtered_layout_and_shard(amino_db, monkeypatch):
         lens[np.arange(db.num_keys) % shard_count != shard_index] = 0
         assert plan.kept_entries == int(lens.sum())
         assert (table[:-8].view(np.uint32).reshape(-1, 2)[:, 0] & 0xFFFF).tolist() == lens.tolist()
-        words = filt.view(np.uint64)
+        if records == "narrow":
+            assert len(filt) == blocks * 5 + 8 and not filt[blocks * 5:].any()
+            packed = np.zeros((blocks, 8), dtype=np.uint8)
+            packed[:, :5] = filt[:blocks * 5].reshape(blocks, 5)
+            words = packed.view(np.uint64).reshape(-1)
+        else:
+            words = filt.view(np.uint64)
         for x in range(blocks):
             want = 0
             for a in range(sigma):
