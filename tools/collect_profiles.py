@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r03_* and
+"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r04_* and
 rewrites profiles/traffic.json from the PMC summaries, stamped with the hash of the kernel sources in
 the tree (run it on the same sources the GPU run used).
 
-    python tools/collect_profiles.py r03_a
+    python tools/collect_profiles.py r04_a
 """
 import json
 import os
@@ -14,12 +14,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from epik_amd import provenance  # noqa: E402
 
-ROUND = "r03"
+ROUND = "r04"
 FILES = {
     "bench.json": f"{ROUND}_bench.json",
     "bench_headline.json": f"{ROUND}_bench_headline_trace_run.json",
     "bench_k11.json": f"{ROUND}_bench_k11.json",
     "bench_n9999.json": f"{ROUND}_bench_n9999_team.json",
+    "bench_n9999_clades.json": f"{ROUND}_bench_clades_n9999.json",
+    "bench_n2999.json": f"{ROUND}_bench_n2999_team2.json",
+    "bench_kmer_shard_n9999_0of8.json": f"{ROUND}_bench_kmer_shard_n9999_shard_0_of_8.json",
+    "bench_amino_k7_wide_filter.json": f"{ROUND}_bench_amino_k7_1g_wide_filter.json",
+    "kernel_stats_n9999_clades.csv": f"{ROUND}_kernel_stats_clades_n9999.csv",
+    "kernel_stats_n2999.csv": f"{ROUND}_kernel_stats_n2999_team2.csv",
+    "kernel_stats_kmer_shard_n9999_0of8.csv": f"{ROUND}_kernel_stats_kmer_shard_n9999_shard_0_of_8.csv",
+    "kernel_stats_amino_k7_wide_filter.csv": f"{ROUND}_kernel_stats_amino_k7_1g_wide_filter.csv",
+    "pmc_summary_n9999_clades.txt": f"{ROUND}_pmc_summary_clades_n9999.txt",
+    "shard_halves_wave_timeline.txt": f"{ROUND}_shard_halves_wave_timeline.txt",
+    "shard_halves_0of8_wave_timeline.txt": f"{ROUND}_shard_halves_shard_0_of_8_wave_timeline.txt",
+    "team_stream_wave_timeline_clades.txt": f"{ROUND}_team_stream_wave_timeline_clades.txt",
     "bench_amino_k7.json": f"{ROUND}_bench_amino_k7_1g.json",
     "bench_kmer_shard_n9999.json": f"{ROUND}_bench_kmer_shard_n9999_1gpu.json",
     "bench_kmer_shard_n9999_256k.json": f"{ROUND}_bench_kmer_shard_n9999_1gpu_256k_reads.json",
@@ -98,12 +110,14 @@ def main():
         "note": "bench.py reports these numbers only while kernel_source_sha equals the hash of the kernel sources it "
                 "runs (epik_amd/provenance.py); `workloads` is keyed by the exact config.workload string of the bench line",
         "workloads": {},
-        "previous": dict(old.get("previous", {}), **{"r02 final (headline)": old.get("hbm_bytes_per_launch")}),
+        "previous": dict(old.get("previous", {}), **{"r03 final (headline)": old.get("hbm_bytes_per_launch")}),
     }
     for bench_file, kerns, f, out, sq in (("bench_k11.json", ("place_reads_kernel",), "pmc_summary_k11.txt",
                                            f"{ROUND}_pmc_summary_k11.txt", "sq_counters_k11.txt"),
                                           ("bench_n9999.json", ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"),
                                            "pmc_summary_n9999.txt", f"{ROUND}_pmc_summary_n9999_team.txt", "sq_counters_n9999_team.txt"),
+                                          ("bench_n9999_clades.json", ("team_front_kernel", "team_stream_kernel", "team_merge_kernel"),
+                                           "pmc_summary_n9999_clades.txt", f"{ROUND}_pmc_summary_clades_n9999.txt", "sq_counters_n9999_clades.txt"),
                                           ("bench_amino_k7.json", ("place_reads_kernel",), "pmc_summary_amino_k7.txt",
                                            f"{ROUND}_pmc_summary_amino_k7_1g.txt", "sq_counters_amino_k7.txt")):
         try:

@@ -13,8 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 log() { echo "[profile_round] $*"; }
 
 # PART=1: bench lines, kernel traces, driver and shard rates; PART=3: PMC passes; PART=2: SQ counters, instruction
-# counts, timelines, sweep (a GPU call is limited to 20 minutes: three calls); default: all.
-PART=${PART:-123}
+# counts, timelines; PART=4: the tree-size sweep (a GPU call is limited to 20 minutes: four calls); default: all.
+PART=${PART:-1234}
 if [[ $PART == *1* ]]; then
 log "full default bench line"
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || log "bench failed"
@@ -75,6 +75,8 @@ log "timeline of one wave of the streaming kernel on the clade workload (diagnos
 (cd $R && CLADES=1 EPIK_AMD_TRACE_FILE=$OUT/team_stream_wave_trace_clades.txt LEAVES=5000 ROUNDS=1 python3 tools/ablate.py lib=_ablate,kernel=team4,wide=2,stamps=1 > $OUT/team_stream_wave_trace_clades.log 2>&1 && python3 tools/trace_summary.py $OUT/team_stream_wave_trace_clades.txt > $OUT/team_stream_wave_timeline_clades.txt)
 log "timeline of one wave of the streaming kernel (diagnostic build)"
 (cd $R && EPIK_AMD_TRACE_FILE=$OUT/team_stream_wave_trace.txt LEAVES=5000 ROUNDS=1 python3 tools/ablate.py lib=_ablate,kernel=team4,wide=2,stamps=1 > $OUT/team_stream_wave_trace.log 2>&1 && python3 tools/trace_summary.py $OUT/team_stream_wave_trace.txt > $OUT/team_stream_wave_timeline.txt)
+fi
+if [[ $PART == *4* ]]; then
 log "tree sizes, kernels, passes"
 (cd $R && bash tools/sweep_tree_sizes.sh > $OUT/sweep_tree_sizes_passes.txt 2>&1)
 fi

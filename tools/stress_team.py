@@ -33,6 +33,20 @@ def main():
     dirty = rng.choice(int(offs[-1]), size=int(offs[-1]) // 400, replace=False)
     data[dirty] = np.frombuffer(b"NRYKM-*", dtype=np.uint8)[rng.integers(0, 7, size=len(dirty))]
 
+    def same_rows(got, want, what):
+        """Branches, float32 scores and k-mer counts bit for bit; like-weight ratios to 2e-6: which epilogue a slice
+        takes (dense, or over its touched quads) decides the order in which its share of sum_scores is added up, and
+        the halves of a sharded placement finish in the streaming kernel the reads that a one-pass placement leaves
+        to team_place_kernel (ambiguous k-mers)."""
+        rows, n_rows, counts = got
+        assert np.array_equal(n_rows, want[1]), (what, "row counts")
+        valid = np.arange(rows.shape[1])[None, :] < n_rows[:, None]
+        for field in ("branch", "score"):
+            a, b = rows[field][valid], want[0][field][valid]
+            assert a.tobytes() == b.tobytes(), (what, field, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+        assert np.array_equal(counts[valid], want[2][valid]), (what, "counts")
+        assert np.abs(rows["lwr"][valid] - want[0]["lwr"][valid]).max() <= 2e-6, (what, "lwr")
+
     def place(kernel):
         os.environ["EPIK_AMD_KERNEL"] = kernel
         with Placer.from_synth(db) as pl:
@@ -40,7 +54,14 @@ def main():
 
     ref, info = place("wave")
     print("wave  :", info, flush=True)
-    for kernel in ("team4", "team8", "team4x2"):
+    # (team4: the wide streaming kernel with its epilogue over the touched quads at this tree size; team2 / team8 /
+    # team4x2: the lean one; EPIK_AMD_TEAM_SPARSE=always: the touched-quad epilogue on every item its list holds)
+    for kernel in ("team4", "team2", "team8", "team4x2", "team4+sparse"):
+        if kernel.endswith("+sparse"):
+            os.environ["EPIK_AMD_TEAM_SPARSE"] = "always"
+            kernel = kernel[:-len("+sparse")]
+        else:
+            os.environ.pop("EPIK_AMD_TEAM_SPARSE", None)
         got, info = place(kernel)
         print(f"{kernel:6s}:", info, flush=True)
         for run, (rows, n_rows, counts) in enumerate(got):
@@ -51,7 +72,8 @@ def main():
                 assert a.tobytes() == b.tobytes(), (kernel, run, field, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
             assert np.array_equal(counts[valid], ref[0][2][valid]), (kernel, run, "counts")
             assert np.abs(rows["lwr"][valid] - ref[0][0]["lwr"][valid]).max() <= 2e-6, (kernel, run, "lwr")
-    print(f"one-pass: {n} reads x {repeats} runs x 3 team geometries agree with the one-wavefront kernel", flush=True)
+    os.environ.pop("EPIK_AMD_TEAM_SPARSE", None)
+    print(f"one-pass: {n} reads x {repeats} runs x 5 team geometries agree with the one-wavefront kernel", flush=True)
 
     m = min(n, 200_000)
     sub_offs = offs[:m + 1]
@@ -64,8 +86,7 @@ def main():
         for run in range(repeats):
             accumulate, finish = edist.kmer_sharded_gpu_fns(pl, sub, sub_offs, dev)
             got = edist.place_kmer_sharded(accumulate, finish, m, None, amb_slot=slot, amb_per_owner=per)
-            for a, b in zip(got, one_pass):
-                assert a.tobytes() == b.tobytes(), ("accumulate+finish", run)
+            same_rows(got, one_pass, ("accumulate+finish", run))
     print(f"accumulate + finish: {m} reads x {repeats} runs agree with the one-pass placement", flush=True)
 
     # the same halves with partial lists (round 3), through the pipelined driver of epik_amd.dist in four batches, and
@@ -78,12 +99,8 @@ def main():
             batches = [(sub[int(sub_offs[a]):int(sub_offs[b])], (sub_offs[a:b + 1] - sub_offs[a]).astype(np.uint64))
                        for a, b in zip(cuts, cuts[1:])]
             got = list(edist.place_kmer_sharded_lists(engine, batches, None, char_class=cls))
-            for i in range(3):
-                joined = np.concatenate([g[i] for g in got])
-                assert joined.tobytes() == one_pass[i].tobytes(), ("accumulate_lists + finish_lists", run, i)
-            native = Placer.place_sharded([pl], sub, sub_offs)
-            for a, b in zip(native, one_pass):
-                assert a.tobytes() == b.tobytes(), ("place_sharded, one shard", run)
+            same_rows(tuple(np.concatenate([g[i] for g in got]) for i in range(3)), one_pass, ("accumulate_lists + finish_lists", run))
+            same_rows(Placer.place_sharded([pl], sub, sub_offs), one_pass, ("place_sharded, one shard", run))
     print(f"partial lists: {m} reads x {repeats} runs (pipelined halves and place_sharded) agree with the one-pass placement", flush=True)
     # three shards on the one device: the library's own exchange against the halves driven from here, bit for bit
     os.environ["EPIK_AMD_SHARD_CHUNK"] = "20000"
