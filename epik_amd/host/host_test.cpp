@@ -29,10 +29,18 @@ int main(int argc, char** argv)
     using namespace epik_amd;
     // host_test load <file>: epik_amd::load by itself (tests/test_host_cpu.py hands it damaged containers; the driver
     // asks for its devices first)
-    if (argc == 3 && std::string(argv[1]) == "load") {
+    // ... host_test load <file> <max_entries> <shard_index> <shard_count>: the k-mer codes that shard keeps
+    if ((argc == 3 || argc == 6) && std::string(argv[1]) == "load") {
         try {
-            const auto db = load(argv[2], 1.0f, 1.5f, std::numeric_limits<size_t>::max());
+            const size_t limit = argc == 6 ? (size_t)std::stoull(argv[3]) : std::numeric_limits<size_t>::max();
+            const auto db = load(argv[2], 1.0f, 1.5f, limit, argc == 6 ? (uint32_t)std::stoul(argv[4]) : 0u,
+                                 argc == 6 ? (uint32_t)std::stoul(argv[5]) : 1u);
             std::cout << "loaded " << db.get_num_entries_loaded() << " phylo-k-mers, version " << db.version() << std::endl;
+            if (argc == 6) {
+                std::cout << "keys";
+                for (const auto key : db.keys()) std::cout << ' ' << key;
+                std::cout << std::endl;
+            }
             return 0;
         } catch (const std::exception& e) {
             std::cerr << "Error: " << e.what() << std::endl;

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <cstddef>
 #include <stdexcept>
 
@@ -240,19 +241,30 @@ phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t ma
     // ---- first walk: which records stay, and how many of their postings (file order: mu and --max-ram cut it)
     std::vector<kmer_record> records;
     uint64_t kept_total = 0;
+    // --max-ram with shards: the limit is what ONE shard may keep, but the cut is ONE position in the file for all of
+    // them -- where the shards together hold shard_count times the limit -- so that the union of the shards is the
+    // prefix an unsharded load with that total would keep (cut shard by shard, every shard would stop somewhere else).
+    const bool global_cut = shard_count > 1 && max_entries != std::numeric_limits<size_t>::max();
+    const uint64_t limit_all = global_cut && max_entries > std::numeric_limits<uint64_t>::max() / shard_count
+                                   ? std::numeric_limits<uint64_t>::max() : (uint64_t)max_entries * (global_cut ? shard_count : 1u);
+    uint64_t kept_all = 0;  // every shard's postings so far (global_cut)
     for (uint64_t r = 0; r < num_kmers && r < kmers_to_load; ++r) {
         const uint32_t key = in.pod<uint32_t>();
         const uint32_t n = in.pod<uint32_t>();
         if (key >= num_keys) throw std::runtime_error("k-mer code out of range in the database");
         const unsigned char* first = in.bytes((size_t)n * sizeof(pkdb_value), "postings");
-        if (key % shard_count != shard_index) continue;
+        const bool mine = key % shard_count == shard_index;
+        if (!mine && !global_cut) continue;
         uint32_t kept = 0;
         for (uint32_t j = 0; j < n; ++j) {
             float score;
             std::memcpy(&score, first + (size_t)j * sizeof(pkdb_value) + offsetof(pkdb_value, score), sizeof score);
             kept += score >= log_thr;
         }
-        if (kept_total + kept > max_entries) break;  // --max-ram: stop in front of the k-mer that does not fit
+        // --max-ram: stop in front of the k-mer that does not fit
+        if (global_cut ? kept_all + kept > limit_all : kept_total + kept > max_entries) break;
+        kept_all += kept;
+        if (!mine) continue;
         kept_total += kept;
         if (kept) records.push_back(kmer_record{key, kept, first, n});
     }

@@ -157,6 +157,29 @@ def test_loader_refuses_damaged_and_foreign_containers(host_bins, tmp_path):
     assert driver(good).returncode == 0
 
 
+def test_max_ram_cuts_every_shard_at_the_same_place(host_bins, tmp_path):
+    """--max-ram with --db-shard: the limit is per shard, the cut ONE position of the file -- the union of the shards
+    is the prefix an unsharded load with the summed limit keeps (advisor, round 3)."""
+    tree = synth.make_tree(8, seed=1)
+    db = synth.make_db(tree.num_nodes, kmer_size=4, p_present=0.7, seed=5, lognormal=(1.0, 1.0))
+    path = str(tmp_path / "db.ekdb")
+    dbfile.write_db(path, db, tree.newick())
+
+    def keys(limit, index, count):
+        out = subprocess.run([os.path.join(host_bins, "host_test"), "load", path, str(limit), str(index), str(count)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        line = [x for x in out.stdout.splitlines() if x.startswith("keys")][0]
+        return [int(x) for x in line.split()[1:]]
+
+    per_shard, shards = 60, 3
+    whole = keys(per_shard * shards, 0, 1)
+    parts = [keys(per_shard, g, shards) for g in range(shards)]
+    assert 0 < len(whole) < int((np.diff(db.offsets.astype(np.int64)) != 0).sum())      # the limit really cuts
+    assert sorted(k for p in parts for k in p) == whole
+    assert all(k % shards == g for g, p in enumerate(parts) for k in p)
+
+
 def test_pendant_lengths_formula():
     """place.cpp:110-123: distal = len/2; pendant = subtree mean (if > 1 node) + distal."""
     distal, pendant = pendant_lengths(np.array([0.2, 0.4, 1.0]), np.array([1, 1, 3]),
