@@ -1,5 +1,5 @@
-"""BASELINE configs[1] at its full size (N=999, k=10, 1 M x 150 bp reads, the bench.py workload) and
-the configs[4] tree (N=9 999, the team kernel) on 300 k reads: too many reads for the oracle, so the
+"""BASELINE configs[1] at its full size (N=999, k=10, 1 M x 150 bp reads, the bench.py workload), a mid-size
+tree (N=2 999) and the configs[4] tree (N=9 999, the team kernels) on 200-400 k reads: too many reads for the oracle, so the
 whole batch goes through size-independent properties and a random sample of it through the oracle,
 bit for bit."""
 import numpy as np
@@ -11,14 +11,22 @@ from epik_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[(500, 1_000_000), (5000, 300_000)], ids=["n999", "n9999"])
+@pytest.fixture(scope="module", params=[(500, 1_000_000, False), (1500, 400_000, False), (5000, 300_000, False), (5000, 200_000, True)],
+                ids=["n999", "n2999", "n9999", "n9999-clades"])
 def full_case(gpu_available, request):
+    """n999: one wavefront per read; n2999: two slices per pass, the lean streaming kernel; n9999: four slices, the
+    wide one -- dense and touched-quad epilogues side by side on SURVEY 8d's random lists, touched-quad and empty
+    slices only on lists over the clades of references (synth.make_clade_db, reads cut from the references)."""
     assert gpu_available, "pytest -m gpu needs a HIP device (no CPU fallback exists)"
     from epik_amd.placer import Placer
-    leaves, N_READS = request.param
+    leaves, N_READS, clades = request.param
     tree = synth.make_tree(leaves, seed=42)
-    db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
-    data, offs = synth.make_reads(N_READS, 150, seed=44)
+    if clades:
+        db, refs, _ = synth.make_clade_db(tree.num_nodes, kmer_size=10, seed=47)
+        data, offs = synth.make_clade_reads(refs, N_READS, 150, seed=48)
+    else:
+        db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
+        data, offs = synth.make_reads(N_READS, 150, seed=44)
     with Placer.from_synth(db) as pl:
         first = pl.place_packed(data, offs)
         again = pl.place_packed(data, offs)
@@ -36,14 +44,18 @@ def test_rows_are_well_formed(full_case):
     valid = np.arange(keep)[None, :] < n_rows[:, None]
     assert rows["branch"][valid].max() < db.num_branches
     score = np.where(valid, rows["score"], -np.inf)
-    assert (np.diff(score, axis=1) <= 0).all(), "scores must be sorted in descending order"
+    with np.errstate(invalid="ignore"):  # (-inf) - (-inf) behind a read's last row
+        steps = np.diff(score, axis=1)
+    assert (steps[valid[:, 1:]] <= 0).all(), "scores must be sorted in descending order"
     lwr = np.where(valid, rows["lwr"], 0.0)
-    assert (lwr >= 0).all() and (lwr.sum(axis=1) <= 1.0 + 1e-9).all()
+    # (sum_scores is accumulated relative to its largest term in float32, ~1e-7 relative: a read whose reported rows
+    # carry all but 1e-4 of the mass -- reads cut from a reference -- may add up to 1 + 1e-7; the bar on a ratio is 1e-5)
+    assert (lwr >= 0).all() and (lwr.sum(axis=1) <= 1.0 + 1e-6).all()
     assert (lwr[:, :1] >= lwr).all(), "the best row carries the largest like_weight_ratio"
     assert (lwr[valid] >= 0.01 * np.repeat(lwr[:, 0], n_rows) - 1e-15).all(), "filter_by_ratio (place.cpp:188-199)"
     assert (counts[valid] <= 141).all() and (counts[valid] >= 0).all()
     # equal like_weight_ratio <=> equal score inside a read (both are monotone in the score)
-    same_score = (np.diff(score, axis=1) == 0) & valid[:, 1:]
+    same_score = (steps == 0) & valid[:, 1:]
     assert (np.diff(lwr, axis=1)[same_score] == 0).all()
 
 
