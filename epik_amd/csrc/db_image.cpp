@@ -110,11 +110,17 @@ constexpr bool kNarrowFilterByDefault = true;  // (protein k = 7, 998 M postings
 TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
 {
     TeamChoice best;
-    double best_score = 0.0;
+    uint32_t best_blocks = 0;
     // (measured, round 4, 150 bp reads, million-read batches, M reads/s with one wavefront per read / 2 / 4 slices:
     // N = 1 999: 125 / 130 / 107; 2 499: 103 / 127 / 103; 2 999: 93 / 114 / 103; 3 999: 71 / 92 / 100; 4 999: 58 / 88 / 97;
     // 9 999: 25 / 63 / 67 -- an item's fixed cost against the slice epilogue's sweeps and the waves LDS leaves room for)
     const int waves = forced_waves ? forced_waves : (n <= 3500u ? 2 : 4);
+    // Passes (measured, round 4, `profiles/r04_sweep_tree_sizes_passes.txt` and DESIGN.md 3.2: M reads/s by passes --
+    // N = 12 499: 42.6 / 44.7; 14 999: 41.8 / 43.4; 15 999: 23.1 / 42.3; 19 999: 19.2 / 41.9 / 26.1; 29 999: - / 29.2 / 24.9 /
+    // 17.7; 39 999: - / - / 19.6 / 19.5 / 14.7; 49 999: - / - / - / 15.7 / 14.6 / 12.2): the fewest passes whose slices
+    // leave room for two workgroups of the streaming kernel on a CU -- three where one pass would do: every pass
+    // looks every k-mer up again and adds an item per slice, which costs more than the third workgroup brings.
+    // (Round 2's rule -- most resident workgroups per (0.15 + passes) -- took 6 passes at N = 49 999: 12.2 M.)
     for (uint32_t passes = forced_passes ? forced_passes : 1; passes <= 4096; ++passes) {
         const uint32_t slices = (uint32_t)waves * passes;
         const uint32_t rows = (n + slices - 1) / slices;
@@ -126,12 +132,10 @@ TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t for
         const int usual = (rows_pad + 7u) / 8u <= desc ? kCounts8 : kCounts16;
         const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, usual), desc, keep);
         const uint32_t blocks = team_resident_blocks(waves, normal);
-        const double score = (double)blocks / (0.15 + (double)passes);
-        if (score > best_score) {
-            best_score = score;
-            best = TeamChoice{waves, passes, rows, rows_pad, blocks * (uint32_t)waves};
-        }
-        if (forced_passes || blocks >= team_kernel_waves_per_cu(waves) / (uint32_t)waves) break;  // more passes only cost
+        const uint32_t stream_blocks = stream_blocks_by_lds(stream_lds_bytes(team_slice_bytes(rows_pad, usual), desc));
+        const TeamChoice choice{waves, passes, rows, rows_pad, blocks * (uint32_t)waves};
+        if (best.waves == 0 || stream_blocks > best_blocks) best = choice, best_blocks = stream_blocks;  // (should none reach two)
+        if (forced_passes || stream_blocks >= (passes == 1 ? 3u : 2u)) return choice;
     }
     return best;
 }
