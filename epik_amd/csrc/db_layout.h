@@ -7,7 +7,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define EPIK_AMD_TILES_PER_PASS 3
+#ifndef EPIK_AMD_TILES_PER_PASS
+#define EPIK_AMD_TILES_PER_PASS 3  // 64-character tiles of a read encoded, looked up and laid out per pass (experiments: -D)
+#endif
 #ifndef EPIK_AMD_RING
 #define EPIK_AMD_RING 8  // posting-chunk loads kept in flight per wave (power of two)
 #endif
