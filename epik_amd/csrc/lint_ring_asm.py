@@ -137,10 +137,80 @@ def _walk(name, body, lo, hi, inflight, problems):
     return inflight
 
 
+def sregs_of(token):
+    token = token.strip().rstrip(",")
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", token)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", token)
+    return {int(m.group(1))} if m else set()
+
+
+def lint_settled(name, body, problems):
+    """A scalar register written by a vector instruction (v_readlane, v_readfirstlane, a comparison) needs five
+    wait states before a vector-memory instruction may read it as its buffer resource or offset.  The ring's
+    refill in a stage carries no s_nop of its own (Layout::issue<kSettled>): the stage's other instructions lie
+    between.  Checked here for every buffer load: walking back over every path through straight-line code and
+    the local labels of an asm statement (the two arms of the run-coded refill), no such write to one of its
+    scalar operands within the last five wait states (s_nop N counts N + 1).  A basic-block label of the
+    compiler's ends the walk: the first instructions behind one are not checked against what precedes them on
+    other paths -- which is why the ring's first trip, straight from the lanes, keeps its s_nop 4."""
+    code = []  # the instructions in program order: (line number, text); labels as (line number, "LABEL", name)
+    for n, l in enumerate(body):
+        t = l.strip()
+        if not t or t.startswith((";", "//")):
+            continue
+        m = re.match(r"(\.L\w+):", t)
+        if m:
+            code.append((n, "LABEL", m.group(1)))
+            continue
+        if t.startswith("."):
+            continue
+        code.append((n, t, None))
+
+    def walk(back, states, reads, load_line, load_text):
+        while back >= 0 and states < 5:
+            n, u, label = code[back]
+            if u == "LABEL":
+                if label.startswith(".LBB"):
+                    return
+                # a label inside an asm statement: from the branches to it, and from above unless an
+                # unconditional branch stands there
+                for src in range(back - 1, max(back - 40, -1), -1):
+                    w = code[src][1].split()
+                    if w and w[0].startswith(("s_cbranch", "s_branch")) and w[-1] == label:
+                        walk(src, states, reads, load_line, load_text)
+                if back > 0 and code[back - 1][1].startswith("s_branch "):
+                    return
+                back -= 1
+                continue
+            w = u.split(None, 1)
+            if w[0].startswith(("v_readlane_b32", "v_readfirstlane_b32")) or (w[0].startswith("v_cmp") and "_e64" in w[0]):
+                dst = sregs_of(w[1].split(",")[0]) if len(w) > 1 else set()
+                if dst & reads:
+                    problems.append(f"{name}: line {load_line}: {load_text.split()[0]} reads s{sorted(dst & reads)[0]} "
+                                    f"{states} wait state(s) behind `{u}` (needs 5)")
+                    return
+            states += int(w[1]) + 1 if w[0] == "s_nop" and len(w) > 1 and w[1].strip().isdigit() else 1
+            back -= 1
+
+    for k, (n, t, _) in enumerate(code):
+        if not t.startswith("buffer_load_"):
+            continue
+        ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+        reads = set()
+        for o in ops[1:]:
+            reads |= sregs_of(o.split()[0])
+        before = len(problems)
+        walk(k - 1, 0, reads, n, t)
+        del problems[before + 1:]  # (one report per load)
+
+
 def lint(path):
     problems = []
     linted = 0
     for name, body in kernels(open(path).read().split("\n")):
+        lint_settled(name, body, problems)
         # asm statements in program order: (line, kind, regs), kind in {"wait", "drain", "load"}
         events, in_asm = [], False
         for n, l in enumerate(body):

@@ -219,16 +219,22 @@ struct CompactLayout {
         f[1] = hi & 0xffffu;
         f[2] = (hi >> 16) * 8u;
     }
+    // kSettled: the caller has put five instructions or more between the v_readlane that made `f` and this
+    // statement (stream_round's stages; lint_ring_asm.py checks the distance in the ISA)
+    template <bool kSettled = false>
     __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
                                                  uint32_t &score)
     {
         const v4i srd = {(int)f[0], (int)f[1], (int)f[2], kRawBufferFormat};
         v2u out;
         // s_nop 4: the descriptor comes out of v_readlane (VALU-written SGPR -> VMEM needs 5 wait states)
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen"
-                     : "=&v"(out)
-                     : "v"(lane * 8u), "s"(srd)
-                     : "memory");
+        if constexpr (kSettled)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(out) : "v"(lane * 8u), "s"(srd) : "memory");
+        else
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen"
+                         : "=&v"(out)
+                         : "v"(lane * 8u), "s"(srd)
+                         : "memory");
         score = out.x;
         cell = out.y;
     }
@@ -349,6 +355,8 @@ struct PackedLayout {
     // One descriptor over the whole chunk; the cell load adds the scalar offset 4*cnt, which
     // takes part in the range check: lane l < cnt reads score l and cell l, every other lane
     // reads cell 0 (and, up to lane 1.5*cnt, a score made of cell bytes that lands on the dummy row).
+    // (kSettled: see CompactLayout::issue)
+    template <bool kSettled = false>
     __device__ static __forceinline__ void issue(const uint32_t (&f)[kFields], uint32_t lane, uint32_t &cell,
                                                  uint32_t &score)
     {
@@ -361,7 +369,7 @@ struct PackedLayout {
             // compiler give the slot different registers in each arm and copy them where the arms meet.
             const uint32_t cnt = f[2] & 127u, first_cell = f[2] >> 7;
             const v4i srd = {(int)f[0], (int)f[1], (int)(cnt * (first_cell ? 4u : 6u)), kRawBufferFormat};
-            asm volatile("s_nop 4\n\t"
+            asm volatile(".if %9 == 0\n\ts_nop 4\n\t.endif\n\t"
                          "s_cmp_eq_u32 %6, 0\n\t"
                          "s_cbranch_scc1 .Lexplicit%=\n\t"
                          "buffer_load_dword %0, %2, %4, 0 offen\n\t"
@@ -374,15 +382,21 @@ struct PackedLayout {
                          "buffer_load_dword %0, %2, %4, 0 offen\n"
                          ".Lissued%=:"
                          : "=&v"(score), "=&v"(cell)
-                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u), "s"(first_cell), "v"(lane), "s"(cnt)
+                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u), "s"(first_cell), "v"(lane), "s"(cnt), "n"(kSettled ? 1 : 0)
                          : "memory", "vcc", "scc");
         } else {
             const uint32_t cnt = f[1] >> 16;
             const v4i srd = {(int)f[0], (int)(f[1] & 0xffffu), (int)(cnt * 6u), kRawBufferFormat};
-            asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
-                         : "=&v"(score), "=&v"(cell)
-                         : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u)
-                         : "memory");
+            if constexpr (kSettled)
+                asm volatile("buffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
+                             : "=&v"(score), "=&v"(cell)
+                             : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u)
+                             : "memory");
+            else
+                asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_ushort %1, %3, %4, %5 offen"
+                             : "=&v"(score), "=&v"(cell)
+                             : "v"(lane * 4u), "v"(lane * 2u), "s"(srd), "s"(cnt * 4u)
+                             : "memory");
         }
     }
     __device__ static __forceinline__ uint2 load_posting(const PlaceParams &p, uint32_t rows_pad, uint64_t addr,
@@ -703,12 +717,18 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
             stage(
                 sa, ca, ring_s[i],
                 [&]() {
+                    // (asm statements keep their order: the descriptor words leave the lanes HERE, and the wait and
+                    // the two multiply-adds below, the add of this stage, the scalar instructions that split the
+                    // words and the LDS writes lie between them and the refill that reads them as a buffer resource --
+                    // the five wait states a VALU-written SGPR needs before a VMEM instruction may read it, without
+                    // the s_nop 4 the refill would otherwise begin with)
 #pragma unroll
-                    for (int q = 0; q < Layout::kFields; ++q) f[q] = __builtin_amdgcn_readlane(field[q], i);
+                    for (int q = 0; q < Layout::kFields; ++q)
+                        asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(f[q]) : "v"(field[q]), "i"(i));
                     addresses(ring_c[(i + 1) % kDepth], std::integral_constant<int, Layout::kWaitLoads *(kDepth - 2)>{}, sa_next, ca_next, score_top,
                               count_top);
                 },
-                [&]() { Layout::issue(f, (uint32_t)lane, ring_c[i], ring_s[i]); });
+                [&]() { Layout::template issue<true>(f, (uint32_t)lane, ring_c[i], ring_s[i]); });
             sa = sa_next, ca = ca_next;
         }
     }

@@ -178,6 +178,37 @@ def test_the_ring_lint_sees_a_copy_of_a_register_in_flight(tmp_path):
     assert kernel(in_first_trip="\tv_mov_b32_e32 v20, v7") == []         # slot 1's registers are still free there
 
 
+def test_the_ring_lint_counts_the_wait_states_in_front_of_a_refill(tmp_path):
+    """A refill without its s_nop 4 (the stages of the ring: Layout::issue<kSettled>) must lie five wait states
+    behind the v_readlane that made its buffer resource -- in straight-line code and through the local labels of the
+    run-coded refill's two arms."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lint_ring_asm", os.path.join(root, "epik_amd", "csrc", "lint_ring_asm.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+
+    def problems(between, load):
+        lines = ["_ZN8epik_amd18place_reads_kernelIcEEvNS_11PlaceParamsE:", "\ts_load_dwordx2 s[0:1], s[4:5], 0x0",
+                 "\tv_readlane_b32 s9, v2, 0", "\tv_readlane_b32 s4, v3, 0"] + between + load + ["\ts_endpgm"]
+        out = []
+        lint.lint_settled("k", lines, out)
+        return out
+
+    filler = ["\ts_lshr_b32 s10, s9, 16", "\ts_and_b32 s5, s9, 0xffff", "\ts_mul_i32 s6, s10, 6", "\ts_lshl_b32 s3, s10, 2"]
+    plain = ["\tbuffer_load_dword v6, v1, s[4:7], 0 offen", "\tbuffer_load_ushort v4, v2, s[4:7], s3 offen"]
+    assert len(problems(filler, plain)) == 1                                  # four instructions between: one short
+    assert problems(filler + ["\tv_add_f32 v1, v2, v3"], plain) == []
+    assert problems(filler[:1] + ["\ts_nop 3"], plain) == []                   # s_nop 3: four wait states
+    assert len(problems(filler[:1] + ["\ts_nop 2"], plain)) == 1
+    # the two arms of the run-coded refill: the arm behind the label is reached from the branch
+    arms = ["\ts_cmp_eq_u32 s8, 0", "\ts_cbranch_scc1 .Lexplicit7", "\tbuffer_load_dword v6, v1, s[4:7], 0 offen",
+            "\tv_sub_u32 v4, s8, v0", "\ts_branch .Lissued7", ".Lexplicit7:", "\tbuffer_load_ushort v4, v2, s[4:7], s3 offen",
+            "\tbuffer_load_dword v6, v1, s[4:7], 0 offen", ".Lissued7:"]
+    assert len(problems(filler[:2], arms)) == 2      # both arms four wait states behind the v_readlane
+    assert problems(filler[:3], arms) == []
+
+
 def test_release_scratch_rejects_null():
     lib = capi.load()
     assert lib.epik_amd_placer_release_scratch(None) == capi.ERR_INVALID
