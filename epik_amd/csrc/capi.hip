@@ -292,6 +292,10 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
 
     epik_amd_placer *p = new (std::nothrow) epik_amd_placer();
     if (!p) return fail(EPIK_AMD_ERR_INVALID, "out of host memory");
+    {
+        static std::atomic<uint64_t> created{0};
+        p->generation = ++created;
+    }
     struct guard {  // whatever way this function is left before the end, the placer goes with it
         epik_amd_placer *p;
         ~guard() { epik_amd_placer_destroy(p); }

@@ -23,6 +23,9 @@ struct epik_amd_placer {
     uint64_t db_bytes = 0;
     uint32_t *d_char_class = nullptr;
     // buffers of epik_amd_placer_place_sharded, kept from call to call on the first handle of the set (shard_place.hip)
+    // which create() made this handle, counted over the process: a set of handles kept from call to call
+    // (shard_place.hip) knows a handle by it, not by an address that a later create() may be given again
+    uint64_t generation = 0;
     void *shard_state = nullptr;
     void (*shard_state_free)(void *) = nullptr;
     std::vector<uint32_t> h_char_class;  // the same on the host (shard_place.hip: which reads may hold an ambiguous k-mer)

@@ -140,6 +140,7 @@ struct ShardSide {
 // places group after group of batches through the same handles), freed with it.
 struct ShardState {
     std::vector<epik_amd_placer *> handles;
+    std::vector<uint64_t> generations;  // (of the handles: an address may come back from a later create())
     std::vector<ShardSide> sides;
     bool ready = false;
     ~ShardState()
@@ -281,6 +282,7 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     ShardState *state = static_cast<ShardState *>(shards[0]->shard_state);
     // (the same handles -- and still the same streams: a handle destroyed and another created at its address is not it)
     bool same = state && state->handles.size() == G && std::equal(state->handles.begin(), state->handles.end(), shards);
+    for (uint32_t g = 0; same && g < G; ++g) same = state->generations[g] == shards[g]->generation;
     for (uint32_t g = 0; same && state->ready && g < G; ++g)
         same = state->sides[g].compute == shards[g]->stream && state->sides[g].copy == shards[g]->stream_in &&
                state->sides[g].device == shards[g]->device;
@@ -292,6 +294,7 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     if (!state) {
         state = new ShardState();
         state->handles.assign(shards, shards + G);
+        for (uint32_t g = 0; g < G; ++g) state->generations.push_back(shards[g]->generation);
         state->sides.resize(G);
         shards[0]->shard_state = state;
         shards[0]->shard_state_free = free_shard_state;
