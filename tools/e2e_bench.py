@@ -82,7 +82,12 @@ def main():
                           "reads_per_s_fasta_to_jplace": args.reads / (place_ms / 1e3) if place_ms else None,
                           "process_wall_s": wall, "fasta_mb": os.path.getsize(fasta) / 1e6,
                           "jplace_mb": os.path.getsize(jp) / 1e6,
-                          "stages": re.findall(r"^stage .*$", run.stdout, flags=re.M)}), flush=True)
+                          "stages": re.findall(r"^stage .*$", run.stdout, flags=re.M),
+                          # (EPIK_AMD_WRITE_TIMES=1: the writer's two halves, summed over the groups)
+                          "writer_ms": {"format": round(sum(float(x) for x in re.findall(r"format ([\d.]+) ms", run.stderr)), 1),
+                                        "to_file": round(sum(float(x) for x in re.findall(r"(?:pwrite|mapped copy) ([\d.]+) ms", run.stderr)), 1),
+                                        "how": os.environ.get("EPIK_AMD_JPLACE_WRITE", "pwrite")}
+                          if os.environ.get("EPIK_AMD_WRITE_TIMES") else None}), flush=True)
     if not args.keep:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
