@@ -62,7 +62,16 @@ jplace_writer::jplace_writer(const std::string& filename, const std::string& inv
 
 jplace_writer::~jplace_writer()
 {
+    try {
+        wait_for_flush();
+    } catch (...) {  // (end() was not reached: an error is on its way up already)
+    }
     if (_fd >= 0) ::close(_fd);
+}
+
+void jplace_writer::wait_for_flush()
+{
+    if (_flush.valid()) _flush.get();
 }
 
 namespace {
@@ -266,13 +275,17 @@ jplace_writer& jplace_writer::write_group(const std::vector<const Batch*>& group
     }
     // Every part formats its runs into a buffer of its own, then -- the sizes known -- writes it at its place in
     // the file: the pieces of a group go out side by side (pwrite), not one after the other through one thread.
-    if (_buffers.size() < parts) _buffers.resize(parts);
+    // ... while the pieces of the group before this one are still on their way to the file: buffered writes to one
+    // file pass through its inode one after the other to a good part (16 threads: 873 MB in 90 ms), and the
+    // formatting threads of the next group have the cores meanwhile.
+    std::vector<std::string>& buffers = _buffers[_set];
+    if (buffers.size() < parts) buffers.resize(parts);
     const auto t0 = std::chrono::steady_clock::now();
     parallel_for(parts, parts, [&](size_t part) {
         // (a string of the thread's own while it grows: the size fields of neighbouring strings share cache
-        // lines, and every append writes one -- eight threads formatting into _buffers[] directly ran no faster
+        // lines, and every append writes one -- eight threads formatting into buffers[] directly ran no faster
         // than one)
-        std::string buffer = std::move(_buffers[part]);
+        std::string buffer = std::move(buffers[part]);
         buffer.clear();
         size_t objects = 0;
         for (const auto& r : work[part]) objects += r.end - r.begin;
@@ -284,19 +297,25 @@ jplace_writer& jplace_writer::write_group(const std::vector<const Batch*>& group
             first_run = false;
             format_objects(*group[r.batch], r.begin, r.end, buffer, _length_text.empty() ? nullptr : &_length_text);
         }
-        _buffers[part] = std::move(buffer);
+        buffers[part] = std::move(buffer);
     });
     const auto t1 = std::chrono::steady_clock::now();
+    wait_for_flush();  // (the other set's pieces: at most one group is on its way)
     std::vector<uint64_t> at(parts + 1, _size);
-    for (size_t part = 0; part < parts; ++part) at[part + 1] = at[part] + _buffers[part].size();
-    parallel_for(parts, parts, [&](size_t part) {
-        write_at(_fd, _buffers[part].data(), _buffers[part].size(), at[part], _filename);
+    for (size_t part = 0; part < parts; ++part) at[part + 1] = at[part] + buffers[part].size();
+    const bool times = std::getenv("EPIK_AMD_WRITE_TIMES") != nullptr;
+    const double format_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    _flush = std::async(std::launch::async, [this, &buffers, at, parts, total, times, format_ms] {
+        const auto t2 = std::chrono::steady_clock::now();
+        parallel_for(parts, parts, [&](size_t part) {
+            write_at(_fd, buffers[part].data(), buffers[part].size(), at[part], _filename);
+        });
+        if (times)
+            std::fprintf(stderr, "write: %zu objects in %zu parts: format %.1f ms, pwrite %.1f ms (%.1f MB)\n", total, parts, format_ms,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count(),
+                         (double)(at[parts] - at[0]) / 1e6);
     });
-    const auto t2 = std::chrono::steady_clock::now();
-    if (std::getenv("EPIK_AMD_WRITE_TIMES"))
-        std::fprintf(stderr, "write: %zu objects in %zu parts: format %.1f ms, pwrite %.1f ms (%.1f MB)\n", total, parts,
-                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                     std::chrono::duration<double, std::milli>(t2 - t1).count(), (double)(at[parts] - _size) / 1e6);
+    _set ^= 1;
     _size = at[parts];
     _first = false;
     return *this;
@@ -304,6 +323,7 @@ jplace_writer& jplace_writer::write_group(const std::vector<const Batch*>& group
 
 void jplace_writer::end()
 {
+    wait_for_flush();
     const std::string tail = _first ? "]\n}\n" : "\n    ]\n}\n";  // jplace.cpp:61-69
     append(tail.data(), tail.size());
     if (::close(_fd) != 0) {

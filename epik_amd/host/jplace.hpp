@@ -7,6 +7,7 @@
 #define EPIK_AMD_HOST_JPLACE_HPP
 
 #include <cstdint>
+#include <future>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -46,7 +47,12 @@ private:
     std::string _tree;
     bool _first = true;
     std::vector<std::string> _length_text;  // per branch: ", <distal>, <pendant>]"
-    std::vector<std::string> _buffers;  // one per formatting thread, kept from group to group (no fresh pages every time)
+    // one per formatting thread, kept from group to group (no fresh pages every time); two sets: the pieces of a group
+    // go to the file (_flush) while the next group is formatted into the other set
+    std::vector<std::string> _buffers[2];
+    int _set = 0;
+    std::future<void> _flush;
+    void wait_for_flush();  // (throws what the write threw)
 };
 
 std::string json_escape(std::string_view s);
