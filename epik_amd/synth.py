@@ -301,8 +301,10 @@ def reads_hitting(db: SynthDB, n_reads: int, length: int, hit_rate: float, seed:
     rng = np.random.default_rng(seed)
     sigma, k = db.alphabet_size, db.kmer_size
     chars = np.frombuffer(alphabet.state_chars(db.states).encode(), dtype=np.uint8)
-    lens = np.diff(db.offsets.view(np.int64)) if db.num_keys <= (1 << 26) else None
-    if lens is not None:
+    lens = np.diff(db.offsets.view(np.int64)) if db.keys is None and db.num_keys <= (1 << 26) else None
+    if db.keys is not None:  # the sparse form: the present codes are listed
+        present = db.keys.astype(np.int64)
+    elif lens is not None:
         present = np.nonzero(lens)[0]
     else:  # large key space: sample codes until enough present ones are found
         present = np.zeros(0, dtype=np.int64)

@@ -83,6 +83,7 @@ typedef struct orc_node {
 struct orc_hash {
     orc_node **buckets;
     uint64_t n_buckets;
+    int borrowed; /* the nodes' lists lie in the caller's values[] (orc_hash_create_sparse) */
 };
 
 static int is_prime(uint64_t x)
@@ -127,6 +128,37 @@ struct orc_hash *orc_hash_create(const orc_db *db)
     return h;
 }
 
+/* The same map from the sparse form of a database -- keys[n_present] ascending, offsets[n_present + 1] into
+ * db->values -- for key spaces where an offset per POSSIBLE code is out of reach (amino k = 7: 10 GB).  The lists
+ * stay where they are (db->values must outlive the map); db->offsets is not read and may be NULL. */
+struct orc_hash *orc_hash_create_sparse(const orc_db *db, const uint32_t *keys, const uint64_t *offsets, uint64_t n_present)
+{
+    struct orc_hash *h = (struct orc_hash *)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->borrowed = 1;
+    h->n_buckets = n_present + 1;
+    while (!is_prime(h->n_buckets)) ++h->n_buckets;
+    h->buckets = (orc_node **)calloc(h->n_buckets, sizeof(orc_node *));
+    if (!h->buckets) {
+        free(h);
+        return NULL;
+    }
+    for (uint64_t i = 0; i < n_present; ++i) {
+        if (offsets[i + 1] == offsets[i]) continue;
+        orc_node *node = (orc_node *)malloc(sizeof(*node));
+        if (!node) {
+            orc_hash_destroy(h);
+            return NULL;
+        }
+        node->key = keys[i];
+        node->begin = (orc_pkdb_value *)(uintptr_t)(db->values + offsets[i]);
+        node->len = offsets[i + 1] - offsets[i];
+        node->next = h->buckets[node->key % h->n_buckets];
+        h->buckets[node->key % h->n_buckets] = node;
+    }
+    return h;
+}
+
 void orc_hash_destroy(struct orc_hash *h)
 {
     if (!h) return;
@@ -134,7 +166,7 @@ void orc_hash_destroy(struct orc_hash *h)
         orc_node *node = h->buckets[i];
         while (node) {
             orc_node *next = node->next;
-            free(node->begin);
+            if (!h->borrowed) free(node->begin);
             free(node);
             node = next;
         }

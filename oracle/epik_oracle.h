@@ -73,6 +73,8 @@ typedef struct {
 
 /* The hash-map form of the database (see orc_db.hash); built from the CSR arrays. */
 struct orc_hash *orc_hash_create(const orc_db *db);
+/* ... from keys[n_present] (ascending) + offsets[n_present + 1]: no array per possible code; db->offsets unused */
+struct orc_hash *orc_hash_create_sparse(const orc_db *db, const uint32_t *keys, const uint64_t *offsets, uint64_t n_present);
 void orc_hash_destroy(struct orc_hash *h);
 
 /* Scratch for one thread: the per-thread arrays of placer (place.h:126-137). */

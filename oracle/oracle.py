@@ -68,6 +68,8 @@ def _load():
                                           ctypes.c_void_p]
         lib.orc_hash_create.restype = ctypes.c_void_p
         lib.orc_hash_create.argtypes = [ctypes.POINTER(_OrcDb)]
+        lib.orc_hash_create_sparse.restype = ctypes.c_void_p
+        lib.orc_hash_create_sparse.argtypes = [ctypes.POINTER(_OrcDb), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         lib.orc_hash_destroy.restype = None
         lib.orc_hash_destroy.argtypes = [ctypes.c_void_p]
         _lib = lib
@@ -105,6 +107,27 @@ class Oracle:
                    num_branches=db.num_branches, threshold=db.threshold,
                    log_threshold=db.log_threshold, keep_at_most=keep_at_most,
                    keep_factor=keep_factor)
+
+    @classmethod
+    def from_sparse(cls, db, states=None, keep_at_most=7, keep_factor=0.01):
+        """From the sparse form of a database (db.keys[present] ascending, db.offsets[present + 1]): search() through
+        the hash map alone, no offset per possible code (amino k = 7 would need 10 GB of them)."""
+        from epik_amd import alphabet  # tables only; not the product path
+        assert getattr(db, "keys", None) is not None
+        self = cls(np.zeros(1, dtype=np.uint64), db.values, alphabet.char_class_table(states or db.states),
+                   kmer_size=db.kmer_size, alphabet_size=db.alphabet_size, num_branches=db.num_branches,
+                   threshold=db.threshold, log_threshold=db.log_threshold, keep_at_most=keep_at_most,
+                   keep_factor=keep_factor)
+        self._keys = np.ascontiguousarray(db.keys, dtype=np.uint32)
+        self._sparse_offsets = np.ascontiguousarray(db.offsets, dtype=np.uint64)
+        self._db.num_keys = int(db.alphabet_size) ** int(db.kmer_size)
+        self._db.offsets = None  # (not read while the map is in place)
+        self._hash = self._lib.orc_hash_create_sparse(ctypes.byref(self._db), self._keys.ctypes.data,
+                                                      self._sparse_offsets.ctypes.data, int(self._keys.shape[0]))
+        if not self._hash:
+            raise MemoryError("orc_hash_create_sparse")
+        self._db.hash = self._hash
+        return self
 
     def place(self, seqs, seq_offsets, num_threads: int = 1):
         """Returns (rows[n, keep_at_most] ORC_ROW, n_rows[n] uint32, counts[n, keep_at_most] uint32)."""

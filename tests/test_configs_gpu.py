@@ -130,6 +130,40 @@ def test_amino_k7_100k_reads(amino_k7, amino_k7_placer, oracle_lib, monkeypatch)
     assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
 
 
+def test_amino_k7_at_the_stated_size(gpu_available, oracle_lib, monkeypatch):
+    """configs[3] at the size BASELINE.md states: p_present 0.0133 of the 1.28 G codes, about 1 G postings (8 GB of
+    values, an 18 GB image), handed to create() in the sparse form of the descriptor -- nothing here holds an array
+    per possible code, the oracle neither: it searches through its hash map built from the same keys
+    (oracle.Oracle.from_sparse).  50 000 reads through the size-independent properties, a sample of them bit for bit."""
+    assert gpu_available
+    from epik_amd.placer import Placer
+    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_RUNS", "EPIK_AMD_FILTER"):
+        monkeypatch.delenv(var, raising=False)
+    tree = synth.make_tree(500, seed=42)
+    db = synth.make_sparse_db(tree.num_nodes, states="amino", kmer_size=7, p_present=0.0133, seed=43, dense=False)
+    assert db.keys is not None and 0.9e9 < db.num_entries < 1.1e9 and db.offsets.shape[0] == db.keys.shape[0] + 1
+    n = 50_000
+    data, offs = synth.reads_hitting(db, n, 300, hit_rate=0.25, seed=53, dirty="BZXJ*")
+    with Placer.from_synth(db) as pl:
+        rows, n_rows, counts = pl.place_packed(data, offs)
+        again = pl.place_packed(data, offs)
+    for a, b in zip((rows, n_rows, counts), again):
+        assert a.tobytes() == b.tobytes()
+    keep = rows.shape[1]
+    assert n_rows.min() >= 1 and n_rows.max() <= keep
+    valid = np.arange(keep)[None, :] < n_rows[:, None]
+    assert rows["branch"][valid].max() < db.num_branches
+    assert (np.diff(rows["score"], axis=1)[valid[:, 1:]] <= 0).all(), "scores must be sorted in descending order"
+    lwr = np.where(valid, rows["lwr"], 0.0)
+    assert (lwr >= 0).all() and (lwr.sum(axis=1) <= 1.0 + 1e-9).all() and (lwr[:, :1] >= lwr).all()
+    assert (lwr[valid] >= 0.01 * np.repeat(lwr[:, 0], n_rows) - 1e-15).all()     # filter_by_ratio, place.cpp:188-199
+    assert (counts[valid] <= 294).all() and (counts[:, 0] > 0).mean() > 0.9, "the reads must find their planted k-mers"
+    pick = np.sort(np.random.default_rng(11).choice(n, size=1500, replace=False))
+    sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
+    ref = oracle_lib.Oracle.from_sparse(db).place(sample, sample_offs, num_threads=0)
+    assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
+
+
 def test_protein_reads_across_the_underflow_limits(amino_k7, amino_k7_placer, oracle_lib, monkeypatch):
     """sum_scores has three regimes by the size of its largest term 10^ref: relative to it in float32 (ref > -280),
     term by term in double (down to -325, where a double still holds a denormal), and nothing to add at all below that

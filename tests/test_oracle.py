@@ -217,3 +217,19 @@ def test_hash_map_lookup_and_batched_dedup_change_nothing(oracle_lib, small_case
         for got in (orc.place(data, offs, num_threads=2), orc.place_batched(data, offs, batch_size=700, num_threads=3)):
             for a, b in zip(plain, got):
                 assert a.tobytes() == b.tobytes()
+
+
+def test_hash_map_from_the_sparse_form_gives_the_same_placements(oracle_lib):
+    """Oracle.from_sparse: search() through a hash map built from keys[present] + offsets[present + 1] -- no array per
+    possible code -- against the direct index over the densified database (what tests at amino k = 7's stated size
+    check the device against)."""
+    from epik_amd import synth
+    tree = synth.make_tree(50, seed=1)
+    db = synth.make_sparse_db(tree.num_nodes, states="amino", kmer_size=4, p_present=0.05, seed=3, dense=False)
+    dense = db.densified()
+    data, offs = synth.reads_hitting(db, 300, 60, hit_rate=0.3, seed=5, dirty="BZXJ*")
+    sparse_rows = oracle_lib.Oracle.from_sparse(db).place(data, offs)
+    dense_rows = oracle_lib.Oracle.from_synth(dense).place(data, offs)
+    assert (dense_rows[1] > 0).mean() > 0.9
+    for a, b in zip(sparse_rows, dense_rows):
+        assert a.tobytes() == b.tobytes()
