@@ -41,10 +41,10 @@ def test_the_collectives_run_on_rccl(gpu_available, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["reads", "kmer-shard"])
-def test_bench_with_two_ranks(gpu_available, mode):
-    """bench.py as the driver launches it for N = 2 -- torch.distributed.run, one process per rank, barrier + maximum
-    over ranks, one JSON line from rank 0 -- rehearsed on the one device (EPIK_AMD_BENCH_REHEARSAL=1: both ranks on
+@pytest.mark.parametrize("mode,world", [("reads", 2), ("kmer-shard", 2), ("reads", 4), ("kmer-shard", 4)])
+def test_bench_with_several_ranks(gpu_available, mode, world):
+    """bench.py as the driver launches it for N = 2 and 4 -- torch.distributed.run, one process per rank, barrier +
+    maximum over ranks, one JSON line from rank 0 -- rehearsed on the one device (EPIK_AMD_BENCH_REHEARSAL=1: all ranks on
     device 0, gloo in place of RCCL, which wants a device per rank)."""
     assert gpu_available
     import json
@@ -60,8 +60,8 @@ def test_bench_with_two_ranks(gpu_available, mode):
     for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_MAX_BLOCKS",
                 "EPIK_AMD_DIST_WORLD1"):
         env.pop(var, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
            "--reads-per-step", "16384", "--mode", mode]
     if mode == "kmer-shard":
         cmd += ["--leaves", "5000"]
@@ -70,12 +70,12 @@ def test_bench_with_two_ranks(gpu_available, mode):
     lines = [x for x in out.stdout.strip().splitlines() if x.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["collectives"] == "gloo"
+    assert line["n_gpus"] == world and line["value"] > 0 and line["config"]["collectives"] == "gloo"
     assert line["scaling"] == ("weak" if mode == "reads" else "strong")
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None  # N = 1 only
-    # the line says by itself that two ranks took part, on which devices, and what each of them measured
+    # the line says by itself how many ranks took part, on which devices, and what each of them measured
     config = line["config"]
-    assert config["world_size"] == 2 and [r["rank"] for r in config["ranks"]] == [0, 1]
+    assert config["world_size"] == world and [r["rank"] for r in config["ranks"]] == list(range(world))
     for r in config["ranks"]:
         assert r["device"] == 0 and r["ms_per_step"] > 0 and r["host"]
         assert r["pci_bus_id"] is None or ":" in r["pci_bus_id"]
