@@ -37,6 +37,14 @@ def main():
     if what == "lint":
         record["lint"] = "lint_ring_asm.py passed on place_kernel.hip, team_kernel.hip, team_stream.hip"
         path = os.path.join(HERE, "lint_passed.json")
+        # (the committed record changes when the compiler or the sources do, not with every run of the test suite)
+        try:
+            with open(path) as fh:
+                last = json.load(fh)
+            if all(last.get(k) == record[k] for k in ("hipcc", "kernel_source_hash", "lint")):
+                return
+        except (OSError, ValueError):
+            pass
     else:
         path = os.path.join(ROOT, "epik_amd", "libepik_amd.build.json")
     with open(path, "w") as fh:
