@@ -142,6 +142,51 @@ def test_generated_isa_keeps_its_hands_off_the_load_ring():
     assert run.stdout.count("ring-asm lint: 0 problem(s)") == 3   # place_kernel.hip, team_kernel.hip, team_stream.hip
 
 
+def test_the_streaming_kernels_keep_their_register_budgets():
+    """The hardware fills a CU by the registers a kernel USES: the lean build of the streaming
+    kernel owes its twenty waves per CU to 96 registers and no scratch, the wide build its three workgroups to at most
+    168 and none, the front kernel its eight waves per SIMD to 64 (six, 85, when it also sizes the partial lists), the one-wavefront kernel its five to 96.  A source
+    or compiler change that breaks one of them costs tens of percent on some tree size without failing anything else."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    listing = {f: os.path.join(root, "gpurun_out", f + ".s") for f in ("place_kernel", "team_stream")}
+    if not all(os.path.exists(v) for v in listing.values()):
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        run = subprocess.run(["make", "-C", os.path.join(root, "epik_amd", "csrc"), "asm"], capture_output=True, text=True)
+        assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+
+    def kernels(path):
+        text = open(path).read()
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+            field = lambda k: int(re.search(r"\.amdhsa_" + k + r"\s+(\d+)", m.group(2)).group(1))
+            yield m.group(1), field("next_free_vgpr"), field("private_segment_fixed_size")
+
+    seen = 0
+    for name, vgpr, scratch in kernels(listing["team_stream"]):
+        m = re.match(r"_ZN8epik_amd18team_stream_kernelILi(\d)E([htj])Li(\d)ELb([01])E", name)
+        if m and m.group(3) == "0":  # the one-pass placement
+            wide, counts = m.group(4) == "1", m.group(2)
+            if wide:
+                assert vgpr <= 168 and (scratch == 0 or counts == "j"), (name, vgpr, scratch)
+            elif counts == "h":
+                assert vgpr <= 96 and scratch == 0, (name, vgpr, scratch)
+            else:
+                assert vgpr <= 128, (name, vgpr, scratch)   # 16- and 32-bit counts: four waves per SIMD at least
+            seen += 1
+        f = re.match(r"_ZN8epik_amd17team_front_kernelILi(\d)ELb([01])E", name)
+        if f and int(f.group(1)) <= 4:  # (eight slices per pass: one workgroup per SIMD asked, what fits runs)
+            assert vgpr <= (85 if f.group(2) == "1" else 64), (name, vgpr)   # six / eight waves per SIMD
+            seen += 1
+    assert seen >= 12
+    n = 0
+    for name, vgpr, _ in kernels(listing["place_kernel"]):
+        if name.startswith("_ZN8epik_amd18place_reads_kernel"):
+            assert vgpr <= 96, (name, vgpr)
+            n += 1
+    assert n >= 6
+
+
 def test_the_ring_lint_sees_a_copy_of_a_register_in_flight(tmp_path):
     """The lint itself: a two-slot ring in the shape hipcc emits passes; the same loop with one compiler-made copy of
     a slot register between its load and its wait is reported -- in the loop, and in the first trip of loads alone
