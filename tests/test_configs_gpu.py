@@ -188,6 +188,30 @@ def test_protein_reads_across_the_underflow_limits(amino_k7, amino_k7_placer, or
     assert_rows_match(*got, *ref)
 
 
+@pytest.mark.parametrize("n_branches", [1983, 1984, 1985, 2047, 2048, 2049, 3499, 3500, 3501, 4095, 4097, 10001, 14999, 19999, 30001, 50001])
+def test_tree_sizes_around_the_kernel_thresholds(gpu_available, oracle_lib, n_branches, monkeypatch):
+    """What create() picks by itself on either side of its thresholds -- one wavefront per read below N = 1 984, two
+    slices per pass up to 3 500, four beyond (db_image.cpp: make_plan, choose_team) -- and around the powers of two
+    where the padded row counts step, and the sizes beyond one pass (two, three and more passes by the rule of
+    choose_team): every one against the oracle."""
+    assert gpu_available
+    from epik_amd.placer import Placer
+    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_RUNS", "EPIK_AMD_WIDE_COUNTS", "EPIK_AMD_TEAM_SPARSE"):
+        monkeypatch.delenv(var, raising=False)
+    db = synth.make_db(n_branches, kmer_size=7, seed=90 + n_branches % 7, p_present=0.6, lognormal=(3.5, 1.7))
+    rng = np.random.default_rng(n_branches)
+    reads = mixed_reads(rng, 600, db.kmer_size, max_len=151)
+    reads += ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(900)]
+    reads += ["".join(rng.choice(list("ACGT"), size=400))]     # one read beyond the 8-bit counts
+    data, offs = synth.pack_reads(reads)
+    ref = oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0)
+    with Placer.from_synth(db) as pl:
+        got = pl.place_packed(data, offs)
+        short = pl.place_packed(*synth.pack_reads(reads[:-1]))   # ... and the same batch without it (8-bit counts)
+    assert_rows_match(*got, *ref)
+    assert_rows_match(*short, *(a[:-1] for a in ref))
+
+
 @pytest.fixture(scope="module")
 def large_tree(gpu_available):
     assert gpu_available
