@@ -7,10 +7,12 @@ A "step" is one pass of the hot path (`epik::placer::place`'s per-read loop,
 reference place.cpp:201-440) over one batch of synthetic reads that is already
 resident in HBM.  Workload = BASELINE.json configs[1]: ~1k-branch nucl DB
 (N=999, k=10, omega=1.5, mu=1.0, SURVEY.md 8d synthetic model), 150 bp reads,
-1M reads per step per GPU.  With N>1 (launched by torch.distributed.run, one rank
-per GPU) the reads are sharded across ranks and the DB is replicated: there is no
-data-path collective (weak scaling); torch.distributed is used for the barriers
-and the max-over-ranks time only.
+1M reads per step per GPU.  With N>1 (one rank per GPU under torch.distributed.run:
+either the caller launches it that way, or -- `python bench.py --gpus N` with no
+WORLD_SIZE in the environment -- this script starts the launcher itself as a child
+process and passes its output and exit code through) the reads are sharded across
+ranks and the DB is replicated: there is no data-path collective (weak scaling);
+torch.distributed is used for the barriers and the max-over-ranks time only.
 
 Rank 0 prints ONE JSON line.  Extra objects (rank 0, N=1 where they cost time):
   roofline              -- achieved algorithmic GB/s of the placement kernel (HIP events on the
@@ -294,8 +296,7 @@ def pci_bus_id(device: int) -> str | None:
 
 def sub_bench(extra_args, timeout=600):
     """Another bench.py line in a process of its own (the k-mer-space shard on this GPU): the parsed JSON, or a note."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
-                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE")}
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
     try:
         run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-seconds", "0", "--no-extras"]
                              + list(extra_args), capture_output=True, text=True, timeout=timeout, env=env)
@@ -328,14 +329,40 @@ def kernel_name(plan, pl, placing: bool = True) -> str:
     return f"team_place_kernel<{w}>"
 
 
+LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                "TORCHELASTIC_RUN_ID")
+
+
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start `python -m torch.distributed.run --nproc-per-node N
+    bench.py <the same arguments>` as a CHILD process -- this process has not touched HIP or torch yet and never will
+    (a process that has initialised the GPU must not exec; a child is always allowed) --, pass the child's output
+    through (rank 0's one JSON line on stdout, the progress lines on stderr) and return its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n_ranks} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch

@@ -41,11 +41,14 @@ def test_the_collectives_run_on_rccl(gpu_available, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
 @pytest.mark.parametrize("mode,world", [("reads", 2), ("kmer-shard", 2), ("reads", 4), ("kmer-shard", 4)])
-def test_bench_with_several_ranks(gpu_available, mode, world):
+def test_bench_with_several_ranks(gpu_available, mode, world, launcher):
     """bench.py as the driver launches it for N = 2 and 4 -- torch.distributed.run, one process per rank, barrier +
     maximum over ranks, one JSON line from rank 0 -- rehearsed on the one device (EPIK_AMD_BENCH_REHEARSAL=1: all ranks on
-    device 0, gloo in place of RCCL, which wants a device per rank)."""
+    device 0, gloo in place of RCCL, which wants a device per rank).  `self`: the command is `python bench.py --gpus N`
+    with NO launcher in it and none in the environment, the shape of the driver's N = 1 command -- bench.py starts
+    torch.distributed.run itself as a child process and passes its one line and exit code through."""
     assert gpu_available
     import json
     import os
@@ -58,11 +61,14 @@ def test_bench_with_several_ranks(gpu_available, mode, world):
         port = s.getsockname()[1]
     env = dict(os.environ, EPIK_AMD_BENCH_REHEARSAL="1", OMP_NUM_THREADS="1")
     for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_MAX_BLOCKS",
-                "EPIK_AMD_DIST_WORLD1"):
+                "EPIK_AMD_DIST_WORLD1", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(var, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--reads-per-step", "16384", "--mode", mode]
+    cmd = [sys.executable]
+    if launcher == "torchrun":
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+            "--reads-per-step", "16384", "--mode", mode]
     if mode == "kmer-shard":
         cmd += ["--leaves", "5000"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)

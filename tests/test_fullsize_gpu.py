@@ -73,3 +73,76 @@ def test_random_sample_matches_the_oracle(full_case, oracle_lib):
     sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
     ref = oracle_lib.Oracle.from_synth(db).place(sample, sample_offs, num_threads=0)
     assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
+
+
+# ---- BASELINE configs[2]: 100 M x 150 bp reads over 8 GPUs, database replicated: ONE GPU's share -------------------
+SHARE_READS = 12_500_000
+
+
+def _check_rows_in_pieces(rows, n_rows, counts, num_branches, piece=1_000_000):
+    """test_rows_are_well_formed's properties, a million reads at a time (12.5 M reads x 7 rows x 16 bytes are 1.4 GB:
+    no full-size temporaries)."""
+    keep = rows.shape[1]
+    for at in range(0, len(n_rows), piece):
+        r, n, c = rows[at:at + piece], n_rows[at:at + piece], counts[at:at + piece]
+        assert n.min() >= 1 and n.max() <= keep
+        valid = np.arange(keep)[None, :] < n[:, None]
+        assert r["branch"][valid].max() < num_branches
+        score = np.where(valid, r["score"], -np.inf)
+        with np.errstate(invalid="ignore"):
+            steps = np.diff(score, axis=1)
+        assert (steps[valid[:, 1:]] <= 0).all(), "scores must be sorted in descending order"
+        lwr = np.where(valid, r["lwr"], 0.0)
+        assert (lwr >= 0).all() and (lwr.sum(axis=1) <= 1.0 + 1e-6).all()
+        assert (lwr[:, :1] >= lwr).all()
+        assert (lwr[valid] >= 0.01 * np.repeat(lwr[:, 0], n) - 1e-15).all(), "filter_by_ratio (place.cpp:188-199)"
+        assert (c[valid] <= 141).all()
+
+
+def test_one_gpus_share_of_configs2(gpu_available, oracle_lib):
+    """12.5 M x 150 bp reads (configs[2] / 8: the OpenMP loop of place.cpp:218-230 over one GPU's share of the
+    hundred million) on the N = 999 database: once in ONE `epik_amd_placer_place_device` call on device-resident reads
+    (what bench.py --gpus 8 does per rank and step at its largest), once through `epik_amd_placer_place` (host
+    buffers in chunks).  Both must give the same bytes; the whole batch goes through the property checks, 4 000
+    reads of it -- drawn over the whole range, the last read included -- through the oracle."""
+    assert gpu_available
+    import torch
+    from epik_amd import capi
+    from epik_amd.placer import Placer
+    tree = synth.make_tree(500, seed=42)
+    db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
+    data, offs = synth.make_reads(SHARE_READS, 150, seed=44 + 3)   # (rank 3's seed in bench.py)
+    n = SHARE_READS
+    with Placer.from_synth(db) as pl:
+        keep = pl.keep_at_most
+        dev = torch.device("cuda", 0)
+        d_seqs = torch.from_numpy(data).to(dev)
+        d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+        d_rows = torch.zeros(n * keep * 2, dtype=torch.float64, device=dev)
+        d_nrows = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_counts = torch.zeros(n * keep, dtype=torch.int32, device=dev)
+        pl.choose_counts(150)
+        stream = torch.cuda.current_stream()
+        pl.place_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, d_rows.data_ptr(), d_nrows.data_ptr(), d_counts.data_ptr(),
+                        stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert pl.last_path() == capi.PATH_WAVE
+        rows = d_rows.cpu().numpy().view(capi.PLACEMENT).reshape(n, keep)
+        n_rows = d_nrows.cpu().numpy().view(np.uint32)
+        counts = d_counts.cpu().numpy().view(np.uint32).reshape(n, keep)
+        del d_rows, d_nrows, d_counts, d_seqs, d_offs
+        torch.cuda.empty_cache()
+        _check_rows_in_pieces(rows, n_rows, counts, db.num_branches)
+        # the same reads through the host entry point: pageable buffers in, rows out, chunked by the library
+        h_rows, h_n, h_counts = pl.place_packed(data, offs)
+    assert h_n.tobytes() == n_rows.tobytes()
+    valid = np.arange(keep)[None, :] < n_rows[:, None]
+    for field in ("branch", "score", "lwr"):
+        assert np.array_equal(h_rows[field][valid].view(np.uint32 if field != "lwr" else np.uint64),
+                              rows[field][valid].view(np.uint32 if field != "lwr" else np.uint64)), field
+    assert np.array_equal(h_counts[valid], counts[valid])
+    del h_rows, h_counts, valid
+    pick = np.unique(np.concatenate([np.random.default_rng(9).choice(n, size=3998, replace=False), [0, n - 1]]))
+    sample, sample_offs = synth.pack_reads([bytes(data[int(offs[i]):int(offs[i + 1])]) for i in pick])
+    ref = oracle_lib.Oracle.from_synth(db).place(sample, sample_offs, num_threads=0)
+    assert_rows_match(rows[pick], n_rows[pick], counts[pick], *ref)
