@@ -163,6 +163,9 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C epik_amd/csrc` (hipcc, gfx950).  epik_amd has no CPU fallback.")
+    if not os.environ.get("EPIK_AMD_LIB"):  # (a library named by hand is the caller's: tools/ablate.py variants)
+        from . import provenance
+        provenance.check_library()  # no record of a passed ISA lint: refused
     lib = ctypes.CDLL(LIB_PATH)
     check_hip_runtime()
     vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int

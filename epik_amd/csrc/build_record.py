@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Records what built the library and what the ISA lint passed on (called by the Makefile).
 
-    build_record.py build   -> epik_amd/libepik_amd.build.json (travels with the .so, git-ignored): hipcc --version and
-                               the hash of the kernel sources the library was built from
+    build_record.py build [suffix] -> epik_amd/libepik_amd<suffix>.build.json (travels with the .so, git-ignored):
+                               hipcc --version, the hash of the kernel sources the library was built from, and that
+                               lint_ring_asm.py passed on the ISA it was linked from (the Makefile links nothing else)
     build_record.py lint    -> epik_amd/csrc/lint_passed.json (committed): the same two facts for the last run of
                                `make asm` in which lint_ring_asm.py accepted the generated ISA of every kernel
 
@@ -46,7 +47,9 @@ def main():
         except (OSError, ValueError):
             pass
     else:
-        path = os.path.join(ROOT, "epik_amd", "libepik_amd.build.json")
+        suffix = sys.argv[2] if len(sys.argv) > 2 else ""
+        record["lint"] = "lint_ring_asm.py passed on the ISA this library was linked from"
+        path = os.path.join(ROOT, "epik_amd", f"libepik_amd{suffix}.build.json")
     with open(path, "w") as fh:
         json.dump(record, fh, indent=1)
         fh.write("\n")

@@ -68,8 +68,11 @@ constexpr uint32_t wave_kernel_resident_waves(uint32_t n_pad, int counts)
 }
 
 // ---- team kernel ---------------------------------------------------------------------------------
-constexpr uint32_t kTeamRing = 8;      // posting-chunk loads in flight per wave (16 measured slower: r02 notes in DESIGN.md)
-constexpr uint32_t kTeamDescCap = 56;  // chunk descriptors per slice and round (a multiple of the ring)
+#ifndef EPIK_AMD_TEAM_RING
+#define EPIK_AMD_TEAM_RING 8
+#endif
+constexpr uint32_t kTeamRing = EPIK_AMD_TEAM_RING;  // posting-chunk loads in flight per wave (16 measured slower: r02 notes in DESIGN.md)
+constexpr uint32_t kTeamDescCap = 64u - kTeamRing;  // chunk descriptors per slice and round (a multiple of the ring; + one trip of spare entries: 64)
 constexpr uint32_t kTeamCandCap = 60;  // top-k candidates of a slice (+ 4 spare entries = the list's 64)
 // bytes of one table entry {u32 line, u16 len[W]}
 constexpr int team_entry_bytes(int waves) { return waves <= 6 ? 16 : waves <= 14 ? 32 : 64; }

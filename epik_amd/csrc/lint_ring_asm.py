@@ -1,22 +1,45 @@
 #!/usr/bin/env python3
 """Lints the generated ISA of the kernels that stream postings (place_kernel.hip, team_kernel.hip,
-team_stream.hip) for the one hazard hipcc cannot see.
+team_stream.hip) for the two hazards hipcc cannot see.
 
-The ring's posting loads are issued from inline asm (uncounted by hipcc's s_waitcnt
-bookkeeping), so a compiler-generated copy of a ring register made while its load is
-still in flight would capture stale data.  Every ring stage is, in program order,
+1. The ring's posting loads are issued from inline asm, uncounted by hipcc's s_waitcnt bookkeeping, and waited
+   for with hand-counted `s_waitcnt vmcnt(N)`.  A register a load writes is IN FLIGHT from the load until a wait
+   that retires it; any instruction -- compiler-made or asm -- that names a register in flight reads stale data
+   (or has its result overwritten).  The lint runs the hardware's own rule over the kernel's control-flow graph:
+   vector-memory loads return in issue order, so after `s_waitcnt vmcnt(N)` a load is done if at least N loads
+   were issued behind it (stores share the counter but may overtake loads: they are not counted as "behind").
+   Every load in the listing takes part in the counting, the compiler's as well: a compiler-made load that slipped
+   in between the ring's would make a counted wait one too short, and shows here as a ring register read in
+   flight.  Only the registers of asm-issued loads are watched (the compiler waits for its own loads itself: a
+   spill reload in flight across a call is its business, and the callee begins with a full wait).
+   State per program point: {register in flight: loads issued behind its own, at least}; where paths meet, a
+   register is in flight if it is on any of them, with the smallest count; iterated to the fixed point (the ring
+   loop is cyclic, and its body may hold branches: the two arms of the run-coded refill, the tail that leaves
+   padding slots alone).
 
-    asm: s_waitcnt vmcnt(N) ; v_mad / v_mov    wait for slot i and move its values out
-    compiler code                              LDS read-add-write on the moved-out values
-    asm: buffer_load_* -> slot i               refill of the slot
+2. A scalar register written by a vector instruction (v_readlane, v_readfirstlane, a comparison) needs five wait
+   states before a vector-memory instruction may read it as its buffer resource or offset.  The ring's refill in
+   a stage carries no s_nop of its own (Layout::issue<kSettled>): the stage's other instructions lie between.
+   Checked for every buffer load, walking back over EVERY path of the control-flow graph (through the compiler's
+   basic-block labels as well as the local labels of an asm statement).
 
-so a ring register is in flight from the asm load that writes it until an asm VALU
-instruction reads it behind a wait; a compiler-generated instruction that names a register
-in flight fails the lint.
 Usage: lint_ring_asm.py place_kernel.s
 """
 import re
 import sys
+
+LOAD_PREFIXES = ("buffer_load_", "global_load_", "flat_load_", "scratch_load_")
+INF = 1 << 20
+
+
+def vregs_in(text):
+    """Every vector register named in an operand string."""
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        regs.add(int(m.group(1)))
+    return regs
 
 
 def regs_of(token):
@@ -25,6 +48,15 @@ def regs_of(token):
     if m:
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
     m = re.fullmatch(r"v(\d+)", token)
+    return {int(m.group(1))} if m else set()
+
+
+def sregs_of(token):
+    token = token.strip().rstrip(",")
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", token)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", token)
     return {int(m.group(1))} if m else set()
 
 
@@ -42,200 +74,181 @@ def kernels(lines):
                 name = None
 
 
-def lint_loop(name, body, events, problems):
-    """One ring loop: `events` are its asm statements in program order."""
-    # The ring of a round that starts empty is filled by a first trip of loads alone (no stage, no wait): straight-line
-    # code in front of the loop, in which a slot's registers are in flight from its load on and free before it.
-    k = 0
-    while k < len(events) and events[k][1] == "load":
-        k += 1
-    if 2 <= k < len(events):
-        start = events[0][0]
-        while start > 0 and not body[start].strip().startswith(";;#ASMSTART"):
-            start -= 1
-        _walk(name, body, start, events[k][0] - 1, set(), problems)
-        events = events[k:]
-    ring = set()
-    for e in events:
-        if e[1] == "load":
-            ring |= e[2]
-    waits = [e[0] for e in events if e[1] == "wait"]
-    loads = [e[0] for e in events if e[1] == "load"]
-    if not loads or not waits:
-        return
-    # From the loop's first asm statement to a margin behind its last asm load (the
-    # fall-through into the tail, which still runs before the drain).  Walk it in program
-    # order with a per-register state: a slot register is IN FLIGHT from its asm load until an
-    # asm vector instruction reads it (behind the stage's asm wait); from there to the refill
-    # the compiler may reuse it.  The loop is cyclic, so at its top every slot counts as in flight.
-    lo, hi = max(0, min(waits[0], loads[0]) - 1), loads[-1] + 15  # -1: the ;;#ASMSTART line
-    for back in range(lo, max(lo - 40, -1), -1):  # ... from the loop's label on (the pipelined ring reads LDS before its first asm)
-        if body[back].startswith(".LBB"):
-            lo = back
-            break
-    # Which slots are in flight where the loop is entered again: those its last trip left in flight behind
-    # its last asm load -- all of them for the plain ring, all but the cell of slot 0 for the pipelined one
-    # (its last stage has already waited for slot 0 and turned its cell into addresses).  One silent walk
-    # from "everything in flight" finds that state; the walk that reports starts from it.
-    end = loads[-1] + 1
-    if body[lo].startswith(".LBB"):  # ... to the branch back to the loop's label
-        label = body[lo].split(":")[0]
-        for n in range(loads[-1], min(loads[-1] + 60, len(body))):
-            t = body[n].strip()
-            if t.startswith(("s_cbranch", "s_branch")) and t.split()[-1] == label:
-                end = n
-                break
-    inflight = _walk(name, body, lo, end, set(ring), None)
-    _walk(name, body, lo, hi, inflight, problems)
+class Code:
+    """A kernel body as instructions and labels in program order, with its control-flow edges."""
+
+    def __init__(self, body):
+        self.ins = []       # (line number in body, text)
+        self.in_asm = []    # the instruction stands inside an inline-asm statement
+        self.label_at = {}  # label -> index of the instruction behind it
+        pending = []
+        asm = False
+        for n, raw in enumerate(body):
+            t = raw.strip()
+            if t.startswith(";;#ASMSTART"):
+                asm = True
+            elif t.startswith(";;#ASMEND"):
+                asm = False
+            if not t or t.startswith((";", "//")):
+                continue
+            m = re.match(r"([.\w$]+):", t)
+            if m and not t.startswith(("s_", "v_", "ds_", "buffer_", "global_", "flat_", "scratch_")):
+                pending.append(m.group(1))
+                continue
+            if t.startswith("."):
+                continue
+            for label in pending:
+                self.label_at[label] = len(self.ins)
+            pending = []
+            self.ins.append((n, t))
+            self.in_asm.append(asm)
+        for label in pending:  # (labels behind the last instruction)
+            self.label_at[label] = len(self.ins)
+        self.succ = [[] for _ in self.ins]
+        for k, (_, t) in enumerate(self.ins):
+            w = t.split()
+            op = w[0]
+            if op == "s_branch":
+                if w[1] in self.label_at:
+                    self.succ[k].append(self.label_at[w[1]])
+                continue
+            if op.startswith("s_cbranch") and w[-1] in self.label_at:
+                self.succ[k].append(self.label_at[w[-1]])
+            if op in ("s_endpgm", "s_setpc_b64"):
+                continue
+            if k + 1 < len(self.ins):
+                self.succ[k].append(k + 1)
+        self.pred = [[] for _ in self.ins]
+        for k, out in enumerate(self.succ):
+            for s in out:
+                if s < len(self.ins):
+                    self.pred[s].append(k)
 
 
-def _walk(name, body, lo, hi, inflight, problems):
-    inflight = set(inflight)
-    in_asm = False
-    skip_to = None  # behind an unconditional branch forwards: the walk goes on at its target (what lies between is
-                    # reached from elsewhere -- the path that skipped the loop, on which nothing is in flight)
-    for n in range(lo, min(hi, len(body) - 1) + 1):
-        s = body[n].strip()
-        if skip_to is not None:
-            if s.startswith(skip_to + ":"):
-                skip_to = None
-            continue
-        if not in_asm and s.startswith("s_branch "):
-            target = s.split()[1]
-            if any(body[m].strip().startswith(target + ":") for m in range(n + 1, min(n + 80, len(body)))):
-                skip_to = target  # (the target may lie behind `hi`: then the walk ends inside the skipped block)
-            continue
-        if s.startswith(";;#ASMSTART"):
-            in_asm = True
-            continue
-        if s.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        if not s or s.startswith((";", ".")):
-            continue
-        parts = s.split(None, 1)
-        operands = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
-        if in_asm:
-            if s.startswith(("buffer_load_", "global_load_")):
-                inflight |= regs_of(operands[0])
-            elif s.startswith("v_") and len(operands) >= 2:
-                # consumed (v_mov / v_mad) behind the wait of this same asm statement
-                for o in operands[1:]:
-                    inflight -= regs_of(o)
-            continue
-        touched = set()
-        for o in operands:
-            if o:
-                touched |= regs_of(o.split()[0])
-        # `v_mov vX, <constant>` is how hipcc initialises the empty ring on the path that skips
-        # the loop (laid out behind it): it reads no register, and nothing is in flight there
-        if parts[0].startswith("v_mov_b32") and len(operands) == 2 and not regs_of(operands[1]) \
-                and not operands[1].startswith(("s", "v")):
-            continue
-        if touched & inflight and problems is not None:
-            problems.append(f"{name}: line {n}: compiler code touches an in-flight ring register: {s}")
-    return inflight
+def operands_of(text):
+    parts = text.split(None, 1)
+    return parts[0], (parts[1] if len(parts) > 1 else "")
 
 
-def sregs_of(token):
-    token = token.strip().rstrip(",")
-    m = re.fullmatch(r"s\[(\d+):(\d+)\]", token)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"s(\d+)", token)
-    return {int(m.group(1))} if m else set()
+def is_load(op, rest):
+    if op.startswith(LOAD_PREFIXES):
+        return True
+    # an atomic that returns its old value comes back through the same counter, in load order
+    return "_atomic_" in op and (" glc" in rest or " sc0" in rest)
+
+
+def lint_in_flight(name, body, problems):
+    """Hazard 1: no instruction names a register whose load has not been waited for."""
+    code = Code(body)
+    n = len(code.ins)
+    if n == 0:
+        return 0
+    state_in = [None] * n   # None: not reached yet; else {reg: loads issued behind it}
+    state_in[0] = {}
+    work = [0]
+    reported = {}
+    loads_seen = 0
+
+    def step(k, state, report):
+        line, t = code.ins[k]
+        op, rest = operands_of(t)
+        out = state
+        if op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", rest)
+            if m:
+                keep = int(m.group(1))
+                out = {r: c for r, c in state.items() if c < keep}
+            return out
+        named = vregs_in(rest)
+        hit = named & state.keys() if state else set()
+        if hit and report:
+            reported.setdefault(line, f"{name}: line {line}: `{t}` names v{sorted(hit)[0]} while its load is in flight "
+                                      f"({state[sorted(hit)[0]]} load(s) issued behind it, no wait has retired it)")
+        if op == "s_swappc_b64" and state and report:
+            reported.setdefault(line, f"{name}: line {line}: a call with {len(state)} register(s) of the ring in flight")
+        if is_load(op, rest):
+            dst = regs_of(rest.split(",")[0])
+            out = {r: min(c + 1, INF) for r, c in state.items() if r not in dst}
+            if code.in_asm[k]:  # (a compiler-made load into a register: the register is the compiler's from here on)
+                for r in dst:
+                    out[r] = 0
+        return out
+
+    while work:
+        k = work.pop()
+        state = state_in[k]
+        out = step(k, state, False)
+        for s in code.succ[k]:
+            if s >= n:
+                continue
+            old = state_in[s]
+            if old is None:
+                new = dict(out)
+            else:
+                new = dict(old)
+                for r, c in out.items():
+                    new[r] = min(c, old[r]) if r in old else c
+            if new != old:
+                state_in[s] = new
+                work.append(s)
+    for k in range(n):
+        if state_in[k] is not None:
+            step(k, state_in[k], True)
+            op, rest = operands_of(code.ins[k][1])
+            if op.startswith("buffer_load_"):
+                loads_seen += 1
+    problems.extend(reported[line] for line in sorted(reported))
+    return loads_seen
 
 
 def lint_settled(name, body, problems):
-    """A scalar register written by a vector instruction (v_readlane, v_readfirstlane, a comparison) needs five
-    wait states before a vector-memory instruction may read it as its buffer resource or offset.  The ring's
-    refill in a stage carries no s_nop of its own (Layout::issue<kSettled>): the stage's other instructions lie
-    between.  Checked here for every buffer load: walking back over every path through straight-line code and
-    the local labels of an asm statement (the two arms of the run-coded refill), no such write to one of its
-    scalar operands within the last five wait states (s_nop N counts N + 1).  A basic-block label of the
-    compiler's ends the walk: the first instructions behind one are not checked against what precedes them on
-    other paths -- which is why the ring's first trip, straight from the lanes, keeps its s_nop 4."""
-    code = []  # the instructions in program order: (line number, text); labels as (line number, "LABEL", name)
-    for n, l in enumerate(body):
-        t = l.strip()
-        if not t or t.startswith((";", "//")):
-            continue
-        m = re.match(r"(\.L\w+):", t)
-        if m:
-            code.append((n, "LABEL", m.group(1)))
-            continue
-        if t.startswith("."):
-            continue
-        code.append((n, t, None))
+    """Hazard 2: five wait states between a vector instruction that writes a scalar register and a buffer load that
+    reads it (s_nop N counts N + 1), over every path that leads to the load."""
+    code = Code(body)
 
-    def walk(back, states, reads, load_line, load_text):
-        while back >= 0 and states < 5:
-            n, u, label = code[back]
-            if u == "LABEL":
-                if label.startswith(".LBB"):
-                    return
-                # a label inside an asm statement: from the branches to it, and from above unless an
-                # unconditional branch stands there
-                for src in range(back - 1, max(back - 40, -1), -1):
-                    w = code[src][1].split()
-                    if w and w[0].startswith(("s_cbranch", "s_branch")) and w[-1] == label:
-                        walk(src, states, reads, load_line, load_text)
-                if back > 0 and code[back - 1][1].startswith("s_branch "):
-                    return
-                back -= 1
-                continue
-            w = u.split(None, 1)
-            if w[0].startswith(("v_readlane_b32", "v_readfirstlane_b32")) or (w[0].startswith("v_cmp") and "_e64" in w[0]):
-                dst = sregs_of(w[1].split(",")[0]) if len(w) > 1 else set()
-                if dst & reads:
-                    problems.append(f"{name}: line {load_line}: {load_text.split()[0]} reads s{sorted(dst & reads)[0]} "
-                                    f"{states} wait state(s) behind `{u}` (needs 5)")
-                    return
-            states += int(w[1]) + 1 if w[0] == "s_nop" and len(w) > 1 and w[1].strip().isdigit() else 1
-            back -= 1
+    def writes_sgpr_from_valu(op):
+        return op.startswith(("v_readlane_b32", "v_readfirstlane_b32")) or (op.startswith("v_cmp") and "_e64" in op)
 
-    for k, (n, t, _) in enumerate(code):
-        if not t.startswith("buffer_load_"):
+    for k, (line, t) in enumerate(code.ins):
+        op, rest = operands_of(t)
+        if not op.startswith("buffer_load_"):
             continue
-        ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
         reads = set()
-        for o in ops[1:]:
-            reads |= sregs_of(o.split()[0])
-        before = len(problems)
-        walk(k - 1, 0, reads, n, t)
-        del problems[before + 1:]  # (one report per load)
+        for o in rest.split(",")[1:]:
+            o = o.strip()
+            if o:
+                reads |= sregs_of(o.split()[0])
+        found = None
+        seen = set()
+        stack = [(p, 0) for p in code.pred[k]]
+        while stack and found is None:
+            at, states = stack.pop()
+            if states >= 5 or (at, states) in seen:
+                continue
+            seen.add((at, states))
+            u_op, u_rest = operands_of(code.ins[at][1])
+            if writes_sgpr_from_valu(u_op):
+                dst = sregs_of(u_rest.split(",")[0]) if u_rest else set()
+                if dst & reads:
+                    found = (sorted(dst & reads)[0], states, code.ins[at][1])
+                    break
+            cost = int(u_rest) + 1 if u_op == "s_nop" and u_rest.strip().isdigit() else 1
+            for p in code.pred[at]:
+                stack.append((p, states + cost))
+        if found:
+            problems.append(f"{name}: line {line}: {op} reads s{found[0]} {found[1]} wait state(s) behind `{found[2]}` (needs 5)")
 
 
 def lint(path):
     problems = []
     linted = 0
     for name, body in kernels(open(path).read().split("\n")):
-        lint_settled(name, body, problems)
-        # asm statements in program order: (line, kind, regs), kind in {"wait", "drain", "load"}
-        events, in_asm = [], False
-        for n, l in enumerate(body):
-            s = l.strip()
-            if s.startswith(";;#ASMSTART"):
-                in_asm = True
-            elif s.startswith(";;#ASMEND"):
-                in_asm = False
-            elif in_asm and s.startswith(("buffer_load_", "global_load_")):
-                events.append((n, "load", regs_of(s.split()[1])))
-            elif in_asm and s.startswith("s_waitcnt vmcnt("):
-                events.append((n, "drain" if "vmcnt(0)" in s else "wait", set()))
-        if not any(e[1] == "load" for e in events):
+        has_ring = any(re.match(r"\s*buffer_load_", l) for l in body)
+        if not has_ring:
             continue  # a kernel without a stream (the finish halves of a sharded placement)
         linted += 1
-        # the kernel may hold several copies of the ring loop (first pass / further passes):
-        # each ends with its tail's `s_waitcnt vmcnt(0)`
-        group = []
-        for e in events:
-            if e[1] == "drain":
-                lint_loop(name, body, group, problems)
-                group = []
-            else:
-                group.append(e)
-        lint_loop(name, body, group, problems)
+        lint_settled(name, body, problems)
+        lint_in_flight(name, body, problems)
     if linted == 0:
         problems.append(f"{path}: no kernel with asm ring loads found")
     return problems

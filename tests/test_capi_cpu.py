@@ -139,7 +139,8 @@ def test_generated_isa_keeps_its_hands_off_the_load_ring():
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     run = subprocess.run(["make", "-C", os.path.join(root, "epik_amd", "csrc"), "asm"], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
-    assert run.stdout.count("ring-asm lint: 0 problem(s)") == 3   # place_kernel.hip, team_kernel.hip, team_stream.hip
+    # place_kernel.hip, team_kernel.hip, team_stream.hip (more lines when the library had to be rebuilt: its own rule lints too)
+    assert run.stdout.count("ring-asm lint: 0 problem(s)") >= 3 and "problem(s)" not in run.stdout.replace("0 problem(s)", "")
 
 
 def test_the_streaming_kernels_keep_their_register_budgets():
@@ -187,51 +188,88 @@ def test_the_streaming_kernels_keep_their_register_budgets():
     assert n >= 6
 
 
-def test_the_ring_lint_sees_a_copy_of_a_register_in_flight(tmp_path):
-    """The lint itself: a two-slot ring in the shape hipcc emits passes; the same loop with one compiler-made copy of
-    a slot register between its load and its wait is reported -- in the loop, and in the first trip of loads alone
-    that fills an empty ring."""
+def _load_lint():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("lint_ring_asm", os.path.join(root, "epik_amd", "csrc", "lint_ring_asm.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
+    return lint
 
-    def issue(score, cell):
-        return ["\t;;#ASMSTART", "\ts_nop 4", f"\tbuffer_load_dword v{score}, v1, s[4:7], 0 offen",
-                f"\tbuffer_load_ushort v{cell}, v2, s[4:7], s3 offen", "\t;;#ASMEND"]
 
-    def consume(cell, out, count):
-        return ["\t;;#ASMSTART", f"\ts_waitcnt vmcnt({count})", f"\tv_mad_i32_i24 v{out}, v{cell}, -4, s1", "\t;;#ASMEND"]
+def _issue(score, cell):
+    return ["\t;;#ASMSTART", "\ts_nop 4", f"\tbuffer_load_dword v{score}, v1, s[4:7], 0 offen",
+            f"\tbuffer_load_ushort v{cell}, v2, s[4:7], s3 offen", "\t;;#ASMEND"]
 
-    def kernel(in_first_trip="", in_loop=""):
-        lines = ["_ZN8epik_amd18place_reads_kernelIcEEvNS_11PlaceParamsE:", "\ts_load_dwordx2 s[0:1], s[4:5], 0x0"]
-        lines += issue(6, 4) + ([in_first_trip] if in_first_trip else []) + issue(7, 5)      # the first trip: loads alone
-        lines += consume(4, 10, 2) + [".LBB0_1:"]
-        lines += ["\tds_read_b32 v12, v10"] + consume(5, 11, 2)
-        lines += ["\tds_write_b32 v10, v12"] + issue(6, 4) + ([in_loop] if in_loop else [])
-        lines += ["\tds_read_b32 v12, v11"] + consume(4, 10, 2)
-        lines += ["\tds_write_b32 v11, v12"] + issue(7, 5) + ["\ts_cbranch_scc1 .LBB0_1"]
-        lines += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(0)", "\tv_mad_i32_i24 v11, v5, -4, s1", "\t;;#ASMEND", "\ts_endpgm"]
-        path = tmp_path / "k.s"
-        path.write_text("\n".join(lines) + "\n")
+
+def _consume(cell, out, count):
+    return ["\t;;#ASMSTART", f"\ts_waitcnt vmcnt({count})", f"\tv_mad_i32_i24 v{out}, v{cell}, -4, s1", "\t;;#ASMEND"]
+
+
+def _ring_kernel(tmp_path, lint, in_first_trip="", in_loop="", loop_wait=0, in_arm=""):
+    """A two-slot ring in the shape hipcc emits: a first trip of loads alone, slot 0 waited for, then the loop -- a
+    stage per slot: LDS read, wait for the OTHER slot (this one is out and not yet refilled: nothing else in flight,
+    vmcnt(0)), LDS write, refill.  Stage 0's write sits in a branch of its own (two paths through the loop)."""
+    lines = ["_ZN8epik_amd18place_reads_kernelIcEEvNS_11PlaceParamsE:", "\ts_load_dwordx2 s[0:1], s[4:5], 0x0"]
+    lines += _issue(6, 4) + ([in_first_trip] if in_first_trip else []) + _issue(7, 5)   # the first trip: loads alone
+    lines += _consume(4, 10, 2) + [".LBB0_1:"]
+    lines += ["\tds_read_b32 v12, v10"] + _consume(5, 11, loop_wait)
+    lines += ["\ts_cbranch_scc1 .LBB0_2", "\tds_write_b32 v10, v12"] + ([in_arm] if in_arm else []) + [".LBB0_2:"]
+    lines += _issue(6, 4) + ([in_loop] if in_loop else [])
+    lines += ["\tds_read_b32 v12, v11"] + _consume(4, 10, loop_wait)
+    lines += ["\tds_write_b32 v11, v12"] + _issue(7, 5) + ["\ts_cbranch_scc1 .LBB0_1"]
+    lines += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(0)", "\tv_mad_i32_i24 v11, v5, -4, s1", "\t;;#ASMEND", "\tv_mov_b32_e32 v30, v6", "\ts_endpgm"]
+    path = tmp_path / "k.s"
+    path.write_text("\n".join(lines) + "\n")
+    return lint.lint(str(path))
+
+
+def test_the_ring_lint_sees_a_copy_of_a_register_in_flight(tmp_path):
+    """The lint itself (hazard 1, the hardware's rule over the control-flow graph): the ring passes; the same loop with
+    one compiler-made copy of a slot register between its load and the wait that retires it is reported -- in the
+    loop, in one arm of a branch inside it, and in the first trip of loads alone that fills an empty ring."""
+    lint = _load_lint()
+    assert _ring_kernel(tmp_path, lint) == []
+    assert len(_ring_kernel(tmp_path, lint, in_loop="\tv_mov_b32_e32 v20, v4")) == 1         # slot 0 was refilled a moment ago
+    assert len(_ring_kernel(tmp_path, lint, in_first_trip="\tv_mov_b32_e32 v20, v6")) == 1    # slot 0's score: its load has just been issued
+    assert _ring_kernel(tmp_path, lint, in_first_trip="\tv_mov_b32_e32 v20, v7") == []        # slot 1's registers are still free there
+    # (one arm of the branch inside the loop: slot 0 is out there and not yet refilled -- free; slot 1 has been waited for)
+    assert _ring_kernel(tmp_path, lint, in_arm="\tv_mov_b32_e32 v20, v4") == []
+    assert _ring_kernel(tmp_path, lint, in_arm="\tv_mov_b32_e32 v20, v5") == []
+
+
+def test_the_ring_lint_checks_the_counted_waits_themselves(tmp_path):
+    """A wait that counts one load too many leaves the slot it was meant for in flight: the asm instruction behind it
+    that reads the slot is reported.  So is the same correct count when a load the ring did not issue -- a
+    compiler-made one -- has slipped in behind the slot's: vmcnt(N) then retires one load fewer of the ring's."""
+    lint = _load_lint()
+    too_long = _ring_kernel(tmp_path, lint, loop_wait=2)     # vmcnt(2) with two loads in flight waits for nothing
+    assert too_long and all("v_mad_i32_i24" in p for p in too_long)
+    # a compiler load between slot 0's refill and the next wait: the wait's count no longer covers slot 1 ... it does
+    # (vmcnt(0) drains everything); with counted waits that leave loads in flight it would not:
+    lines = ["_ZN8epik_amd18place_reads_kernelIcEEvNS_11PlaceParamsE:"]
+    lines += _issue(6, 4) + _issue(7, 5) + _consume(4, 10, 2)                 # slot 0 is retired: two loads behind its cell
+    ok = lines + ["\ts_endpgm"]
+    slipped = lines[:1] + _issue(6, 4) + ["\tglobal_load_dword v40, v[2:3], off"] + _issue(7, 5)
+    slipped += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(3)", "\tv_mad_i32_i24 v10, v4, -4, s1", "\t;;#ASMEND", "\ts_endpgm"]   # right again: three behind
+    short = lines[:1] + _issue(6, 4) + _issue(7, 5) + ["\tglobal_load_dword v40, v[2:3], off"]
+    short += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(3)", "\tv_mad_i32_i24 v10, v4, -4, s1", "\t;;#ASMEND", "\ts_endpgm"]   # three behind: retired
+    stale = lines[:1] + _issue(6, 4) + _issue(7, 5)
+    stale += ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(3)", "\tv_mad_i32_i24 v10, v4, -4, s1", "\t;;#ASMEND", "\ts_endpgm"]   # only two behind: in flight
+
+    def run(body):
+        path = tmp_path / "q.s"
+        path.write_text("\n".join(body) + "\n")
         return lint.lint(str(path))
-
-    assert kernel() == []
-    assert len(kernel(in_loop="\tv_mov_b32_e32 v20, v4")) == 1          # slot 0 was refilled a moment ago
-    assert len(kernel(in_first_trip="\tv_mov_b32_e32 v20, v6")) == 1     # slot 0's score: its load has just been issued
-    assert kernel(in_first_trip="\tv_mov_b32_e32 v20, v7") == []         # slot 1's registers are still free there
+    assert run(ok) == [] and run(slipped) == [] and run(short) == []
+    assert len(run(stale)) == 1
 
 
 def test_the_ring_lint_counts_the_wait_states_in_front_of_a_refill(tmp_path):
     """A refill without its s_nop 4 (the stages of the ring: Layout::issue<kSettled>) must lie five wait states
-    behind the v_readlane that made its buffer resource -- in straight-line code and through the local labels of the
-    run-coded refill's two arms."""
-    import importlib.util
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("lint_ring_asm", os.path.join(root, "epik_amd", "csrc", "lint_ring_asm.py"))
-    lint = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(lint)
+    behind the v_readlane that made its buffer resource -- in straight-line code, through the local labels of the
+    run-coded refill's two arms, and through a basic-block label of the compiler's (over every path that reaches it)."""
+    lint = _load_lint()
 
     def problems(between, load):
         lines = ["_ZN8epik_amd18place_reads_kernelIcEEvNS_11PlaceParamsE:", "\ts_load_dwordx2 s[0:1], s[4:5], 0x0",
@@ -252,6 +290,12 @@ def test_the_ring_lint_counts_the_wait_states_in_front_of_a_refill(tmp_path):
             "\tbuffer_load_dword v6, v1, s[4:7], 0 offen", ".Lissued7:"]
     assert len(problems(filler[:2], arms)) == 2      # both arms four wait states behind the v_readlane
     assert problems(filler[:3], arms) == []
+    # a basic-block label of the compiler's between the v_readlane and the load: the load is checked against what
+    # precedes the label on every path -- the fall-through and the branch that jumps to it
+    assert len(problems(filler[:2] + [".LBB0_9:"], plain)) == 2     # (both loads of the chunk)
+    assert problems(filler + [".LBB0_9:", "\ts_nop 0"], plain) == []
+    jump = ["\ts_cbranch_scc1 .LBB0_9"] + filler + ["\ts_nop 0", ".LBB0_9:"]   # the fall-through is long enough, the jump is not
+    assert len(problems(jump, plain)) == 2
 
 
 def test_release_scratch_rejects_null():
@@ -290,6 +334,41 @@ def test_two_hip_runtimes_are_named_not_left_to_fail_later():
         assert out.returncode == 0, out.stderr[-2000:]
     else:
         assert "REFUSED" in out.stdout and "two HIP runtimes" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def test_a_library_without_a_passed_lint_is_refused(tmp_path):
+    """capi.load() and smoke() refuse a library whose build record does not carry the ISA lint's mark (built by hand, or
+    by something other than the Makefile's lint-then-link rule), and smoke() also one older than the sources."""
+    import json
+    import subprocess
+    import sys
+    from epik_amd import provenance
+    record = os.path.join(ROOT, "epik_amd", "libepik_amd.build.json")
+    good = open(record).read()
+    assert provenance.summary()["lint_covers_this_build"]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from epik_amd import capi\n"
+            "capi.load()\nprint('LOADED')\n" % ROOT)
+    try:
+        doc = json.loads(good)
+        doc.pop("lint")
+        with open(record, "w") as fh:
+            json.dump(doc, fh)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "no record of a passed ISA lint" in out.stderr and "LOADED" not in out.stdout
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, EPIK_AMD_ALLOW_UNLINTED="1"))
+        assert "LOADED" in out.stdout
+        doc = json.loads(good)
+        doc["kernel_source_hash"] = "0" * 16   # a library older than the tree's sources
+        with open(record, "w") as fh:
+            json.dump(doc, fh)
+        with pytest.raises(ImportError, match="rebuild it"):
+            provenance.check_library(strict_sources=True)
+        provenance.check_library()   # (the plain load does not mind: the CPU suite runs while sources are being edited)
+    finally:
+        with open(record, "w") as fh:
+            fh.write(good)
 
 
 def test_build_record_names_the_compiler_and_the_sources():
