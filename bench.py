@@ -33,6 +33,9 @@ Rank 0 prints ONE JSON line.  Extra objects (rank 0, N=1 where they cost time):
   e2e                   -- FASTA in -> jplace closed through the native driver epik-dna, the
                            reference's own "Placement time" quantity (main.cpp:322,378-381), on the step's
                            million reads, timed in microseconds;
+  host_entry            -- the boundary's own rate: reads/s through `epik_amd_placer_place` (pageable host buffers in,
+                           rows out, synchronous: what a drop-in placer::place calls, place.h:103) on the step's
+                           reads, and under `large_tree` on the N = 9 999 tree; the box's raw pageable copy rates beside it;
   roofline_large_tree, roofline_large_tree_clades
                         -- the tree of BASELINE configs[4] (N = 9 999) placed in one pass by the front / streaming /
                            merge kernels, three steps: SURVEY 8d's random lists, and lists over the clades of
@@ -232,6 +235,11 @@ def end_to_end(db, tree, data, read_length: int, n_reads: int, jobs: int):
         stages = dict(re.findall(r"stage (read|place|write) ([0-9.]+) ms", run.stdout))
         if stages:
             result["stage_busy_ms"] = {k: float(v) for k, v in stages.items()}
+            if float(stages.get("write", 0)) > 0:
+                result["writer_gbps"] = os.path.getsize(jplace) / (float(stages["write"]) * 1e-3) / 1e9
+        # (one writer formats and writes the jplace of every device's batches: FASTA -> jplace does not scale with
+        # devices, the device-resident rate does -- DESIGN.md 4)
+        result["scales_with_devices"] = False
         result["cpu_baseline"] = end_to_end_cpu(db, tree, tmp, fasta, n_reads, jobs)
         return result
     except (OSError, subprocess.SubprocessError) as e:
@@ -268,6 +276,53 @@ def end_to_end_cpu(db, tree, tmp, fasta, n_reads: int, threads: int):
                           "thread as main.cpp:332-361"}
     except (OSError, subprocess.SubprocessError) as e:
         return {"value": None, "note": repr(e)[:300]}
+
+
+def host_entry(pl, data, offs, n: int, reps: int = 3):
+    """The boundary's own rate: `epik_amd_placer_place` -- what a drop-in for placer::place (place.h:103: host records
+    in, placed_collection out) calls -- with PAGEABLE host buffers in and out, synchronous: copy in, kernels, copy out,
+    pipelined in chunks by the library.  Best of `reps` calls after one warm-up; the raw pageable copy rates of this
+    box beside it (one torch copy each way of the same buffers)."""
+    import ctypes
+    import torch
+    from epik_amd import capi
+    keep = pl.keep_at_most
+    rows = np.ones((n, keep), dtype=capi.PLACEMENT)   # ones: the pages exist before the timing starts
+    n_rows = np.ones(n, dtype=np.uint32)
+    counts = np.ones((n, keep), dtype=np.uint32)
+    seqs = np.ascontiguousarray(data[:int(offs[n])])
+    seq_offs = np.ascontiguousarray(offs[:n + 1], dtype=np.uint64)
+
+    def call():
+        capi.check(pl._lib.epik_amd_placer_place(pl._handle, seqs.ctypes.data, seq_offs.ctypes.data, n, rows.ctypes.data,
+                                                 n_rows.ctypes.data, counts.ctypes.data))
+    call()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        call()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    bytes_in, bytes_out = seqs.nbytes + seq_offs.nbytes, rows.nbytes + n_rows.nbytes + counts.nbytes
+    dev = torch.device("cuda", pl.device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d = torch.from_numpy(seqs).to(dev)
+    torch.cuda.synchronize()
+    h2d = seqs.nbytes / (time.perf_counter() - t0) / 1e9
+    d_rows = torch.empty(rows.nbytes, dtype=torch.uint8, device=dev)
+    back = torch.from_numpy(rows.view(np.uint8).reshape(-1))   # (pages that exist: the copy alone is timed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    back.copy_(d_rows)
+    torch.cuda.synchronize()
+    d2h = rows.nbytes / (time.perf_counter() - t0) / 1e9
+    del d, d_rows, back
+    return {"entry_point": "epik_amd_placer_place (pageable host buffers in, rows out, synchronous)", "reads": n,
+            "reads_per_s": n / best, "ms": best * 1e3, "ms_all": [t * 1e3 for t in times],
+            "bytes_in": bytes_in, "bytes_out": bytes_out, "moved_gbps": (bytes_in + bytes_out) / best / 1e9,
+            "pageable_h2d_gbps": h2d, "pageable_d2h_gbps": d2h,
+            "rows_checksum": int(n_rows.astype(np.int64).sum())}
 
 
 def pci_bus_id(device: int) -> str | None:
@@ -702,9 +757,13 @@ def main():
             # lint of the streaming loop passed on both (epik_amd/provenance.py)
             "build": provenance.summary(),
         }
+    extras = rank == 0 and world == 1 and not kmer_shard
+    if extras and not args.no_extras:
+        # ---- the boundary's own rate (PCIe-inclusive), beside the device-resident `value` and the FASTA -> jplace `e2e`
+        log("host entry point (epik_amd_placer_place) ...")
+        result["host_entry"] = {"workload": workload, **host_entry(placer, data, offs, n)}
     placer.close()
 
-    extras = rank == 0 and world == 1 and not kmer_shard
     if extras and not args.no_extras and args.states == "nucl" and args.kmer_size < 11:
         # ---- the same kernel on a database the Infinity Cache cannot hold (SURVEY.md 8d sized the
         # workload to be HBM-bound; the packed layout moved the headline database just under 256 MiB)
@@ -734,6 +793,8 @@ def main():
         # ---- the weakest product paths, in the driver's record: the large tree of configs[4] placed
         # in one pass on this GPU -- SURVEY.md 8d's random lists, and lists over the clades of references -- and the
         # two halves of its k-mer-space-sharded placement.  Three steps each.
+        host_reads = (data, offs)   # (the step's reads on the host: what the host entry point is handed)
+
         def large_tree(clades):
             big_tree = synth.make_tree(5000, seed=42)
             seqs, offs = d_seqs, d_offs
@@ -756,6 +817,8 @@ def main():
                     pl.place_device(seqs.data_ptr(), offs.data_ptr(), n, d_rows.data_ptr(), d_nrows.data_ptr(), 0, stream.cuda_stream)
                 _, ms = timed_steps(one, 3, 1)
                 roof = roofline_of(pl, big_plan, ms, name, seqs, offs)
+                if not clades:
+                    result.setdefault("host_entry", {})["large_tree"] = {"workload": name, **host_entry(pl, host_reads[0], host_reads[1], n)}
             keep_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_read", "valu_busy")
             out = {k: roof[k] for k in keep_keys if k in roof}
             out["reads_per_s"] = n / (ms * 1e-3)

@@ -30,6 +30,7 @@ EXPORTS = (
     "epik_amd_last_error",
     "epik_amd_placer_create",
     "epik_amd_placer_plan",
+    "epik_amd_placer_plan_sizes",
     "epik_amd_placer_build_image",
     "epik_amd_placer_destroy",
     "epik_amd_placer_place",
@@ -71,7 +72,7 @@ class PlacerDesc(ctypes.Structure):
         ("values", ctypes.c_void_p),
         ("char_class", ctypes.c_void_p),
         ("device", ctypes.c_int32),
-        ("reserved", ctypes.c_uint32),
+        ("shard", ctypes.c_uint32),
         ("keys", ctypes.c_void_p),
         ("num_present", ctypes.c_uint64),
     ]
@@ -92,8 +93,14 @@ class Plan(ctypes.Structure):
         ("posting_bytes", ctypes.c_uint64),
         ("kept_entries", ctypes.c_uint64),
         ("run_coded", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("posting_bytes_is_bound", ctypes.c_uint32),
     ]
+
+
+class ListBin(ctypes.Structure):
+    """`epik_amd_list_bin`."""
+
+    _fields_ = [("length", ctypes.c_uint64), ("lists", ctypes.c_uint64), ("lists_in_runs", ctypes.c_uint64)]
 
 
 class PartialInfo(ctypes.Structure):
@@ -198,6 +205,9 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_placer_plan.restype = i32
     lib.epik_amd_placer_plan.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32, u64,
                                          ctypes.POINTER(Plan)]
+    lib.epik_amd_placer_plan_sizes.restype = i32
+    lib.epik_amd_placer_plan_sizes.argtypes = [ctypes.c_uint32] * 4 + [ctypes.POINTER(ListBin), u64, ctypes.c_uint32, ctypes.c_uint32,
+                                               u64, ctypes.POINTER(Plan)]
     lib.epik_amd_placer_build_image.restype = i32
     lib.epik_amd_placer_build_image.argtypes = [ctypes.POINTER(PlacerDesc), ctypes.c_uint32, ctypes.c_uint32, u64,
                                                 vp, vp, vp]

@@ -282,6 +282,7 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
     *out = nullptr;
     std::string err;
     // everything that needs no device first: argument checks, then the lists themselves
+    if (const int rc = image::resolve_shard(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
     if (const int rc = image::validate(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
 
     int n_dev = 0;
@@ -554,6 +555,46 @@ private:
 };
 }  // namespace
 
+static void fill_plan(const epik_amd::image::Plan &plan, epik_amd_plan *out)
+{
+    *out = epik_amd_plan{};
+    out->kernel = plan.layout == epik_amd::DbLayout::kTeam ? 1u : 0u;
+    out->layout = (uint32_t)plan.layout;
+    out->team_waves = (uint32_t)plan.team_waves;
+    out->team_passes = plan.team_passes;
+    out->slice_rows = plan.team_slice_rows;
+    for (int c = 0; c < 3; ++c) out->resident_waves[c] = plan.wave_resident[c];
+    out->table_bytes = plan.table_bytes;
+    out->filter_bytes = plan.filter_bytes;
+    out->posting_bytes = plan.posting_bytes;
+    out->kept_entries = plan.kept_entries;
+    out->run_coded = plan.runs ? 1u : 0u;
+}
+
+int epik_amd_placer_plan_sizes(uint32_t kmer_size, uint32_t alphabet_size, uint32_t num_branches, uint32_t keep_at_most,
+                               const epik_amd_list_bin *bins, uint64_t n_bins, uint32_t shard_index, uint32_t shard_count,
+                               uint64_t free_bytes, epik_amd_plan *out)
+{
+    namespace image = epik_amd::image;
+    if (!out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    try {
+        std::string err;
+        image::SizeDesc z;
+        z.kmer_size = kmer_size, z.alphabet_size = alphabet_size, z.num_branches = num_branches, z.keep_at_most = keep_at_most;
+        z.bins = bins, z.n_bins = n_bins, z.shard_index = shard_index, z.shard_count = shard_count;
+        image::Plan plan;
+        bool bound = false;
+        if (const int rc = image::plan_sizes(z, (size_t)free_bytes, std::getenv("EPIK_AMD_LAYOUT"), std::getenv("EPIK_AMD_KERNEL"), plan, bound, err);
+            rc != EPIK_AMD_OK)
+            return fail(rc, err);
+        fill_plan(plan, out);
+        out->posting_bytes_is_bound = bound ? 1u : 0u;
+        return EPIK_AMD_OK;
+    } catch (const std::exception &e) {
+        return fail(EPIK_AMD_ERR_INVALID, std::string("plan_sizes: ") + e.what());
+    }
+}
+
 int epik_amd_placer_plan(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count,
                          uint64_t free_bytes, epik_amd_plan *out)
 {
@@ -561,24 +602,14 @@ int epik_amd_placer_plan(const epik_amd_placer_desc *d, uint32_t shard_index, ui
     if (!out) return fail(EPIK_AMD_ERR_INVALID, "null argument");
     try {
         std::string err;
+        if (const int rc = image::resolve_shard(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
         if (const int rc = image::validate(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
         image::Plan plan;
         if (const int rc = image::make_plan(image::Source{d, shard_index, shard_count}, (size_t)free_bytes,
                                             std::getenv("EPIK_AMD_LAYOUT"), std::getenv("EPIK_AMD_KERNEL"), plan, err);
             rc != EPIK_AMD_OK)
             return fail(rc, err);
-        *out = epik_amd_plan{};
-        out->kernel = plan.layout == epik_amd::DbLayout::kTeam ? 1u : 0u;
-        out->layout = (uint32_t)plan.layout;
-        out->team_waves = (uint32_t)plan.team_waves;
-        out->team_passes = plan.team_passes;
-        out->slice_rows = plan.team_slice_rows;
-        for (int c = 0; c < 3; ++c) out->resident_waves[c] = plan.wave_resident[c];
-        out->table_bytes = plan.table_bytes;
-        out->filter_bytes = plan.filter_bytes;
-        out->posting_bytes = plan.posting_bytes;
-        out->kept_entries = plan.kept_entries;
-        out->run_coded = plan.runs ? 1u : 0u;
+        fill_plan(plan, out);
         return EPIK_AMD_OK;
     } catch (const std::exception &e) {
         return fail(EPIK_AMD_ERR_INVALID, std::string("plan: ") + e.what());
@@ -591,6 +622,7 @@ int epik_amd_placer_build_image(const epik_amd_placer_desc *d, uint32_t shard_in
     namespace image = epik_amd::image;
     try {
         std::string err;
+        if (const int rc = image::resolve_shard(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
         if (const int rc = image::validate(d, shard_index, shard_count, err); rc != EPIK_AMD_OK) return fail(rc, err);
         image::Plan plan;
         const image::Source src{d, shard_index, shard_count};
@@ -805,7 +837,8 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
         epik_amd::TeamParams tp{};
         tp.base = pp;
         tp.team_table = p->team_table;
-        tp.num_keys = p->num_keys;
+        tp.num_keys = p->plan.table_keys;
+        tp.shard_index = p->plan.shard_index, tp.shard_count = p->plan.shard_count;
         tp.team_paired = p->plan.team_paired ? 1u : 0u;
         tp.passes = p->team_passes;
         tp.slice_rows = p->team_slice_rows;
@@ -1237,7 +1270,8 @@ int epik_amd_placer_algorithmic_bytes(epik_amd_placer *p, const void *d_seqs,
         epik_amd::TeamParams tp{};
         tp.base = pp;
         tp.team_table = p->team_table;
-        tp.num_keys = p->num_keys;
+        tp.num_keys = p->plan.table_keys;
+        tp.shard_index = p->plan.shard_index, tp.shard_count = p->plan.shard_count;
         tp.team_paired = p->plan.team_paired ? 1u : 0u;
         tp.passes = p->team_passes;
         HIP_TRY(epik_amd::launch_team_algorithmic_bytes(tp, p->team_waves, p->d_total, s));

@@ -142,6 +142,22 @@ TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t for
 
 }  // namespace
 
+int resolve_shard(const epik_amd_placer_desc *d, uint32_t &shard_index, uint32_t &shard_count, std::string &err)
+{
+    if (!d || d->shard == 0) return EPIK_AMD_OK;
+    const uint32_t g = d->shard & 0xffffu, count = d->shard >> 16;
+    if (count < 2 || g >= count) {
+        err = "desc.shard must be 0 or g | G << 16 with G >= 2 and g < G";
+        return EPIK_AMD_ERR_INVALID;
+    }
+    if (shard_count > 1 && (shard_count != count || shard_index != g)) {
+        err = "desc.shard says the descriptor holds another shard than the one asked for";
+        return EPIK_AMD_ERR_INVALID;
+    }
+    shard_index = g, shard_count = count;
+    return EPIK_AMD_OK;
+}
+
 int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard_count, std::string &err)
 {
     auto fail = [&](int code, const char *msg) {
@@ -200,6 +216,8 @@ int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard
         if (e < b || e > d->num_entries) return fail(EPIK_AMD_ERR_INVALID, "offsets not monotone");
         if (e - b >= (1ull << 24)) return fail(EPIK_AMD_ERR_INVALID, "posting list of 2^24 entries or more");
         if (e == b) continue;
+        if (d->shard != 0 && (src.sparse() ? d->keys[i] : i) % (d->shard >> 16) != (d->shard & 0xffffu))
+            return fail(EPIK_AMD_ERR_INVALID, "desc.shard names a shard, and the descriptor holds a list of another shard's code");
         if (++list_id == 0) {  // the list counter wrapped (> 4 G non-empty lists): start a new epoch
             std::fill(seen_in.begin(), seen_in.end(), 0u);
             list_id = 1;
@@ -217,37 +235,40 @@ int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard
     return EPIK_AMD_OK;
 }
 
-int make_plan(const Source &src, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
-              std::string &err)
+namespace {
+
+// Which kernel places a read, from the tree alone (+ EPIK_AMD_KERNEL): one wavefront per read while enough of them fit
+// a CU, else the branch range in slices.  Fills plan.n_pad / wave_resident.
+struct KernelDecision {
+    bool team = false;
+    int forced_waves = 0;
+    uint32_t forced_passes = 0;
+};
+int decide_kernel(uint32_t num_branches, const char *forced_kernel, const char *forced_layout, Plan &plan, KernelDecision &k,
+                  std::string &err)
 {
-    const epik_amd_placer_desc *d = src.d;
     auto fail = [&](int code, const char *msg) {
         err = msg;
         return code;
     };
-    plan = Plan{};
-    plan.n_pad = (d->num_branches + 1u + 63u) & ~63u;
+    plan.n_pad = (num_branches + 1u + 63u) & ~63u;
     const bool wave_fits = wave_lds_bytes(plan.n_pad, kCounts32) <= kLdsPerCu;
     for (int c = 0; c < 3; ++c) plan.wave_resident[c] = wave_fits ? wave_kernel_resident_waves(plan.n_pad, c) : 0;
-
-    // ---- kernel: one wavefront per read while enough of them fit a CU, else the branch range in slices ----
     // (measured, round 4 -- choose_team: with two slices per pass the front + streaming + merge kernels win where fewer
     // than 12 waves of the other fit a CU with 16-bit counts, i.e. from 2 048 LDS rows per wave on, N >= 1 984)
-    bool team = !wave_fits || plan.wave_resident[kCounts16] < 12;
-    int forced_waves = 0;
-    uint32_t forced_passes = 0;
+    k.team = !wave_fits || plan.wave_resident[kCounts16] < 12;
     if (forced_kernel && forced_kernel[0]) {
         if (std::strcmp(forced_kernel, "wave") == 0) {
             if (!wave_fits) return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the one-wavefront-per-read kernel");
-            team = false;
+            k.team = false;
         } else if (std::strcmp(forced_kernel, "team") == 0) {
-            team = true;
+            k.team = true;
         } else if (std::strncmp(forced_kernel, "team2", 5) == 0 || std::strncmp(forced_kernel, "team4", 5) == 0 ||
                    std::strncmp(forced_kernel, "team8", 5) == 0) {
-            team = true;  // teamW or teamWxP: W waves, (tests) at least P passes
-            forced_waves = forced_kernel[4] - '0';
-            if (forced_kernel[5] == 'x') forced_passes = (uint32_t)std::strtoul(forced_kernel + 6, nullptr, 10);
-            if (forced_kernel[5] != 0 && (forced_kernel[5] != 'x' || forced_passes == 0 || forced_passes > 64))
+            k.team = true;  // teamW or teamWxP: W waves, (tests) at least P passes
+            k.forced_waves = forced_kernel[4] - '0';
+            if (forced_kernel[5] == 'x') k.forced_passes = (uint32_t)std::strtoul(forced_kernel + 6, nullptr, 10);
+            if (forced_kernel[5] != 0 && (forced_kernel[5] != 'x' || k.forced_passes == 0 || k.forced_passes > 64))
                 return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team2[xP], team4[xP] or team8[xP]");
         } else {
             return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_KERNEL must be wave, team, team2[xP], team4[xP] or team8[xP]");
@@ -257,6 +278,99 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
         std::strcmp(forced_layout, "packed") != 0 && std::strcmp(forced_layout, "paired") != 0 &&
         std::strcmp(forced_layout, "filtered") != 0)
         return fail(EPIK_AMD_ERR_INVALID, "EPIK_AMD_LAYOUT must be compact, packed, paired or filtered");
+    return EPIK_AMD_OK;
+}
+
+// The sliced layout's geometry and its table (the posting region depends on the lists: the callers size it).
+int plan_team_geometry(uint32_t num_branches, uint32_t keep_at_most, uint32_t alphabet_size, uint32_t kmer_size, uint64_t num_keys,
+                       const KernelDecision &k, Plan &plan, std::string &err)
+{
+    const TeamChoice c = choose_team(num_branches, keep_at_most, k.forced_waves, k.forced_passes);
+    if (c.waves == 0) {
+        err = "no team geometry fits this tree";
+        return EPIK_AMD_ERR_UNSUPPORTED;
+    }
+    plan.layout = DbLayout::kTeam;
+    plan.team_waves = c.waves;
+    plan.team_passes = c.passes;
+    plan.team_slice_rows = c.slice_rows;
+    plan.team_rows_pad = c.rows_pad;
+    // A table entry is 16 bytes, a lookup fetches a 128-byte line: with 4 letters the table is keyed, as the
+    // paired layout of the one-wavefront kernels, by the (k-1)-mer X two consecutive k-mers of a read share
+    // -- block X = the entries of a.X (slots 0-3) and X.b (slots 4-7), one line -- so that two lookups
+    // cost one fetch (the front kernel is bound by exactly these fetches).  Every entry is stored twice.
+    // (a shard's table is not paired: of two consecutive k-mers of a read at most one is the shard's as a rule,
+    // and the kernels do not fetch for the other)
+    plan.team_paired = alphabet_size == 4 && team_entry_bytes(c.waves) == 16 && kmer_size >= 2 && plan.shard_count == 1 &&
+                       !(std::getenv("EPIK_AMD_TEAM_TABLE") && std::strcmp(std::getenv("EPIK_AMD_TEAM_TABLE"), "plain") == 0);
+    plan.table_keys = shard_keys(num_keys, plan.shard_index, plan.shard_count);
+    plan.table_bytes = (uint64_t)c.passes * plan.table_keys * (uint64_t)team_entry_bytes(c.waves) * (plan.team_paired ? 2u : 1u);
+    return EPIK_AMD_OK;
+}
+
+// The layout of the one-wavefront kernels (place_kernel.hip), from the key space, how many codes have a list and the
+// device's free memory (+ EPIK_AMD_LAYOUT):
+//  packed  : an 8-byte {len, line} entry per k-mer code + every list on 128-byte lines of its own;
+//  paired  : the same lists behind a table keyed by the (k-1)-mer that two consecutive k-mers of a read
+//            share: one table line per two lookups, 16 bytes per code; 4-letter alphabets -- their default;
+//  filtered: packed behind a presence filter keyed like the paired table: the other alphabets when at
+//            most a quarter of the codes have a list;
+//  compact : the CSR (4- or 8-byte offsets), 8-byte postings back to back: when the table would take
+//            more than a quarter of the device's free memory.
+struct WaveLayout {
+    bool paired = false, filtered = false, packed = false;
+};
+WaveLayout choose_wave_layout(uint32_t alphabet_size, uint64_t num_keys, uint64_t present_codes, size_t free_mem,
+                              const char *forced_layout)
+{
+    const bool sparse = present_codes * 4u <= num_keys;
+    const bool can_pair = alphabet_size == 4, can_filter = alphabet_size <= 32;
+    const bool table_fits = num_keys * 16u <= free_mem / 4;
+    WaveLayout w;
+    if (forced_layout && forced_layout[0]) {
+        w.filtered = can_filter && (std::strcmp(forced_layout, "filtered") == 0 ||
+                                    (!can_pair && std::strcmp(forced_layout, "paired") == 0));
+        w.paired = can_pair && std::strcmp(forced_layout, "paired") == 0;
+        w.packed = w.paired || w.filtered || std::strcmp(forced_layout, "compact") != 0;
+    } else if (table_fits) {
+        w.paired = can_pair;
+        w.filtered = !w.paired && can_filter && sparse;
+        w.packed = true;
+    }
+    return w;
+}
+// table and presence filter of the packed layouts
+void size_packed_tables(uint32_t alphabet_size, uint64_t num_keys, const WaveLayout &w, Plan &plan)
+{
+    plan.table_bytes = num_keys * (w.paired ? 16u : 8u) + 8u;
+    // A presence record holds 2 x sigma bits.  In 64-bit words the filter of a protein database with k = 7 takes 512 MB,
+    // twice the Infinity Cache; its 40 bits packed into 5 bytes (read as two dwords at any byte) 320 MB, and a record
+    // straddles a 128-byte line once in 32.  EPIK_AMD_FILTER=wide|narrow forces one.
+    plan.filter_rec_bytes = 8;
+    if (w.filtered && 2u * alphabet_size <= 40u) {
+        const char *forced_filter = std::getenv("EPIK_AMD_FILTER");
+        const bool narrow = forced_filter ? std::strcmp(forced_filter, "narrow") == 0 : kNarrowFilterByDefault;
+        if (narrow) plan.filter_rec_bytes = 5;
+    }
+    // (+ 8: a record's second dword may lie behind the last record)
+    plan.filter_bytes = w.filtered ? (num_keys / alphabet_size) * plan.filter_rec_bytes + (plan.filter_rec_bytes == 8 ? 0u : 8u) : 0;
+}
+
+}  // namespace
+
+int make_plan(const Source &src, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
+              std::string &err)
+{
+    const epik_amd_placer_desc *d = src.d;
+    auto fail = [&](int code, const char *msg) {
+        err = msg;
+        return code;
+    };
+    plan = Plan{};
+    plan.shard_index = src.shard_index, plan.shard_count = src.shard_count;
+    KernelDecision kernel;
+    if (const int rc = decide_kernel(d->num_branches, forced_kernel, forced_layout, plan, kernel, err); rc != EPIK_AMD_OK) return rc;
+    const bool team = kernel.team;
 
     {
         Cursor all(src);
@@ -268,23 +382,14 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     }
 
     if (team) {
-        const TeamChoice c = choose_team(d->num_branches, d->keep_at_most, forced_waves, forced_passes);
-        if (c.waves == 0) return fail(EPIK_AMD_ERR_UNSUPPORTED, "no team geometry fits this tree");
-        plan.layout = DbLayout::kTeam;
-        plan.team_waves = c.waves;
-        plan.team_passes = c.passes;
-        plan.team_slice_rows = c.slice_rows;
-        plan.team_rows_pad = c.rows_pad;
+        if (const int rc = plan_team_geometry(d->num_branches, d->keep_at_most, d->alphabet_size, d->kmer_size, d->num_keys, kernel, plan, err);
+            rc != EPIK_AMD_OK)
+            return rc;
+        const TeamChoice c{plan.team_waves, plan.team_passes, plan.team_slice_rows, plan.team_rows_pad, 0};
         // size of the sliced posting region: every (code, pass) on 128-byte lines of its own
         const uint32_t slices = (uint32_t)c.waves * c.passes;
         std::vector<uint32_t> cnt(slices);
         uint64_t lines = 0;
-        // A table entry is 16 bytes, a lookup fetches a 128-byte line: with 4 letters the table is keyed, as the
-        // paired layout of the one-wavefront kernels, by the (k-1)-mer X two consecutive k-mers of a read share
-        // -- block X = the entries of a.X (slots 0-3) and X.b (slots 4-7), one line -- so that two lookups
-        // cost one fetch (the front kernel is bound by exactly these fetches).  Every entry is stored twice.
-        plan.team_paired = d->alphabet_size == 4 && team_entry_bytes(c.waves) == 16 && d->kmer_size >= 2 &&
-                           !(std::getenv("EPIK_AMD_TEAM_TABLE") && std::strcmp(std::getenv("EPIK_AMD_TEAM_TABLE"), "plain") == 0);
         if (plan.team_paired) plan.team_quarter_lines.assign((size_t)c.passes * 4, 0);
         std::vector<uint64_t> pass_lines(c.passes, 0);  // lines of each pass so far (a pass's lines are numbered from the region's start: see build)
         const uint64_t quarter = d->num_keys / 4;
@@ -310,32 +415,12 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
         }
         if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
         plan.posting_bytes = lines * 128u + 512u;  // +512: room behind the last list (descriptors are exact)
-        plan.table_bytes = (uint64_t)c.passes * d->num_keys * (uint64_t)team_entry_bytes(c.waves) * (plan.team_paired ? 2u : 1u);
         return EPIK_AMD_OK;
     }
 
-    // ---- layouts of the one-wavefront-per-read kernels (place_kernel.hip) -------------------------------
-    //  packed  : an 8-byte {len, line} entry per k-mer code + every list on 128-byte lines of its own;
-    //  paired  : the same lists behind a table keyed by the (k-1)-mer that two consecutive k-mers of a read
-    //            share: one table line per two lookups, 16 bytes per code; 4-letter alphabets -- their default;
-    //  filtered: packed behind a presence filter keyed like the paired table: the other alphabets when at
-    //            most a quarter of the codes have a list;
-    //  compact : the CSR (4- or 8-byte offsets), 8-byte postings back to back: when the table would take
-    //            more than a quarter of the device's free memory.
-    const bool sparse = plan.present_codes * 4u <= d->num_keys;
-    const bool can_pair = d->alphabet_size == 4, can_filter = d->alphabet_size <= 32;
-    const bool table_fits = d->num_keys * 16u <= free_mem / 4;
-    bool paired = false, filtered = false, packed = false;
-    if (forced_layout && forced_layout[0]) {
-        filtered = can_filter && (std::strcmp(forced_layout, "filtered") == 0 ||
-                                  (!can_pair && std::strcmp(forced_layout, "paired") == 0));
-        paired = can_pair && std::strcmp(forced_layout, "paired") == 0;
-        packed = paired || filtered || std::strcmp(forced_layout, "compact") != 0;
-    } else if (table_fits) {
-        paired = can_pair;
-        filtered = !paired && can_filter && sparse;
-        packed = true;
-    }
+    // ---- layouts of the one-wavefront-per-read kernels (place_kernel.hip): choose_wave_layout -----------------
+    const WaveLayout w = choose_wave_layout(d->alphabet_size, d->num_keys, plan.present_codes, free_mem, forced_layout);
+    const bool paired = w.paired, filtered = w.filtered, packed = w.packed;
     if (!packed) {
         plan.layout = d->offset_bits == 64 ? DbLayout::kCompact64 : DbLayout::kCompact32;
         plan.table_bytes = (d->num_keys + 1) * (d->offset_bits / 8u);  // (the device table is dense whatever the form handed over)
@@ -369,18 +454,93 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     }
     if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
     plan.posting_bytes = lines * 128u + 512u;
-    plan.table_bytes = d->num_keys * (paired ? 16u : 8u) + 8u;
-    // A presence record holds 2 x sigma bits.  In 64-bit words the filter of a protein database with k = 7 takes 512 MB,
-    // twice the Infinity Cache; its 40 bits packed into 5 bytes (read as two dwords at any byte) 320 MB, and a record
-    // straddles a 128-byte line once in 32.  EPIK_AMD_FILTER=wide|narrow forces one.
-    plan.filter_rec_bytes = 8;
-    if (filtered && 2u * d->alphabet_size <= 40u) {
-        const char *forced_filter = std::getenv("EPIK_AMD_FILTER");
-        const bool narrow = forced_filter ? std::strcmp(forced_filter, "narrow") == 0 : kNarrowFilterByDefault;
-        if (narrow) plan.filter_rec_bytes = 5;
+    size_packed_tables(d->alphabet_size, d->num_keys, w, plan);
+    return EPIK_AMD_OK;
+}
+
+int plan_sizes(const SizeDesc &z, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
+               bool &posting_bytes_is_bound, std::string &err)
+{
+    auto fail = [&](int code, const char *msg) {
+        err = msg;
+        return code;
+    };
+    plan = Plan{};
+    posting_bytes_is_bound = false;
+    if (z.shard_count == 0 || z.shard_index >= z.shard_count) return fail(EPIK_AMD_ERR_INVALID, "shard_index must be below shard_count");
+    if (z.kmer_size < 1 || z.kmer_size > 32) return fail(EPIK_AMD_ERR_UNSUPPORTED, "kmer_size must be in [1, 32]");
+    if (z.alphabet_size < 2 || z.alphabet_size > 32) return fail(EPIK_AMD_ERR_INVALID, "alphabet_size must be in [2, 32]");
+    if (z.num_branches == 0 || z.num_branches >= (1u << 24)) return fail(EPIK_AMD_ERR_INVALID, "num_branches out of range");
+    if (z.keep_at_most == 0 || z.keep_at_most > 64) return fail(EPIK_AMD_ERR_UNSUPPORTED, "keep_at_most must be in [1, 64]");
+    if (z.n_bins && !z.bins) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    uint64_t num_keys = 1;
+    for (uint32_t i = 0; i < z.kmer_size; ++i) {
+        num_keys *= z.alphabet_size;
+        if (num_keys > 0xffffffffull) return fail(EPIK_AMD_ERR_UNSUPPORTED, "alphabet_size^kmer_size exceeds 2^32 keys");
     }
-    // (+ 8: a record's second dword may lie behind the last record)
-    plan.filter_bytes = filtered ? (d->num_keys / d->alphabet_size) * plan.filter_rec_bytes + (plan.filter_rec_bytes == 8 ? 0u : 8u) : 0;
+    plan.shard_index = z.shard_index, plan.shard_count = z.shard_count;
+    uint64_t in_runs = 0;
+    for (uint64_t i = 0; i < z.n_bins; ++i) {
+        const epik_amd_list_bin &b = z.bins[i];
+        if (b.lists_in_runs > b.lists) return fail(EPIK_AMD_ERR_INVALID, "a bin with more lists in runs than lists");
+        if (b.length == 0 || b.lists == 0) continue;
+        if (b.length > z.num_branches) return fail(EPIK_AMD_ERR_INVALID, "a list longer than the tree has branches (branches are distinct inside a list)");
+        plan.kept_entries += b.length * b.lists;
+        plan.present_codes += b.lists;
+        if (b.length < 65536u) in_runs += b.length * b.lists_in_runs;
+    }
+    if (plan.present_codes > shard_keys(num_keys, z.shard_index, z.shard_count))
+        return fail(EPIK_AMD_ERR_INVALID, "more lists than the shard has codes");
+    if (plan.kept_entries >= (1ull << 40)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "more than 2^40 postings");
+    KernelDecision kernel;
+    if (const int rc = decide_kernel(z.num_branches, forced_kernel, forced_layout, plan, kernel, err); rc != EPIK_AMD_OK) return rc;
+    if (kernel.team) {
+        if (const int rc = plan_team_geometry(z.num_branches, z.keep_at_most, z.alphabet_size, z.kmer_size, num_keys, kernel, plan, err);
+            rc != EPIK_AMD_OK)
+            return rc;
+        // The posting region: every (code, pass) on 128-byte lines of its own, the list cut into its sublists, each
+        // padded to 4 bytes.  How a list falls over the slices is not in a histogram of lengths; what is certain: its
+        // sublists take at most 6 len + 3 min(len, slices) bytes, and each pass it reaches beyond the first at most one
+        // more line -- an upper bound, a few percent above what the lists will take.
+        const uint64_t slices = (uint64_t)plan.team_waves * plan.team_passes;
+        uint64_t lines = 0;
+        for (uint64_t i = 0; i < z.n_bins; ++i) {
+            const epik_amd_list_bin &b = z.bins[i];
+            if (b.length == 0 || b.lists == 0) continue;
+            const uint64_t bytes = 6u * b.length + 3u * std::min<uint64_t>(b.length, slices);
+            lines += b.lists * ((bytes + 127u) / 128u + (std::min<uint64_t>(b.length, plan.team_passes) - 1u));
+            plan.team_chunks += b.lists * ((b.length + 63u) / 64u + std::min<uint64_t>(b.length, slices) - 1u);
+        }
+        if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
+        plan.posting_bytes = lines * 128u + 512u;
+        posting_bytes_is_bound = true;
+        return EPIK_AMD_OK;
+    }
+    const WaveLayout w = choose_wave_layout(z.alphabet_size, num_keys, plan.present_codes, free_mem, forced_layout);
+    if (!w.packed) {
+        const uint32_t offset_bits = plan.kept_entries > 0xffffffffull ? 64u : 32u;  // (what a caller's offsets[] would need)
+        plan.layout = offset_bits == 64 ? DbLayout::kCompact64 : DbLayout::kCompact32;
+        plan.table_bytes = (num_keys + 1) * (offset_bits / 8u);
+        plan.posting_bytes = plan.kept_entries * 8u + 512u;
+        return EPIK_AMD_OK;
+    }
+    plan.layout = w.paired ? DbLayout::kPaired : w.filtered ? DbLayout::kFiltered : DbLayout::kPacked;
+    if (plan.n_pad > 65536u) return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the packed layouts");
+    uint64_t explicit_lines = 0;
+    for (uint64_t i = 0; i < z.n_bins; ++i)
+        if (z.bins[i].length && z.bins[i].lists) explicit_lines += z.bins[i].lists * ((z.bins[i].length * 6u + 127u) / 128u);
+    plan.runs = choose_runs(explicit_lines * 128u + num_keys * (w.paired ? 16u : 8u) + 8u, plan.kept_entries, in_runs);
+    uint64_t lines = 0;
+    for (uint64_t i = 0; i < z.n_bins; ++i) {
+        const epik_amd_list_bin &b = z.bins[i];
+        if (b.length == 0 || b.lists == 0) continue;
+        if (b.length >= 65536u) return fail(EPIK_AMD_ERR_INVALID, "a posting list of 65536 entries or more in a tree of fewer branches");
+        const uint64_t as_runs = plan.runs ? b.lists_in_runs : 0;
+        lines += (b.lists - as_runs) * ((b.length * 6u + 127u) / 128u) + as_runs * ((b.length * 4u + 127u) / 128u);
+    }
+    if (lines >= (1ull << 32)) return fail(EPIK_AMD_ERR_UNSUPPORTED, "posting region of 512 GiB or more");
+    plan.posting_bytes = lines * 128u + 512u;
+    size_packed_tables(z.alphabet_size, num_keys, w, plan);
     return EPIK_AMD_OK;
 }
 
@@ -422,10 +582,11 @@ int build(const Source &src, const Plan &plan, Sink &table, Sink *filter, Sink &
                 const uint32_t first_slice = pass * (uint32_t)W;
                 const uint64_t pass_first_line = line;
                 // ---- the postings of the pass, in code order (and, unpaired, the table with them) ----------
-                RecordWriter entries(table, entry_bytes, plan.team_paired ? 0 : num_keys);
+                RecordWriter entries(table, entry_bytes, plan.team_paired ? 0 : plan.table_keys);
                 Cursor walk(src);
                 for (uint64_t key = 0; key < num_keys; ++key) {
-                    uint8_t *entry = plan.team_paired ? nullptr : entries.next();
+                    // (a shard's table: an entry per code of the shard, code / shard_count being its place)
+                    uint8_t *entry = plan.team_paired || !src.kept(key) ? nullptr : entries.next();
                     uint64_t first = 0;
                     const uint64_t len = walk.list(key, &first);
                     if (len == 0) continue;

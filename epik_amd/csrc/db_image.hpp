@@ -104,7 +104,19 @@ struct Plan {
     bool runs = false;  // packed layouts: run-coded lists (place_device.hpp, kRuns)
     uint64_t quarter_lines[4] = {0, 0, 0, 0};  // paired table: posting lines in front of each quarter of the key space
     uint32_t wave_resident[3] = {0, 0, 0};     // resident waves per CU by count width (what chose the kernel)
+    // k-mer-space shard (include/epik_amd.h): the placer keeps the lists of the codes with code % shard_count ==
+    // shard_index.  The sliced table of such a placer holds an entry per code OF THE SHARD, at code / shard_count
+    // (table_keys of them per pass): 1 / shard_count of the bytes, and the kernels test code % shard_count before
+    // they fetch -- the other shards' k-mers of a read cost no table line.
+    uint32_t shard_index = 0, shard_count = 1;
+    uint64_t table_keys = 0;  // sliced layout: entries per pass
 };
+
+// codes of [0, num_keys) with code % count == index
+inline uint64_t shard_keys(uint64_t num_keys, uint32_t index, uint32_t count)
+{
+    return count <= 1 ? num_keys : (num_keys > index ? (num_keys - index + count - 1) / count : 0);
+}
 
 // Sequential writer of one part of the image.
 struct Sink {
@@ -112,6 +124,10 @@ struct Sink {
     // `n` writable bytes that follow everything reserved before, zero-filled; valid until the next call.
     virtual uint8_t *reserve(size_t n) = 0;
 };
+
+// What part of a database the placer is to keep: the caller's (shard_index, shard_count), or -- with (0, 1) -- the shard
+// the descriptor says it holds already (epik_amd_placer_desc.shard); the two must not disagree.
+int resolve_shard(const epik_amd_placer_desc *d, uint32_t &shard_index, uint32_t &shard_count, std::string &err);
 
 // Argument and consistency checks of create() that need no device: sizes, monotone offsets,
 // branches in range and distinct inside a list, finite scores.  Returns an epik_amd_status.
@@ -122,6 +138,20 @@ int validate(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t shard
 // the parts.  Reads every offset, and for the team layout every posting, once.
 int make_plan(const Source &src, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
               std::string &err);
+
+// The same plan from the SIZES of a database alone (epik_amd_placer_plan_sizes: capacity planning before a database
+// exists or is at hand -- main.cpp:252-266's --max-ram is the reference's only capacity control): the tree, the key
+// space, and how many lists of which length the placer (its shard) will keep.  Kernel, layout, geometry, table and
+// filter come out as make_plan() would give them on such a database; the posting region exactly for the layouts of
+// the one-wavefront kernels, as an upper bound (`posting_bytes_is_bound`) for the sliced layout.
+struct SizeDesc {
+    uint32_t kmer_size = 0, alphabet_size = 0, num_branches = 0, keep_at_most = 7;
+    const epik_amd_list_bin *bins = nullptr;
+    uint64_t n_bins = 0;
+    uint32_t shard_index = 0, shard_count = 1;
+};
+int plan_sizes(const SizeDesc &sizes, size_t free_mem, const char *forced_layout, const char *forced_kernel, Plan &plan,
+               bool &posting_bytes_is_bound, std::string &err);
 
 // Produces the image: exactly plan.table_bytes into `table`, plan.filter_bytes into `filter` (may be
 // null when 0), plan.posting_bytes into `postings`.

@@ -64,7 +64,10 @@ struct TeamParams {
     PlaceParams base;            // first member: the out-of-line device functions get &base
                                  // (base.postings = the sliced posting region; base.table / filter unused)
     const uint8_t *team_table;   // [passes][num_keys] entries of team_entry_bytes(W); paired: [passes][num_keys / 4][8]
-    uint64_t num_keys;
+    uint64_t num_keys;           // entries per pass: the codes of the key space, or -- a k-mer-space shard -- those of the shard
+    uint32_t shard_index, shard_count;  // shard_count > 1: the table holds the codes with code % shard_count == shard_index
+                                 // only, code / shard_count being the entry's place; the other codes have no list HERE and
+                                 // are not looked up
     uint32_t team_paired;        // the table is keyed by the (k-1)-mer X two consecutive k-mers share (4 letters): block X =
                                  // the entries of a.X (slots 0-3) and X.b (slots 4-7); a k-mer at an even position of the
                                  // read is looked up as a.X, the next one as X.b -- the same 128-byte line

@@ -196,6 +196,14 @@ int place_sharded_impl(epik_amd_placer *const *shards, uint32_t G, const char *s
     if (n == 0) return EPIK_AMD_OK;
     if (!seqs || !seq_offsets || !rows || !n_rows) return fail_with(EPIK_AMD_ERR_INVALID, "null host buffer");
     if (seq_offsets[0] != 0) return fail_with(EPIK_AMD_ERR_INVALID, "seq_offsets[0] must be 0");
+    // ONE shard is the whole of what there is to place against: the one-pass placement, which streams a read's rows
+    // once -- accumulate + finish stream them twice (as postings, then as list entries), 2.3 x the time for the same
+    // rows (measured, round 4: 16.7 against 38.5 M reads/s at N = 9 999).  EPIK_AMD_SHARD_HALVES=1: the two halves
+    // all the same (tests: the machinery below with one handle).
+    if (G == 1) {
+        const char *halves = std::getenv("EPIK_AMD_SHARD_HALVES");
+        if (!(halves && halves[0] == '1')) return epik_amd_placer_place(shards[0], seqs, seq_offsets, n, rows, n_rows, kmer_counts);
+    }
     // every handle: the same tree and parameters, kernels that leave partial lists, the same list geometry
     epik_amd_partial_info info0{};
     for (uint32_t g = 0; g < G; ++g) {

@@ -32,7 +32,15 @@ struct TeamEntry {
                                                  uint4 (&raw)[kQuads])
     {
         uint64_t index = (uint64_t)pass * tp.num_keys + key;
-        if (tp.team_paired) {  // (wave-uniform)
+        if (tp.shard_count > 1u) {  // (wave-uniform) a k-mer-space shard: the codes of the other shards are not looked up
+            const uint32_t q = key / tp.shard_count;
+            if (key - q * tp.shard_count != tp.shard_index) {
+#pragma unroll
+                for (int i = 0; i < kQuads; ++i) raw[i] = make_uint4(0u, 0u, 0u, 0u);
+                return;
+            }
+            index = (uint64_t)pass * tp.num_keys + q;
+        } else if (tp.team_paired) {  // (wave-uniform)
             const uint32_t shift = 2u * tp.base.kmer_size - 2u;  // X = k-1 letters of 2 bits
             const bool as_prefix = (position & 1u) != 0;
             const uint32_t block = as_prefix ? key >> 2 : key & ((1u << shift) - 1u);

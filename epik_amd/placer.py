@@ -69,12 +69,13 @@ def pendant_lengths(branch_length: np.ndarray, subtree_num_nodes: np.ndarray,
 
 def make_desc(offsets, values, *, states: str, kmer_size: int, num_branches: int, threshold, log_threshold=None,
               keep_at_most: int = 7, keep_factor: float = 0.01, device: int = 0, char_class=None, keys=None,
-              sparse: bool = False):
+              sparse: bool = False, holds_shard=None):
     """`epik_amd_placer_desc` over host arrays (uint32 / uint64 offsets are handed over as they are, no
     copy).  `keys` (ascending uint32 codes that have a list): the sparse form, `offsets` then has
     len(keys) + 1 entries; `sparse=True` turns dense offsets into that form first (EPIK_AMD_SPARSE_DESC=1
-    does it for every descriptor: the GPU tests run on both forms).  Returns (desc, the arrays it points
-    into -- keep them alive as long as the descriptor)."""
+    does it for every descriptor: the GPU tests run on both forms).  `holds_shard=(g, G)`: the arrays hold shard g of
+    G of a database already (only the lists of the codes with code % G == g: `epik_amd_placer_desc.shard`).
+    Returns (desc, the arrays it points into -- keep them alive as long as the descriptor)."""
     sigma = alphabet.alphabet_size(states)
     if log_threshold is None:
         log_threshold = alphabet.log_threshold(np.float32(threshold))
@@ -106,7 +107,8 @@ def make_desc(offsets, values, *, states: str, kmer_size: int, num_branches: int
         keep_factor=float(keep_factor), threshold=float(threshold),
         log_threshold=float(log_threshold), num_keys=int(num_keys),
         num_entries=num_entries, offsets=off.ctypes.data, values=vals.ctypes.data,
-        char_class=cls.ctypes.data, device=int(device), reserved=0,
+        char_class=cls.ctypes.data, device=int(device),
+        shard=0 if holds_shard is None or int(holds_shard[1]) <= 1 else (int(holds_shard[0]) | int(holds_shard[1]) << 16),
         keys=keys.ctypes.data if keys is not None else None, num_present=int(keys.shape[0]) if keys is not None else 0)
     return desc, (off, vals, cls, keys)
 
@@ -115,6 +117,7 @@ def plan(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 28
     """`epik_amd_placer_plan`: kernel, layout and device-image sizes create() would choose for a
     synthetic / loaded database `db` -- no device needed."""
     kw.setdefault("keys", getattr(db, "keys", None))
+    kw.setdefault("holds_shard", getattr(db, "shard", None))
     desc, keep = make_desc(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
                            num_branches=db.num_branches, threshold=db.threshold, log_threshold=db.log_threshold, **kw)
     out = capi.Plan()
@@ -124,10 +127,47 @@ def plan(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 28
     return out
 
 
+def plan_sizes(*, states: str, kmer_size: int, num_branches: int, bins, keep_at_most: int = 7, shard_index: int = 0,
+               shard_count: int = 1, free_bytes: int = 288 << 30) -> capi.Plan:
+    """`epik_amd_placer_plan_sizes`: the plan of a database known by its SIZES only -- `bins` = (length, lists[,
+    lists_in_runs]) per length of posting list the placer (its shard) keeps.  No device, no postings."""
+    arr = (capi.ListBin * max(len(bins), 1))()
+    for i, b in enumerate(bins):
+        arr[i].length, arr[i].lists = int(b[0]), int(b[1])
+        arr[i].lists_in_runs = int(b[2]) if len(b) > 2 else 0
+    out = capi.Plan()
+    capi.check(capi.load().epik_amd_placer_plan_sizes(int(kmer_size), alphabet.alphabet_size(states), int(num_branches),
+                                                      int(keep_at_most), arr, len(bins), int(shard_index), int(shard_count),
+                                                      int(free_bytes), ctypes.byref(out)))
+    return out
+
+
+def list_bins(db, shard_index: int = 0, shard_count: int = 1):
+    """The histogram `plan_sizes` takes, of a database at hand (tests; capacity reports of a loaded database)."""
+    offsets = np.asarray(db.offsets).astype(np.int64)
+    lens = np.diff(offsets)
+    codes = np.asarray(db.keys, dtype=np.int64) if getattr(db, "keys", None) is not None else np.arange(len(lens))
+    mine = (codes % shard_count == shard_index) & (lens > 0)
+    br = db.values["branch"].astype(np.int64)
+    steps_ok = np.ones(len(br), dtype=bool)
+    steps_ok[1:] = np.diff(br) == 1
+    broken = np.zeros(len(br) + 1, dtype=np.int64)   # (how many positions of a list other than its first break the run)
+    inner = np.ones(len(br), dtype=bool)
+    inner[offsets[:-1][lens > 0]] = False
+    broken[1:] = np.cumsum(~steps_ok & inner)
+    is_run = (broken[offsets[1:]] - broken[offsets[:-1]] == 0) & (lens > 0) & (lens < 65536)
+    out = []
+    for length in np.unique(lens[mine]):
+        sel = mine & (lens == length)
+        out.append((int(length), int(sel.sum()), int((sel & is_run).sum())))
+    return out
+
+
 def build_image(db, *, shard_index: int = 0, shard_count: int = 1, free_bytes: int = 288 << 30, discard=False, **kw):
     """`epik_amd_placer_build_image`: the device image as three uint8 arrays (table, filter, postings);
     with `discard` the image is produced and dropped (returns the plan only).  Host only."""
     kw.setdefault("keys", getattr(db, "keys", None))
+    kw.setdefault("holds_shard", getattr(db, "shard", None))
     desc, keep = make_desc(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
                            num_branches=db.num_branches, threshold=db.threshold, log_threshold=db.log_threshold, **kw)
     lib = capi.load()
@@ -150,7 +190,7 @@ class Placer:
                  num_branches: int, threshold, log_threshold=None, keep_at_most: int = 7,
                  keep_factor: float = 0.01, device: int = 0, branch_length=None,
                  subtree_num_nodes=None, subtree_total_length=None, char_class=None,
-                 shard_index: int = 0, shard_count: int = 1, keys=None, sparse: bool = False):
+                 shard_index: int = 0, shard_count: int = 1, keys=None, sparse: bool = False, holds_shard=None):
         lib = capi.load()
         sigma = alphabet.alphabet_size(states)
         self.states = states
@@ -162,7 +202,7 @@ class Placer:
         desc, keepalive = make_desc(
             offsets, values, states=states, kmer_size=kmer_size, num_branches=num_branches, threshold=threshold,
             log_threshold=log_threshold, keep_at_most=keep_at_most, keep_factor=keep_factor, device=device,
-            char_class=char_class, keys=keys, sparse=sparse)
+            char_class=char_class, keys=keys, sparse=sparse, holds_shard=holds_shard)
         handle = ctypes.c_void_p()
         # shard_count > 1: this placer keeps the posting lists of the codes with
         # code % shard_count == shard_index (k-mer-space shard, `epik_amd_placer_create_sharded`)
@@ -189,6 +229,7 @@ class Placer:
             extra = dict(branch_length=tree.branch_length, subtree_num_nodes=tree.subtree_num_nodes,
                          subtree_total_length=tree.subtree_total_length)
         kw.setdefault("keys", getattr(db, "keys", None))
+        kw.setdefault("holds_shard", getattr(db, "shard", None))   # (synth.make_db(shard=...): one shard's lists only)
         return cls(db.offsets, db.values, states=db.states, kmer_size=db.kmer_size,
                    num_branches=db.num_branches, threshold=db.threshold,
                    log_threshold=db.log_threshold, **extra, **kw)

@@ -150,6 +150,7 @@ class SynthDB:
     log_threshold: np.float32 = None
     total_entries: int = None     # postings of the whole database when this object holds one shard of it
     keys: np.ndarray = None       # the sparse form: uint32 ascending codes that have a list, offsets[len(keys) + 1]
+    shard: tuple = None           # (g, G): this object holds the lists of the codes with code % G == g only
 
     def __post_init__(self):
         sigma = alphabet.alphabet_size(self.states)
@@ -237,6 +238,8 @@ def make_db(num_branches: int, states: str = "nucl", kmer_size: int = 10, omega:
     db = SynthDB(states=states, kmer_size=kmer_size, omega=omega, num_branches=num_branches,
                  offsets=offsets, values=values, threshold=threshold)
     db.total_entries = total_all  # of the whole database, whatever the shard
+    if shard is not None and shard[1] > 1:
+        db.shard = (int(shard[0]), int(shard[1]))
     return db
 
 

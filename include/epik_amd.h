@@ -91,7 +91,9 @@ typedef struct {
                                    popcount 1 plain, >1 ambiguous, 0 invalid
                                    (i2l::to_kmers<one_ambiguity_policy>, place.cpp:294) */
     int32_t device;          /* HIP device ordinal */
-    uint32_t reserved;
+    uint32_t shard;          /* 0: a whole database.  g | G << 16 (G >= 2, g < G): the descriptor holds shard g of G of one
+                                ALREADY -- the lists of the codes with code % G == g and no others (k-mer-space shard,
+                                below): create() then sizes its table for those codes alone, as create_sharded() does */
     const uint32_t *keys;    /* NULL: dense form; else [num_present] ascending codes (sparse form) */
     uint64_t num_present;    /* sparse form: number of codes that have a list */
 } epik_amd_placer_desc;
@@ -130,10 +132,28 @@ typedef struct {
     uint64_t kept_entries;   /* postings this placer keeps (its shard) */
     uint32_t run_coded;      /* 1: lists that are one ascending run of branches are stored without their cells
                                 (4 bytes per posting; databases well beyond the Infinity Cache) */
-    uint32_t reserved;
+    uint32_t posting_bytes_is_bound; /* epik_amd_placer_plan_sizes, sliced layout: posting_bytes is an upper bound */
 } epik_amd_plan;
 int epik_amd_placer_plan(const epik_amd_placer_desc *desc, uint32_t shard_index, uint32_t shard_count,
                          uint64_t free_bytes, epik_amd_plan *plan);
+/*
+ * The same plan from the SIZES of a database alone -- before it exists, or is at hand: the tree, the key space, and a
+ * histogram of the posting lists the placer (shard shard_index of shard_count) will keep.  The reference's only
+ * capacity control is --max-ram on the host (main.cpp:252-266, README.md:121-128); this answers "how many GPUs'
+ * HBM does a database of this shape take, table included" without touching a posting.  kernel, layout, geometry,
+ * resident_waves, table_bytes, filter_bytes, kept_entries and run_coded are what epik_amd_placer_plan() gives on
+ * a database with these lists; posting_bytes too for the layouts of the one-wavefront kernel, and an upper bound
+ * (a few percent: how a list falls over the slices of the branch range is not in a histogram) for the sliced
+ * layout -- posting_bytes_is_bound says which.  No device needed.
+ */
+typedef struct {
+    uint64_t length;         /* postings of a list */
+    uint64_t lists;          /* lists of that length this placer keeps */
+    uint64_t lists_in_runs;  /* ... of which are one ascending run of branches b, b + 1, ... (<= lists; 0 if unknown) */
+} epik_amd_list_bin;
+int epik_amd_placer_plan_sizes(uint32_t kmer_size, uint32_t alphabet_size, uint32_t num_branches, uint32_t keep_at_most,
+                               const epik_amd_list_bin *bins, uint64_t n_bins, uint32_t shard_index, uint32_t shard_count,
+                               uint64_t free_bytes, epik_amd_plan *plan);
 /* The image create() uploads for that plan, written front to back into host buffers of
  * plan->table_bytes / filter_bytes / posting_bytes (NULL = that part is produced and dropped).
  * Host only; create() streams the same bytes to the device without holding them. */

@@ -45,7 +45,7 @@ def _desc(db, **over):
              num_branches=db.num_branches, keep_at_most=7, offset_bits=32, keep_factor=0.01,
              threshold=float(db.threshold), log_threshold=float(db.log_threshold),
              num_keys=db.num_keys, num_entries=db.num_entries, offsets=off.ctypes.data,
-             values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, reserved=0)
+             values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, shard=0)
     d.update(over)
     return capi.PlacerDesc(**d), (off, cls)
 

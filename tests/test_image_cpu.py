@@ -9,7 +9,7 @@ import numpy as np
 import psutil
 import pytest
 
-from epik_amd import placer as eplacer, synth
+from epik_amd import capi, placer as eplacer, synth
 
 LINE = 128
 
@@ -192,6 +192,60 @@ def test_team_layout(db, kernel, waves, table, monkeypatch):
     assert postings.tobytes() == bytes(post) + bytes(512)
 
 
+@pytest.mark.parametrize("how", ["create_sharded", "descriptor"])
+@pytest.mark.parametrize("kernel,waves", [("team4", 4), ("team2", 2), ("team8", 8)])
+def test_team_layout_of_a_shard(db, kernel, waves, how, monkeypatch):
+    """A k-mer-space shard (g of G) of the sliced layout knows that it is one: its table holds an entry per code OF THE
+    SHARD, code // G being the entry's place -- 1 / G of the entries, never paired -- and the postings are those of
+    the shard's lists alone; the same image whether create_sharded() picks the shard out of a whole database or the
+    descriptor holds the shard already and says so (desc.shard)."""
+    import copy
+    monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
+    g, G = 1, 3
+    whole = eplacer.plan(db)
+    if how == "create_sharded":
+        plan, table_bytes, _, postings = eplacer.build_image(db, shard_index=g, shard_count=G)
+    else:
+        lens = np.diff(db.offsets.astype(np.int64))
+        mine = np.arange(db.num_keys) % G == g
+        sub = copy.copy(db)
+        sub.offsets = np.concatenate([[0], np.cumsum(np.where(mine, lens, 0))]).astype(np.uint64)
+        sub.values = db.values[np.repeat(mine, lens)].copy()
+        sub.shard = (g, G)
+        plan, table_bytes, _, postings = eplacer.build_image(sub)
+        sub.shard = (0, G)   # the descriptor says shard 0 and holds shard 1's lists: refused
+        with pytest.raises(capi.EpikAmdError, match="another shard"):
+            eplacer.plan(sub)
+    assert plan.kernel == 1 and plan.layout == 5 and plan.team_waves == waves
+    rows = plan.slice_rows
+    rows_pad = (rows + 1 + 15) // 16 * 16
+    entry_bytes = 16 if waves <= 4 else 32
+    n_mine = len(range(g, db.num_keys, G))
+    assert len(table_bytes) == n_mine * entry_bytes
+    # (the whole database's table: every code, twice where it is paired)
+    assert whole.table_bytes == db.num_keys * entry_bytes * (2 if waves <= 4 else 1)
+    post, line = bytearray(), 0
+    for key, (b, e) in enumerate(_lists(db)):
+        if key % G != g:
+            continue
+        v = db.values[b:e]
+        region = bytearray()
+        lens = []
+        for w in range(waves):
+            sub_list = v[(v["branch"] // rows) == w].copy()
+            lens.append(len(sub_list))
+            sub_list["branch"] -= w * rows
+            region += _pad(_chunks(sub_list, 0, len(sub_list), rows_pad - 1), 4)
+        entry = table_bytes[(key // G) * entry_bytes:(key // G + 1) * entry_bytes]
+        assert entry[4:4 + 2 * waves].view(np.uint16).tolist() == lens
+        if e > b:
+            assert int(entry[:4].view(np.uint32)[0]) == line
+        region = _pad(bytes(region), LINE)
+        post += region
+        line += len(region) // LINE
+    assert postings.tobytes() == bytes(post) + bytes(512)
+
+
 def test_plan_chooses_the_kernel_by_tree_size(monkeypatch):
     monkeypatch.delenv("EPIK_AMD_KERNEL", raising=False)
     monkeypatch.delenv("EPIK_AMD_LAYOUT", raising=False)
@@ -296,3 +350,77 @@ def test_sparse_descriptor_is_validated(db):
     bent = offsets.copy()
     bent[2] = bent[4] + 1
     assert plan_rc(keys, bent) == capi.ERR_INVALID                # offsets not monotone
+
+
+def _plan_fields(p):
+    return dict(kernel=p.kernel, layout=p.layout, team_waves=p.team_waves, team_passes=p.team_passes, slice_rows=p.slice_rows,
+                resident_waves=list(p.resident_waves), table_bytes=p.table_bytes, filter_bytes=p.filter_bytes,
+                kept_entries=p.kept_entries, run_coded=p.run_coded)
+
+
+@pytest.mark.parametrize("case", ["nucl-wave", "nucl-wave-runs", "amino-filtered", "nucl-team4", "nucl-team2", "compact"])
+@pytest.mark.parametrize("shard", [(0, 1), (1, 3)])
+def test_plan_from_the_sizes_alone_is_the_plan_of_the_database(case, shard, monkeypatch):
+    """epik_amd_placer_plan_sizes -- the tree, the key space and a histogram of list lengths, no posting -- gives the
+    plan epik_amd_placer_plan gives on the database itself: kernel, layout, geometry, table and filter always; the
+    posting region exactly for the layouts of the one-wavefront kernel (run-coded or not) and as an upper bound,
+    within a few percent, for the sliced layout (how a list falls over the slices is not in a histogram)."""
+    for var in ("EPIK_AMD_KERNEL", "EPIK_AMD_LAYOUT", "EPIK_AMD_RUNS"):
+        monkeypatch.delenv(var, raising=False)
+    free = 288 << 30
+    if case == "amino-filtered":
+        db = synth.make_db(120, states="amino", kmer_size=3, p_present=0.2, seed=9, lognormal=(2.0, 1.0))
+    elif case in ("nucl-team4", "nucl-team2"):
+        leaves = 5000 if case == "nucl-team4" else 1200
+        db = synth.make_db(2 * leaves - 1, kmer_size=7, p_present=0.6, seed=7)
+    else:
+        db = synth.make_db(999, kmer_size=7, p_present=0.6, seed=11)
+        if case == "nucl-wave-runs":
+            monkeypatch.setenv("EPIK_AMD_RUNS", "1")
+        if case == "compact":
+            free = 1 << 19   # a device whose free memory the table would not fit a quarter of
+            # (the compact layout keeps the caller's offset width; plan_sizes assumes the narrowest that holds the postings)
+            db.offsets = db.offsets.astype(np.uint32)
+    g, G = shard
+    real = eplacer.plan(db, shard_index=g, shard_count=G, free_bytes=free)
+    bins = eplacer.list_bins(db, g, G)
+    sized = eplacer.plan_sizes(states=db.states, kmer_size=db.kmer_size, num_branches=db.num_branches, bins=bins,
+                               shard_index=g, shard_count=G, free_bytes=free)
+    assert _plan_fields(sized) == _plan_fields(real)
+    if real.kernel == 1:
+        assert sized.posting_bytes_is_bound == 1
+        assert real.posting_bytes <= sized.posting_bytes <= real.posting_bytes * 1.08
+        if G > 1:   # a shard's table: an entry per code of the shard, unpaired
+            assert real.table_bytes == len(range(g, 4 ** db.kmer_size, G)) * 16
+    else:
+        assert sized.posting_bytes_is_bound == 0 and sized.posting_bytes == real.posting_bytes
+    if case == "nucl-wave-runs":
+        assert real.run_coded == 1
+    if case == "compact":
+        assert real.layout in (0, 1)
+
+
+def test_a_database_beyond_one_gpu_plans_as_shards_that_fit():
+    """BASELINE configs[4] in numbers only: N = 9 999, nucl k = 14 (268 M codes), 60 G postings -- 0.37 TB of posting
+    region, more than one MI355X holds -- planned without a posting: the whole database does not fit 288 GB, two shards
+    do, and each of eight takes an eighth of the table as well (a shard knows its modulus: an entry per code of its own)."""
+    hbm = 288 << 30
+    codes = 4 ** 14
+    present = int(codes * 0.93)
+    bins = [(1, present // 4, present // 4), (40, present // 4, present // 8), (200, present // 4, present // 4), (655, present - 3 * (present // 4), 0)]
+    total = sum(b[0] * b[1] for b in bins)
+    assert total > 55e9
+    common = dict(states="nucl", kmer_size=14, num_branches=9999)
+    whole = eplacer.plan_sizes(bins=bins, **common)
+    assert whole.kernel == 1 and whole.team_waves == 4 and whole.kept_entries == total
+    assert whole.table_bytes == codes * 32 and whole.table_bytes + whole.posting_bytes > hbm
+    for G in (2, 8):
+        for g in (0, G - 1):
+            # (a shard's lists: every G-th code -- the lengths spread evenly over the residues)
+            mine = [(b[0], b[1] // G, b[2] // G) for b in bins]
+            part = eplacer.plan_sizes(bins=mine, shard_index=g, shard_count=G, **common)
+            assert part.table_bytes == (codes // G) * 16
+            assert part.table_bytes + part.posting_bytes < hbm * 0.8
+            assert part.kept_entries * G <= total
+    with pytest.raises(capi.EpikAmdError, match="more lists than the shard has codes"):
+        eplacer.plan_sizes(bins=bins, shard_index=0, shard_count=8, **common)

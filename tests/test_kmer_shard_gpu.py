@@ -331,7 +331,7 @@ def test_n9999_lists_emulated_shards(gpu_available, oracle_lib, shards, db_layou
         _assert_close_to_oracle(got, oracle_lib.Oracle.from_synth(db).place(data, offs, num_threads=0))
 
 
-@pytest.mark.parametrize("shards,chunk,margin", [(1, "0", ""), (2, "300", ""), (3, "97", "0.2")])
+@pytest.mark.parametrize("shards,chunk,margin", [(1, "0", ""), (1, "halves", ""), (2, "300", ""), (3, "97", "0.2")])
 def test_place_sharded_native(gpu_available, oracle_lib, shards, chunk, margin, db_layout, monkeypatch):
     """epik_amd_placer_place_sharded: the whole k-mer-space-sharded placement inside the library (what
     epik-dna --db-shard calls) -- chunks of the batch, peer copies of the parts, the exchange of a chunk under the
@@ -341,7 +341,10 @@ def test_place_sharded_native(gpu_available, oracle_lib, shards, chunk, margin, 
     if not db_layout.startswith("team") or "classic" in db_layout:
         pytest.skip("dense partial vectors only on this kernel")
     from epik_amd.placer import Placer
-    if chunk != "0":
+    monkeypatch.delenv("EPIK_AMD_SHARD_HALVES", raising=False)
+    if chunk == "halves":   # one handle takes the one-pass placement by itself: here through accumulate + finish all the same
+        monkeypatch.setenv("EPIK_AMD_SHARD_HALVES", "1")
+    elif chunk != "0":
         monkeypatch.setenv("EPIK_AMD_SHARD_CHUNK", chunk)
     if margin:
         monkeypatch.setenv("EPIK_AMD_SHARD_MARGIN", margin)

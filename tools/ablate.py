@@ -65,7 +65,7 @@ def main():
             abi_version=capi.ABI_VERSION, kmer_size=10, alphabet_size=4, num_branches=tree.num_nodes, keep_at_most=7,
             offset_bits=32, keep_factor=0.01, threshold=float(db.threshold), log_threshold=float(db.log_threshold),
             num_keys=db.num_keys, num_entries=db.num_entries, offsets=off32.ctypes.data,
-            values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, reserved=0)
+            values=db.values.ctypes.data, char_class=cls.ctypes.data, device=0, shard=0)
         h = ctypes.c_void_p()
         lib.epik_amd_placer_create.argtypes = [ctypes.POINTER(capi.PlacerDesc), ctypes.POINTER(ctypes.c_void_p)]
         rc = lib.epik_amd_placer_create(ctypes.byref(desc), ctypes.byref(h))

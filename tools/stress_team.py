@@ -100,7 +100,9 @@ def main():
                        for a, b in zip(cuts, cuts[1:])]
             got = list(edist.place_kmer_sharded_lists(engine, batches, None, char_class=cls))
             same_rows(tuple(np.concatenate([g[i] for g in got]) for i in range(3)), one_pass, ("accumulate_lists + finish_lists", run))
+            os.environ["EPIK_AMD_SHARD_HALVES"] = "1"   # (one handle would take the one-pass placement by itself)
             same_rows(Placer.place_sharded([pl], sub, sub_offs), one_pass, ("place_sharded, one shard", run))
+            os.environ.pop("EPIK_AMD_SHARD_HALVES")
     print(f"partial lists: {m} reads x {repeats} runs (pipelined halves and place_sharded) agree with the one-pass placement", flush=True)
     # three shards on the one device: the library's own exchange against the halves driven from here, bit for bit
     os.environ["EPIK_AMD_SHARD_CHUNK"] = "20000"
