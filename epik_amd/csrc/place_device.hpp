@@ -629,10 +629,15 @@ __device__ __forceinline__ void preload_chunk(uint64_t d, uint32_t &cell, uint32
 
 // n_real (<= n_padded, 0: all of them): how many of the descriptors are chunks -- the rest is padding, and the slots of
 // the last trip that hold padding are not retired.
-template <typename Layout, typename CountT, int kDepth = kRing, bool kPreloaded = false>
+// cells_out: where the cells of the ring's slots are left when the function returns -- for a round of ONE trip
+// (n_padded == kDepth) slot i still holds chunk i's cells (0 behind its end and in padding slots), drained: the
+// caller lists the rows the round touched from them (team_stream.hip: emit_partial_list_cells).
+struct NoCells {};
+template <typename Layout, typename CountT, int kDepth = kRing, bool kPreloaded = false, typename Cells = NoCells>
 __device__ __forceinline__ void stream_round(const PlaceParams &p, const typename WaveLds<CountT>::u64_t *chunks,
                                                        uint32_t n_padded, uint32_t score_top, uint32_t count_top,
-                                                       const Preloaded<kDepth> *pre = nullptr, uint32_t n_real = 0)
+                                                       const Preloaded<kDepth> *pre = nullptr, uint32_t n_real = 0,
+                                                       Cells &&cells_out = NoCells{})
 {
     typedef __attribute__((address_space(3))) float lds_f32;
     typedef __attribute__((address_space(3))) CountT lds_count;
@@ -747,6 +752,12 @@ __device__ __forceinline__ void stream_round(const PlaceParams &p, const typenam
                 []() {});
             sa = sa_next, ca = ca_next;
         }
+    }
+    if constexpr (!std::is_same_v<std::remove_cvref_t<Cells>, NoCells>) {
+        // (the tail's first stage has drained the ring: every slot's load has returned.  Through an asm statement, so
+        // that the copy stands HERE: a plain read of a slot register the compiler may place ahead of the drain)
+#pragma unroll
+        for (int i = 0; i < kDepth; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(cells_out[i]) : "v"(ring_c[i]));
     }
 }
 

@@ -506,6 +506,38 @@ __device__ __forceinline__ uint32_t emit_partial_list_trips(WaveLds<CountT> lds,
     }
     return n;
 }
+// The same for an item whose stream was ONE trip of the ring (a shard of many holds two or three of a (read, slice)
+// item's lists: most of its items): the rows it touched are the rows of its postings, and the ring still holds their
+// cells (stream_round's cells_out: slot i = chunk i, cell 0 behind a chunk's end and in padding slots).  No pass over
+// the slice's counts, no list of quads: chunk by chunk -- two chunks may name the same row, and the first to come
+// takes it and leaves a zero count behind -- the rows that hold a count go out and are reset.
+template <typename CountT, int kDepth>
+__device__ __forceinline__ uint32_t emit_partial_list_cells(WaveLds<CountT> lds, uint32_t rows_pad, const uint32_t (&cells)[kDepth],
+                                                            uint32_t n_chunks, uint8_t *__restrict__ out, uint32_t cap)
+{
+    typedef WaveLds<CountT> Lds_t;
+    typedef PartialEntry<CountT> Entry;
+    auto *dst = reinterpret_cast<typename Entry::raw_t *>(out);
+    uint32_t n = 0;
+#pragma unroll
+    for (int c = 0; c < kDepth; ++c) {
+        if ((uint32_t)c < n_chunks) {  // wave-uniform
+            const uint32_t row = rows_pad - 1u - cells[c];  // cell 0: the dummy row
+            const uint2 cv = lds.load(row);
+            const uint32_t count = cv.y & ~(uint32_t)Lds_t::kSeen;
+            const bool hit = cells[c] != 0u && count != 0u;
+            const uint64_t m = __ballot(hit);
+            if (m) {
+                const uint32_t slot = n + lanes_below(m);
+                if (hit && slot < cap) dst[slot] = Entry::make(cv.x, row, count);
+                if (hit) lds.store(row, 0u, 0u);
+                n += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    return n;
+}
+
 template <typename CountT>
 __device__ __forceinline__ bool emit_partial_list_sparse(WaveLds<CountT> lds, uint32_t rows_pad, uint32_t max_quads, uint8_t *__restrict__ out,
                                                          uint32_t cap, uint32_t *n_out)

@@ -444,6 +444,11 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     // work anyway, and since an empty ring's first trip only issues loads the fetch ahead costs more instructions
     // than it hides: 64.1 M reads/s without against 62.6 M with, same box, N = 9 999)
     constexpr bool kFetchAhead = kMode == kTeamModeAccumulate || kMode == kTeamModeAccumulateLists;
+    // partial lists of an item that streamed one trip of the ring: listed from the cells the ring held
+#ifndef EPIK_AMD_CELL_LISTS
+#define EPIK_AMD_CELL_LISTS 1
+#endif
+    constexpr bool kCellLists = EPIK_AMD_CELL_LISTS != 0 && kMode == kTeamModeAccumulateLists;
     auto preload = [&](uint64_t descs) {
         if constexpr (kFetchAhead) {
 #pragma unroll
@@ -524,7 +529,9 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
             // nothing reached this slice's rows: they are as the last reset left them (wave-uniform)
             [[maybe_unused]] bool slice_untouched = false;
             // ... or an estimate of how much did, in chunks of 64 postings (0: no idea)
-            [[maybe_unused]] uint32_t sparse_hint = 0u, my_chunks = 0;
+            [[maybe_unused]] uint32_t sparse_hint = 0u, my_chunks = 0, my_padded = 0;
+            // AccumulateLists, an item whose stream is one trip of the ring: the cells the ring held
+            [[maybe_unused]] uint32_t trip_cells[kTeamRing];
             if constexpr (kMode == kTeamModeFinish) {
                 // second half of a k-mer-space-sharded placement: the slice's totals come back from HBM, with
                 // the read's ambiguous record (the average of the first ambiguous key that reached the branch
@@ -582,7 +589,6 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 }
             } else {
             // ---- exact k-mers, read order (place.cpp:349-371): this slice's descriptor list, a round at a time
-            uint32_t my_padded;
             const uint64_t *__restrict__ my_list = slice_list(word, (int)(kFrontHdrWords + pass * W + wave), my_padded, &my_chunks);
             slice_untouched = my_chunks == 0;
             sparse_hint = my_chunks;
@@ -597,10 +603,17 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
 #ifdef EPIK_AMD_ABLATION
                 if (p.ablate & 8u) continue;  // (timing experiments: nothing streamed)
 #endif
-                if (kFetchAhead && pass == 0 && r0 == 0)
+                // (partial lists: the cells the ring held stay -- of a stream of one trip, the rows it touched)
+                if constexpr (kCellLists) {
+                    if (kFetchAhead && pass == 0 && r0 == 0)
+                        stream_round<TeamChunks, CountT, (int)kTeamRing, true>(p, lds.desc, n_round, score_top, count_top, &pre, n_chunks, trip_cells);
+                    else
+                        stream_round<TeamChunks, CountT, (int)kTeamRing, false>(p, lds.desc, n_round, score_top, count_top, nullptr, n_chunks, trip_cells);
+                } else if (kFetchAhead && pass == 0 && r0 == 0) {
                     stream_round<TeamChunks, CountT, (int)kTeamRing, true>(p, lds.desc, n_round, score_top, count_top, &pre, n_chunks);
-                else
+                } else {
                     stream_round<TeamChunks, CountT, (int)kTeamRing, false>(p, lds.desc, n_round, score_top, count_top, nullptr, n_chunks);
+                }
                 STREAM_STAMP(1)  // stream
             }
             // the wave's next read: its first chunks' postings, on their way under what follows
@@ -628,6 +641,14 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
                 const bool fits = first + room <= tp.sparse_entries_cap;
                 uint32_t n_out = 0;
                 bool done = slice_untouched;  // (a shard's lists reach a small part of a slice: nothing, or a few dozen quads)
+                if constexpr (kCellLists) {
+                    if (!done && my_padded == kTeamRing) {
+                        if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
+                        n_out = emit_partial_list_cells<CountT, (int)kTeamRing>(lds, rows_pad, trip_cells, my_chunks,
+                                                                               tp.sparse_entries + first * PartialEntry<CountT>::kBytes, fits ? room : 0u);
+                        done = true;
+                    }
+                }
                 if constexpr (kSparseCounts) {
                     if (!done && my_chunks <= tp.sparse_chunks) {
                         if (lane == 0) lds.store(rows_pad - 1u, 0u, 0u);  // the dummy row of the out-of-range lanes
