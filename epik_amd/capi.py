@@ -43,6 +43,7 @@ EXPORTS = (
     "epik_amd_placer_accumulate_lists_device",
     "epik_amd_placer_finish_lists_device",
     "epik_amd_placer_last_path",
+    "epik_amd_placer_stream_build",
     "epik_amd_placer_place_sharded",
     "epik_amd_placer_release_scratch",
     "epik_amd_placer_set_wide_counts",
@@ -200,6 +201,8 @@ def load() -> ctypes.CDLL:
     lib.epik_amd_placer_place_sharded.argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, vp, vp, u64, vp, vp, vp]
     lib.epik_amd_placer_release_scratch.restype = i32
     lib.epik_amd_placer_release_scratch.argtypes = [vp]
+    lib.epik_amd_placer_stream_build.restype = i32
+    lib.epik_amd_placer_stream_build.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     lib.epik_amd_placer_last_path.restype = i32
     lib.epik_amd_placer_last_path.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.epik_amd_placer_plan.restype = i32

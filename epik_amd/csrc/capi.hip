@@ -1050,6 +1050,18 @@ int epik_amd_placer_finish_lists_device(epik_amd_placer *p, const void *d_seq_of
                   static_cast<hipStream_t>(stream), shard);
 }
 
+int epik_amd_placer_stream_build(const epik_amd_placer *p, uint32_t *wide, uint32_t *sparse_quads)
+{
+    if (!p || !wide || !sparse_quads) return fail(EPIK_AMD_ERR_INVALID, "null argument");
+    *wide = *sparse_quads = 0;
+    if (!p->team || !p->team_front) return EPIK_AMD_OK;
+    const bool is_wide = epik_amd::team_stream_is_wide(p->team_waves, p->geo[p->counts].stream_lds_bytes);
+    *wide = is_wide ? 1u : 0u;
+    // (the touched-quad epilogue is compiled into the wide build, for 8- and 16-bit counts)
+    *sparse_quads = is_wide && p->counts != epik_amd::kCounts32 ? p->sparse_quads : 0u;
+    return EPIK_AMD_OK;
+}
+
 int epik_amd_placer_last_path(const epik_amd_placer *p, uint32_t *path)
 {
     if (!p || !path) return fail(EPIK_AMD_ERR_INVALID, "null argument");

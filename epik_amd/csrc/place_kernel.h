@@ -164,6 +164,7 @@ hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipS
 hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream);
 constexpr size_t kTeamPartialBytes = 24;  // sizeof(TeamPartial) (place_device.hpp)
 hipError_t set_team_stream_lds_limit(int waves, int counts, size_t lds_bytes);
+bool team_stream_is_wide(int waves, size_t lds_bytes);  // the build launch_team_stream picks (EPIK_AMD_STREAM_WIDE overrides the rule)
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream);
 

@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "team_epilogue.hpp"
@@ -947,11 +948,25 @@ hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipS
     return hipGetLastError();
 }
 
+// Which build of the streaming kernel a geometry gets: db_layout.h's rule, or -- EPIK_AMD_STREAM_WIDE=1 / 0, tests --
+// the wide build whatever the slices' size (2 and 4 slices per pass have one) / the lean one.  The wide build holds
+// the slice epilogue over the touched quads (team_epilogue.hpp), which the small trees of the parity tests would
+// otherwise never reach.
+bool team_stream_is_wide(int waves, size_t lds_bytes)
+{
+    // (read at every call: a handful per launch, and the tests create placers of several kinds in one process)
+    const char *e = std::getenv("EPIK_AMD_STREAM_WIDE");
+    const int forced = e && e[0] == '1' ? 1 : e && e[0] == '0' ? 0 : -1;
+    if (forced == 1) return waves <= 4;
+    if (forced == 0) return false;
+    return stream_wide(waves, lds_bytes);
+}
+
 hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
                               hipStream_t stream, const SparseSources *sources)
 {
     const SparseSources src = sources ? *sources : SparseSources{};
-    return stream_dispatch(waves, counts, mode, stream_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
+    return stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
         hipLaunchKernelGGL((team_stream_kernel<W, C, M, kWide>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp, src);
         return hipGetLastError();
     });
@@ -967,7 +982,7 @@ hipError_t set_team_stream_lds_limit(int waves, int counts, size_t lds_bytes)  /
 {
     hipError_t err = hipSuccess;
     for (int mode = 0; mode < 5 && err == hipSuccess; ++mode)
-        err = stream_dispatch(waves, counts, mode, stream_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
+        err = stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M, kWide>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
         });
@@ -976,7 +991,7 @@ hipError_t set_team_stream_lds_limit(int waves, int counts, size_t lds_bytes)  /
 
 hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
 {
-    return stream_dispatch(waves, counts, kTeamModePlace, stream_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
+    return stream_dispatch(waves, counts, kTeamModePlace, team_stream_is_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C, M, kWide>, kStreamWaves * 64,
                                                             lds_bytes);
     });

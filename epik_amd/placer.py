@@ -349,6 +349,13 @@ class Placer:
         capi.check(self._lib.epik_amd_placer_last_path(self._handle, ctypes.byref(out)))
         return int(out.value)
 
+    def stream_build(self) -> dict:
+        """Which build of the streaming kernel a large-tree placer launches with its current count width, and how many
+        touched quads an item may have to take the touched-quad epilogue (`epik_amd_placer_stream_build`)."""
+        wide, quads = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        capi.check(self._lib.epik_amd_placer_stream_build(self._handle, ctypes.byref(wide), ctypes.byref(quads)))
+        return {"wide": bool(wide.value), "sparse_quads": int(quads.value)}
+
     def choose_counts(self, longest_read: int) -> None:
         """Width of the per-branch counts for the device entry points, chosen as `place_packed`
         chooses it from the batch (`epik_amd_placer_choose_counts`)."""

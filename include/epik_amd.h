@@ -328,6 +328,11 @@ int epik_amd_placer_place_sharded(epik_amd_placer *const *shards, uint32_t n_sha
 #define EPIK_AMD_PATH_TEAM_ONE_KERNEL 1u /* team_place_kernel: one workgroup per read */
 #define EPIK_AMD_PATH_TEAM_STREAMED 2u   /* team_front_kernel + team_stream_kernel + team_merge_kernel (+ the other for the rest) */
 int epik_amd_placer_last_path(const epik_amd_placer *p, uint32_t *path);
+/* What the streaming kernel of a large-tree placer is, with the handle's current count width (diagnostics, tests):
+ * *wide = 1: the build for slices so large that LDS keeps a CU to twelve waves, which holds the slice epilogue over
+ * the touched quads; *sparse_quads = how many touched quads (4 rows each) an item may have to take that epilogue
+ * (0: never).  Both 0 for a placer of the one-wavefront kernel. */
+int epik_amd_placer_stream_build(const epik_amd_placer *p, uint32_t *wide, uint32_t *sparse_quads);
 
 /* Gives back what the handle's launches have grown and kept: the scratch of large-tree launches (descriptor pool,
  * headers, slice results: up to ~1 GB after batches of a million reads), the staging buffers of the host entry

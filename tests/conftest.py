@@ -35,14 +35,14 @@ def select_kernel(monkeypatch, name):
     (paired, filtered, packed, compact), or teamW[xP] -- the team placement as front kernel +
     streaming kernel (team_stream.hip) --, teamW[xP]-classic -- team_place_kernel alone --, or
     teamW[xP]-smallpool -- a descriptor pool so small that some reads of a batch fall to
-    team_place_kernel behind the streaming kernel; teamW[xP]-sparse / -dense -- the streaming kernel's slice
-    epilogue over the touched quads (team_epilogue.hpp) wherever their list holds them / nowhere (by itself it
-    is taken by slices of 512 rows or more that streamed little).  A layout of the one-wavefront kernel with -runs: lists that
+    team_place_kernel behind the streaming kernel; teamW[xP]-sparse / -dense -- the WIDE build of the streaming
+    kernel (EPIK_AMD_STREAM_WIDE=1: by itself only large slices get it) with its slice epilogue over the touched quads
+    (team_epilogue.hpp) wherever their list holds them / nowhere.  A layout of the one-wavefront kernel with -runs: lists that
     are one ascending run of branches stored without their cells (the kernels with the run path).  Any of them with -fewblocks: a device that holds two
     workgroups (EPIK_AMD_MAX_BLOCKS), so that the waves of a test-sized batch place several reads one after
     the other on the grids of a million-read batch (capi.hip: spread_grid)."""
     for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT", "EPIK_AMD_MAX_BLOCKS", "EPIK_AMD_RUNS",
-                "EPIK_AMD_TEAM_SPARSE"):
+                "EPIK_AMD_TEAM_SPARSE", "EPIK_AMD_STREAM_WIDE"):
         monkeypatch.delenv(var, raising=False)
     if name.endswith("-runs"):  # the packed lists run-coded (by itself the builder does that for large databases only)
         name = name[:-len("-runs")]
@@ -59,8 +59,12 @@ def select_kernel(monkeypatch, name):
             monkeypatch.setenv("EPIK_AMD_TEAM_POOL", "2048")
         elif variant == "sparse":  # the slice epilogue over the touched quads whatever the slice's size
             monkeypatch.setenv("EPIK_AMD_TEAM_SPARSE", "always")
-        elif variant == "dense":  # ... and never
+            # (that epilogue lives in the WIDE build of the streaming kernel, which by itself only slices of ~2 200
+            # rows and more get: forced onto the small trees of the tests -- with 8 slices per pass there is none)
+            monkeypatch.setenv("EPIK_AMD_STREAM_WIDE", "1")
+        elif variant == "dense":  # ... and never: the wide build with its dense epilogue
             monkeypatch.setenv("EPIK_AMD_TEAM_SPARSE", "0")
+            monkeypatch.setenv("EPIK_AMD_STREAM_WIDE", "1")
         else:
             assert variant == "", name
     else:

@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact", "paired-runs", "filtered-runs", "packed-runs",
-                                      "team4", "team8", "team4x3", "team2", "team2x3", "team2-classic", "team2-smallpool", "team2-sparse", "team4-sparse", "team8x2-sparse", "team4-dense",
+                                      "team4", "team8", "team4x3", "team2", "team2x3", "team2-classic", "team2-smallpool", "team2-sparse", "team4-sparse", "team4x2-sparse", "team4-dense",
                                       "team4-classic", "team4x3-classic", "team4-smallpool", "team8x2-smallpool",
                                       "paired-fewblocks", "team4-fewblocks", "team8x2-fewblocks", "team4-classic-fewblocks"])
 def db_layout(request, monkeypatch):
@@ -29,6 +29,29 @@ def db_layout(request, monkeypatch):
     pool too small for the batch (-smallpool: both, mixed)."""
     select_kernel(monkeypatch, request.param)
     return request.param
+
+
+def test_the_sparse_variants_reach_the_touched_quad_epilogue(gpu_available, small_case, db_layout):
+    """teamW-sparse / -dense run the WIDE build of the streaming kernel on the small trees of these tests
+    (EPIK_AMD_STREAM_WIDE=1), -sparse with the slice epilogue over the touched quads open to every item of up to 256
+    touched quads -- every item of a tree of a few hundred branches: the tie overflow and the tiny-score division of
+    team_epilogue.hpp are then what test_many_ties_overflow_candidate_buffer and test_underflowing_scores_zero_lwr
+    exercise under these variants -- and -dense with it closed."""
+    assert gpu_available
+    from epik_amd.placer import Placer
+    tree, db = small_case
+    with Placer.from_synth(db) as pl:
+        for longest in (40, 300, 40_000):   # 8-, 16-, 32-bit counts
+            pl.choose_counts(longest)
+            build = pl.stream_build()
+            if db_layout.endswith("-sparse"):
+                assert build["wide"] and build["sparse_quads"] == (256 if longest < 40_000 else 0), (longest, build)
+            elif db_layout.endswith("-dense"):
+                assert build["wide"] and build["sparse_quads"] == 0
+            elif db_layout.startswith("team") and "classic" not in db_layout:
+                assert not build["wide"]   # a small tree by itself: the lean build
+            else:
+                assert build == {"wide": False, "sparse_quads": 0}
 
 
 @pytest.fixture(scope="module")
