@@ -301,7 +301,7 @@ int plan_team_geometry(uint32_t num_branches, uint32_t keep_at_most, uint32_t al
     // cost one fetch (the front kernel is bound by exactly these fetches).  Every entry is stored twice.
     // (a shard's table is not paired: of two consecutive k-mers of a read at most one is the shard's as a rule,
     // and the kernels do not fetch for the other)
-    plan.team_paired = alphabet_size == 4 && team_entry_bytes(c.waves) == 16 && kmer_size >= 2 && plan.shard_count == 1 &&
+    plan.team_paired = alphabet_size == 4 && team_entry_bytes(c.waves) <= 16 && kmer_size >= 2 && plan.shard_count == 1 &&
                        !(std::getenv("EPIK_AMD_TEAM_TABLE") && std::strcmp(std::getenv("EPIK_AMD_TEAM_TABLE"), "plain") == 0);
     plan.table_keys = shard_keys(num_keys, plan.shard_index, plan.shard_count);
     plan.table_bytes = (uint64_t)c.passes * plan.table_keys * (uint64_t)team_entry_bytes(c.waves) * (plan.team_paired ? 2u : 1u);

@@ -74,8 +74,10 @@ constexpr uint32_t wave_kernel_resident_waves(uint32_t n_pad, int counts)
 constexpr uint32_t kTeamRing = EPIK_AMD_TEAM_RING;  // posting-chunk loads in flight per wave (16 measured slower: r02 notes in DESIGN.md)
 constexpr uint32_t kTeamDescCap = 64u - kTeamRing;  // chunk descriptors per slice and round (a multiple of the ring; + one trip of spare entries: 64)
 constexpr uint32_t kTeamCandCap = 60;  // top-k candidates of a slice (+ 4 spare entries = the list's 64)
-// bytes of one table entry {u32 line, u16 len[W]}
-constexpr int team_entry_bytes(int waves) { return waves <= 6 ? 16 : waves <= 14 ? 32 : 64; }
+// bytes of one table entry {u32 line, u16 len[W]}: 8 with two slices per pass (round 5: the front kernel is bound by the
+// table lines it fetches, and a block of the paired table is then 64 bytes -- two blocks to a line, the table of a
+// k = 10 database 16 MB instead of 32), else padded to 16 / 32 / 64
+constexpr int team_entry_bytes(int waves) { return waves <= 2 ? 8 : waves <= 6 ? 16 : waves <= 14 ? 32 : 64; }
 // LDS rows of a slice: its branches + the dummy row, to a multiple of 16 (the epilogue's sweeps mask their last trip)
 constexpr uint32_t team_rows_pad(uint32_t slice_rows) { return (slice_rows + 1u + 15u) & ~15u; }
 constexpr uint32_t team_slice_bytes(uint32_t rows_pad, int counts) { return (rows_pad * (4u + (1u << counts)) + 15u) & ~15u; }

@@ -24,19 +24,28 @@ struct TeamEntry {
     static constexpr int kWords = team_entry_bytes(W) / 4;
     uint32_t line;
     uint32_t len[W];
-    // the entry as it lies in HBM (kWords / 4 times 16 bytes), and its fields from that
-    static constexpr int kQuads = kWords / 4;
+    // the entry as it lies in HBM -- kQuads pieces of 16 bytes, or (two slices per pass) one of 8 -- and its fields from that
+    typedef std::conditional_t<(kWords >= 4), uint4, uint2> raw_t;
+    static constexpr int kRawWords = (int)(sizeof(raw_t) / 4);
+    static constexpr int kQuads = kWords / kRawWords;
+    __device__ static __forceinline__ raw_t zero_raw()
+    {
+        if constexpr (kRawWords == 4)
+            return make_uint4(0u, 0u, 0u, 0u);
+        else
+            return make_uint2(0u, 0u);
+    }
     // `position`: where in the read the k-mer starts (its parity picks the form a paired table holds it in;
     // a lookup by code alone passes 0)
     __device__ static __forceinline__ void fetch(const TeamParams &tp, uint32_t pass, uint32_t key, uint32_t position,
-                                                 uint4 (&raw)[kQuads])
+                                                 raw_t (&raw)[kQuads])
     {
         uint64_t index = (uint64_t)pass * tp.num_keys + key;
         if (tp.shard_count > 1u) {  // (wave-uniform) a k-mer-space shard: the codes of the other shards are not looked up
             const uint32_t q = key / tp.shard_count;
             if (key - q * tp.shard_count != tp.shard_index) {
 #pragma unroll
-                for (int i = 0; i < kQuads; ++i) raw[i] = make_uint4(0u, 0u, 0u, 0u);
+                for (int i = 0; i < kQuads; ++i) raw[i] = zero_raw();
                 return;
             }
             index = (uint64_t)pass * tp.num_keys + q;
@@ -47,19 +56,21 @@ struct TeamEntry {
             const uint32_t slot = as_prefix ? 4u + (key & 3u) : key >> shift;
             index = ((uint64_t)pass * (tp.num_keys / 4u) + block) * 8u + slot;
         }
-        const uint4 *e = reinterpret_cast<const uint4 *>(tp.team_table + index * (kWords * 4u));
+        const raw_t *e = reinterpret_cast<const raw_t *>(tp.team_table + index * (kWords * 4u));
 #pragma unroll
         for (int i = 0; i < kQuads; ++i) raw[i] = e[i];
     }
-    __device__ __forceinline__ void unpack(const uint4 (&raw)[kQuads])
+    __device__ __forceinline__ void unpack(const raw_t (&raw)[kQuads])
     {
         uint32_t w[kWords];
 #pragma unroll
         for (int i = 0; i < kQuads; ++i) {
-            w[4 * i] = raw[i].x;
-            w[4 * i + 1] = raw[i].y;
-            w[4 * i + 2] = raw[i].z;
-            w[4 * i + 3] = raw[i].w;
+            w[kRawWords * i] = raw[i].x;
+            w[kRawWords * i + 1] = raw[i].y;
+            if constexpr (kRawWords == 4) {
+                w[4 * i + 2] = raw[i].z;
+                w[4 * i + 3] = raw[i].w;
+            }
         }
         line = w[0];
 #pragma unroll
@@ -67,7 +78,7 @@ struct TeamEntry {
     }
     __device__ __forceinline__ void load(const TeamParams &tp, uint32_t pass, uint32_t key, uint32_t position = 0u)
     {
-        uint4 raw[kQuads];
+        raw_t raw[kQuads];
         fetch(tp, pass, key, position, raw);
         unpack(raw);
     }
@@ -346,6 +357,178 @@ __device__ __attribute__((noinline)) void team_merge(MergeParams p, CandPtr cand
 }
 
 
+
+// ---------------------------------------------------------------------------------
+// The same merge with SEVERAL reads to a wave (round 5).  A read's merge has S * keep_at_most slots -- 14 with two
+// slices per pass, 28 with four -- and team_merge_body gives it a whole wave: 50 of 64 lanes idle through the one
+// expensive thing in it, the double-precision 10^score of the rows that may be reported.  Here a read gets a GROUP of
+// L = 16 or 32 lanes (4 or 2 reads to a wave); everything a read's lanes share is computed by every lane of the
+// group from group reductions (DPP inside a row of 16 lanes; one ds_bpermute between the two rows of a group of 32),
+// there is no scalar branch on a read's values, and the ranking rotates the keys around the row (row_ror) instead of
+// pulling them out of the lanes one by one.  The arithmetic on a read's values is team_merge_body's, operation for
+// operation (the sums over the slices add in the same tree): the same rows, the same bits.
+// ---------------------------------------------------------------------------------
+template <int kCtrl>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    return __longlong_as_double((long long)dpp_u64<kCtrl>((uint64_t)__double_as_longlong(v)));
+}
+// reductions over a group of L lanes (L = 16: a DPP row; L = 32: two rows), the result in every lane of the group
+template <int L, typename T, typename Op, typename Move>
+__device__ __forceinline__ T group_reduce(T v, Op op, Move move)
+{
+    v = op(v, move(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+    v = op(v, move(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+    v = op(v, move(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+    v = op(v, move(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+    if constexpr (L == 32) {
+        T other;
+        if constexpr (sizeof(T) == 8) {
+            const uint64_t bits = sizeof(T) == 8 ? *reinterpret_cast<const uint64_t *>(&v) : 0ull;
+            const uint64_t o = shfl_xor_u64(bits, 16);
+            other = *reinterpret_cast<const T *>(&o);
+        } else {
+            const uint32_t o = (uint32_t)__shfl_xor((int)*reinterpret_cast<const uint32_t *>(&v), 16);
+            other = *reinterpret_cast<const T *>(&o);
+        }
+        v = op(v, other);
+    }
+    return v;
+}
+template <int L>
+__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v)
+{
+    return group_reduce<L>(v, [](uint32_t a, uint32_t b) { return a + b; }, [](uint32_t x, auto c) { return dpp_u32<decltype(c)::value>(x); });
+}
+template <int L>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v)
+{
+    return group_reduce<L>(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }, [](uint32_t x, auto c) { return dpp_u32<decltype(c)::value>(x); });
+}
+template <int L>
+__device__ __forceinline__ uint32_t group_or_u32(uint32_t v)
+{
+    return group_reduce<L>(v, [](uint32_t a, uint32_t b) { return a | b; }, [](uint32_t x, auto c) { return dpp_u32<decltype(c)::value>(x); });
+}
+template <int L>
+__device__ __forceinline__ double group_sum_f64(double v)
+{
+    return group_reduce<L>(v, [](double a, double b) { return a + b; }, [](double x, auto c) { return dpp_f64<decltype(c)::value>(x); });
+}
+template <int L>
+__device__ __forceinline__ double group_max_f64(double v)
+{
+    return group_reduce<L>(v, [](double a, double b) { return a > b ? a : b; }, [](double x, auto c) { return dpp_f64<decltype(c)::value>(x); });
+}
+// how many keys of the lane's group are larger than its own: the keys of the row rotated past it (row_ror:1 .. 15),
+// then (L = 32) the other row's
+template <int L>
+__device__ __forceinline__ uint32_t group_rank(uint64_t key)
+{
+    uint32_t rank = 0;
+    auto pass = [&](uint64_t v, auto first) {
+        if constexpr (decltype(first)::value) rank += v > key ? 1u : 0u;
+        [&]<int... N>(std::integer_sequence<int, N...>) {
+            ((rank += dpp_u64<0x121 + N>(v) > key ? 1u : 0u), ...);  // row_ror:1 .. row_ror:15
+        }(std::make_integer_sequence<int, 15>{});
+    };
+    pass(key, std::false_type{});
+    if constexpr (L == 32) pass(shfl_xor_u64(key, 16), std::true_type{});
+    return rank;
+}
+
+// what a lane of a read's group holds of the read: its slot of the slices' ranked rows, and (the first S lanes) a slice's share
+struct PackedMergeInputs {
+    uint32_t flags, len;
+    v4u mine;
+    uint32_t touched, relative;
+    float ref_score;
+    double sum;
+};
+template <int L>
+__device__ __forceinline__ PackedMergeInputs load_packed_merge_inputs(const TeamParams &tp, const v4u *rows_out, const TeamPartial *sums_out,
+                                                                     uint64_t read, bool valid, uint32_t n_slices, uint32_t keep)
+{
+    const uint32_t slot = (uint32_t)lane_id() % (uint32_t)L;
+    PackedMergeInputs in;
+    in.flags = kFrontSlow, in.len = 0;  // (a group behind the batch's end: nothing to merge)
+    in.mine = v4u{0u, 0u, 0u, 0u};
+    in.touched = in.relative = 0u;
+    in.ref_score = 0.0f;
+    in.sum = 0.0;
+    if (valid) {
+        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(tp.front_hdr + read * tp.front_hdr_stride);
+        in.flags = hdr[1], in.len = hdr[2];
+        if (slot < n_slices * keep) in.mine = rows_out[read * n_slices * keep + slot];
+        if (slot < n_slices) {
+            const TeamPartial &pt = sums_out[read * n_slices + slot];
+            in.touched = pt.touched, in.relative = pt.relative, in.ref_score = pt.ref_score, in.sum = pt.sum;
+        }
+    }
+    return in;
+}
+
+// one read per group of L lanes (S * keep_at_most <= L): team_merge_body<true>, lane for lane
+template <int L>
+__device__ __forceinline__ void team_merge_packed(const MergeParams &p, uint64_t read, bool valid, const PackedMergeInputs &in)
+{
+    const uint32_t slot = (uint32_t)lane_id() % (uint32_t)L;
+    const uint32_t keep = p.keep_at_most;
+    // reads without rows to merge (team_merge_kernel: settled)
+    if (valid && (in.flags & (kFrontNoRows | kFrontTooNarrow)) && !(in.flags & kFrontSlow) && slot == 0)
+        p.n_rows[read] = (in.flags & kFrontNoRows) ? 0u : kCountsTooNarrow;
+    const bool live = valid && !(in.flags & (kFrontSlow | kFrontNoRows | kFrontTooNarrow));  // the same in a group's lanes
+    const uint64_t n_kmers = (uint64_t)in.len - p.kmer_size + 1u;
+    const float k_f = (float)p.kmer_size;
+    const float thr_score = __fdiv_rn(__fmul_rn((float)n_kmers, p.log_threshold), k_f);  // :175 / :146-147
+    constexpr float kLog2Of10 = 3.32192809488736f;
+    const uint32_t touched = group_sum_u32<L>(in.touched);
+    v4u mine = in.mine;
+    uint32_t n_sel = keep < touched ? keep : touched;  // :137
+    if (touched == 0) {  // :141-152: first keep_at_most branches at the threshold score
+        n_sel = keep;
+        mine = slot < keep ? v4u{ord_f32(thr_score), slot, 0u, 0u} : v4u{0u, 0u, 0u, 0u};
+    }
+    const uint64_t key = mine.x ? (((uint64_t)mine.x << 32) | (uint64_t)(~mine.y)) : 0ull;
+    const uint32_t rank = group_rank<L>(key);
+    const float best_score = touched == 0 ? thr_score : unord_f32(group_max_u32<L>(mine.x));  // the row of rank 0
+    // 10^score of the rows that may be reported (:254): once per row, the lanes side by side
+    const bool my_row = live && mine.x != 0 && rank < n_sel;
+    const double my_power = my_row ? pow10_f64((double)unord_f32(mine.x)) : 0.0;
+    const double best_power = group_max_f64<L>(my_power);  // (the largest score's)
+    // ---- sum_scores (:164-184) ------------------------------------------------------------------
+    const float ref_score = fmaxf(best_score, thr_score);
+    const bool counts = in.touched != 0;
+    const double scaled = in.sum * (double)__builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(in.ref_score, ref_score), kLog2Of10));
+    double rel = group_sum_f64<L>(counts && in.relative ? scaled : 0.0);
+    const double absolute = group_sum_f64<L>(counts && !in.relative ? in.sum : 0.0);
+    const float not_placed = (float)p.num_branches - (float)touched;  // :174
+    double score_sum;
+    if (ref_score > -280.0f) {
+        if (not_placed != 0.0f)
+            rel += (double)(not_placed * __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(thr_score, ref_score), kLog2Of10)));
+        const double ref_power = (ref_score == best_score) ? best_power : pow10_f64((double)ref_score);
+        score_sum = ref_power * rel + absolute;
+    } else {
+        score_sum = (double)not_placed * pow10_f64((double)thr_score) + absolute;  // :174-183, all double
+    }
+    const double keep_factor = (score_sum == 0.0) ? 0.0 : p.keep_factor;  // :247-251
+    const double best_ratio = (score_sum == 0.0 || best_power == 0.0) ? 0.0 : best_power / score_sum;  // :191
+    const double ratio_threshold = best_ratio * keep_factor;                                           // :192
+    // ---- LWR (:241-264), filter_by_ratio (:188-199): which ranks stay --------------------------
+    const double lwr = (my_row && score_sum != 0.0 && my_power != 0.0) ? my_power / score_sum : 0.0;  // :255-262
+    const uint32_t kept_ranks = group_or_u32<L>((my_row && lwr >= ratio_threshold) ? 1u << rank : 0u);  // :197 (rank < n_sel <= 32)
+    if (my_row && ((kept_ranks >> rank) & 1u)) {
+        const uint32_t out_slot = (uint32_t)__popc(kept_ranks & ((1u << rank) - 1u));
+        epik_amd_placement out;
+        out.branch = mine.y;
+        out.score = unord_f32(mine.x);
+        out.lwr = lwr;
+        p.rows[read * keep + out_slot] = out;
+        if (p.kmer_counts) p.kmer_counts[read * keep + out_slot] = mine.z;
+    }
+    if (live && slot == 0) p.n_rows[read] = (uint32_t)__popc(kept_ranks);
+}
 
 // ---------------------------------------------------------------------------------
 // Partial LISTS of a k-mer-space shard (include/epik_amd.h): what accumulate leaves per (read, slice) instead of

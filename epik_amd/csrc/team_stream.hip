@@ -65,7 +65,9 @@ __global__ __launch_bounds__(64, W <= 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1)
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint64_t null_desc = null_chunk(p);
     constexpr int T = kTilesPerPass;
-    extern __shared__ __align__(16) uint4 held[];  // [held_passes][T][kQuads][64]: the entries of a short read's tiles, by lane
+    typedef typename TeamEntry<W>::raw_t raw_t;
+    extern __shared__ __align__(16) unsigned char held_bytes[];
+    raw_t *held = reinterpret_cast<raw_t *>(held_bytes);  // [held_passes][T][kQuads][64]: the entries of a short read's tiles, by lane
     constexpr uint32_t kHeldPerPass = T * TeamEntry<W>::kQuads * kWave;
     unsigned long long chunk_at = 0;  // this wave's piece of the pool: next free descriptor, how many are left
     uint32_t chunk_left = 0;
@@ -121,11 +123,11 @@ __global__ __launch_bounds__(64, W <= 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1)
                 uint32_t acc[W];
 #pragma unroll
                 for (int s = 0; s < W; ++s) acc[s] = 0;
-                uint4 raw[T][TeamEntry<W>::kQuads];
+                raw_t raw[T][TeamEntry<W>::kQuads];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
 #pragma unroll
-                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = make_uint4(0u, 0u, 0u, 0u);
+                    for (int q = 0; q < TeamEntry<W>::kQuads; ++q) raw[t][q] = TeamEntry<W>::zero_raw();
                     if (exact[t]) TeamEntry<W>::fetch(tp, pass, tiles[t].key, (uint32_t)t * stride + (uint32_t)lane, raw[t]);
                 }
                 uint32_t plen[W];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64, W <= 4 ? (kLists ? 6 : EPIK_AMD_FRONT_OCC) : 1)
             if (one_group) {
 #pragma unroll 1
                 for (int t = 0; t < T; ++t) {
-                    uint4 raw[TeamEntry<W>::kQuads];
+                    raw_t raw[TeamEntry<W>::kQuads];
 #pragma unroll
                     for (int q = 0; q < TeamEntry<W>::kQuads; ++q)
                         raw[q] = held[pass * kHeldPerPass + (t * TeamEntry<W>::kQuads + q) * kWave + lane];
@@ -864,6 +866,40 @@ __global__ __launch_bounds__(256) void team_merge_kernel(TeamParams tp, uint32_t
     }
 }
 
+// The merge with 4 or 2 reads to a wave (team_device.hpp: team_merge_packed): a group of L lanes per read.
+template <int L>
+__global__ __launch_bounds__(256) void team_merge_packed_kernel(TeamParams tp, uint32_t n_slices)
+{
+    const PlaceParams &p = tp.base;
+    constexpr uint32_t kPerWave = 64u / (uint32_t)L;
+    const uint64_t waves_per_block = blockDim.x >> 6;
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    MergeParams mp;
+    mp.keep_at_most = p.keep_at_most;
+    mp.kmer_size = p.kmer_size;
+    mp.num_branches = p.num_branches;
+    mp.log_threshold = p.log_threshold;
+    mp.keep_factor = p.keep_factor;
+    mp.rows = p.rows;
+    mp.n_rows = p.n_rows;
+    mp.kmer_counts = p.kmer_counts;
+    const v4u *rows_out = static_cast<const v4u *>(tp.slice_rows_out);
+    const TeamPartial *sums_out = static_cast<const TeamPartial *>(tp.slice_sums_out);
+    const uint32_t group = (uint32_t)lane_id() / (uint32_t)L;
+    const uint64_t first = ((uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * kPerWave + group;
+    const uint64_t stride = n_waves * kPerWave;
+    if (first - group >= p.n_reads) return;  // (wave-uniform: the wave's first read)
+    // (a read is a chain of memory round trips around a few hundred instructions: the next reads' inputs are asked for
+    // before this wave works on the ones it has)
+    PackedMergeInputs cur = load_packed_merge_inputs<L>(tp, rows_out, sums_out, first, first < p.n_reads, n_slices, p.keep_at_most);
+    for (uint64_t read = first; read - group < p.n_reads; read += stride) {
+        const uint64_t next_read = read + stride;
+        const PackedMergeInputs next = load_packed_merge_inputs<L>(tp, rows_out, sums_out, next_read, next_read < p.n_reads, n_slices, p.keep_at_most);
+        team_merge_packed<L>(mp, read, read < p.n_reads, cur);
+        cur = next;
+    }
+}
+
 namespace {
 
 template <typename F>
@@ -974,7 +1010,16 @@ hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int m
 
 hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(team_merge_kernel, grid, dim3(256), 0, stream, tp, (uint32_t)waves * tp.passes);
+    // (grid: workgroups of four waves sized for a read per wave; with several reads to a wave fewer do)
+    const uint32_t n_slices = (uint32_t)waves * tp.passes, slots = n_slices * tp.base.keep_at_most;
+    const char *forced = std::getenv("EPIK_AMD_MERGE_PACKED");  // 0: a wave per read (tests, measurements)
+    const bool packed = !(forced && forced[0] == '0');
+    if (packed && slots <= 16u)
+        hipLaunchKernelGGL(team_merge_packed_kernel<16>, dim3((grid.x + 3u) / 4u), dim3(256), 0, stream, tp, n_slices);
+    else if (packed && slots <= 32u)
+        hipLaunchKernelGGL(team_merge_packed_kernel<32>, dim3((grid.x + 1u) / 2u), dim3(256), 0, stream, tp, n_slices);
+    else
+        hipLaunchKernelGGL(team_merge_kernel, grid, dim3(256), 0, stream, tp, n_slices);
     return hipGetLastError();
 }
 

@@ -146,10 +146,12 @@ def test_compact_layout(db, monkeypatch):
     assert rec["cell"].tolist() == (n_pad - 1 - db.values["branch"][keep].astype(np.int64)).tolist()
 
 
-@pytest.mark.parametrize("kernel,waves,table", [("team4", 4, "paired"), ("team4", 4, "plain"), ("team8", 8, "plain")])
+@pytest.mark.parametrize("kernel,waves,table", [("team4", 4, "paired"), ("team4", 4, "plain"), ("team8", 8, "plain"),
+                                                ("team2", 2, "paired"), ("team2", 2, "plain")])
 def test_team_layout(db, kernel, waves, table, monkeypatch):
     """Every list as W sublists, one per slice of the branch range, in the list's order; cells local to
-    the slice; one {line, len[W]} entry per code -- with 4 letters and 16-byte entries twice, in the block
+    the slice; one {line, len[W]} entry per code (8 bytes with two slices per pass, else 16 / 32) -- with 4 letters and
+    entries of up to 16 bytes twice, in the block
     of the (k-1)-mer it ends with (slot = its first letter) and in the block of the (k-1)-mer it starts
     with (slot = 4 + its last letter)."""
     monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
@@ -160,7 +162,7 @@ def test_team_layout(db, kernel, waves, table, monkeypatch):
     rows = plan.slice_rows
     assert rows * waves >= db.num_branches > rows * (waves - 1)
     rows_pad = (rows + 1 + 15) // 16 * 16
-    entry_bytes = 16 if waves == 4 else 32
+    entry_bytes = {2: 8, 4: 16, 8: 32}[waves]
     paired = table == "paired"
     assert len(table_bytes) == db.num_keys * entry_bytes * (2 if paired else 1)
     blocks = db.num_keys // 4
@@ -219,7 +221,7 @@ def test_team_layout_of_a_shard(db, kernel, waves, how, monkeypatch):
     assert plan.kernel == 1 and plan.layout == 5 and plan.team_waves == waves
     rows = plan.slice_rows
     rows_pad = (rows + 1 + 15) // 16 * 16
-    entry_bytes = 16 if waves <= 4 else 32
+    entry_bytes = {2: 8, 4: 16, 8: 32}[waves]
     n_mine = len(range(g, db.num_keys, G))
     assert len(table_bytes) == n_mine * entry_bytes
     # (the whole database's table: every code, twice where it is paired)
@@ -391,7 +393,7 @@ def test_plan_from_the_sizes_alone_is_the_plan_of_the_database(case, shard, monk
         assert sized.posting_bytes_is_bound == 1
         assert real.posting_bytes <= sized.posting_bytes <= real.posting_bytes * 1.08
         if G > 1:   # a shard's table: an entry per code of the shard, unpaired
-            assert real.table_bytes == len(range(g, 4 ** db.kmer_size, G)) * 16
+            assert real.table_bytes == len(range(g, 4 ** db.kmer_size, G)) * (8 if real.team_waves == 2 else 16)
     else:
         assert sized.posting_bytes_is_bound == 0 and sized.posting_bytes == real.posting_bytes
     if case == "nucl-wave-runs":
