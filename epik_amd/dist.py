@@ -394,12 +394,18 @@ def _exchange_lists(engine, parts: Partials, n_reads: int, dist, rank: int, worl
     # the part sizes AND the room this rank had: every rank must know whether ANY rank's lists found no room before
     # the first data collective -- a rank that overflowed alone and left here by itself would meet the others'
     # all-to-all with another collective (capacities differ per shard: so does what overflows)
+    # (... and the width of its entries: the finisher reads every shard's list in ONE format -- ranks whose
+    # choose_counts differ, devices of two kinds or a width forced on one, would mis-size the all-to-all and mis-read
+    # what arrives; shard_place.hip makes its handles agree on the widest, here the disagreement is an error every rank sees)
     mine = torch.cat([sizes_mine.to(torch.int64).reshape(-1),
-                      torch.tensor([int(parts.cap)], dtype=torch.int64, device=sizes_mine.device)]).contiguous()
-    gathered = torch.empty(world * (world + 1), dtype=torch.int64, device=mine.device)
+                      torch.tensor([int(parts.cap), int(eb)], dtype=torch.int64, device=sizes_mine.device)]).contiguous()
+    gathered = torch.empty(world * (world + 2), dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(gathered, mine)
-    gathered = gathered.cpu().view(world, world + 1)
-    sizes, caps = gathered[:, :world], gathered[:, world]   # sizes[g][r]: entries shard g holds for the reads of rank r
+    gathered = gathered.cpu().view(world, world + 2)
+    sizes, caps, widths = gathered[:, :world], gathered[:, world], gathered[:, world + 1]   # sizes[g][r]: entries shard g holds for the reads of rank r
+    if bool((widths != eb).any()):
+        raise RuntimeError(f"k-mer-space shard: the ranks' partial lists have entries of {sorted(set(int(w) for w in widths))} bytes "
+                           "(different count widths: force one with epik_amd_placer_set_wide_counts on every rank)")
     mine_total = int(sizes[rank].sum())
     if bool((sizes.sum(dim=1) > caps).any()):         # every rank leaves together; the caller repeats the accumulate
         return None, None, mine_total
@@ -464,7 +470,8 @@ def place_kmer_sharded_lists(engine, batches, dist, char_class=None, gather_to: 
                 if parts.done is not None:
                     parts.done.synchronize()
                 total = int(parts.part_entries.sum())
-            entries, index = [parts.entries[:total * engine.entry_bytes]], [parts.index]
+            # (the width of THIS batch's entries: the engine's may be the next batch's by now, whose accumulate is under way)
+            entries, index = [parts.entries[:total * (parts.entry_bytes or engine.entry_bytes)]], [parts.index]
             if per_owner:
                 my_slot, my_avg = slot, parts.amb_avg
             return engine.finish(batch, 0, n, entries, index, my_slot, my_avg)

@@ -64,7 +64,10 @@ jplace_writer::~jplace_writer()
 {
     try {
         wait_for_flush();
-    } catch (...) {  // (end() was not reached: an error is on its way up already)
+    } catch (const std::exception& e) {  // (end() was not reached: an error is on its way up already -- this one is said, not lost)
+        std::fprintf(stderr, "jplace: a write in flight failed while the writer was being torn down: %s\n", e.what());
+    } catch (...) {
+        std::fprintf(stderr, "jplace: a write in flight failed while the writer was being torn down\n");
     }
     if (_fd >= 0) ::close(_fd);
 }

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <cstddef>
@@ -268,6 +269,15 @@ phylo_kmer_db load(const std::string& filename, float mu, float omega, size_t ma
         kept_total += kept;
         if (kept) records.push_back(kmer_record{key, kept, first, n});
     }
+    // (the cut holds for the shards TOGETHER: with unevenly long lists over the residues of key % shard_count one shard
+    // may end up over the limit the user named for each -- said here, the load goes on: the limit is a budget, and the
+    // placer's own plan says what the device takes)
+    if (global_cut && kept_total > max_entries + max_entries / 8)
+        std::fprintf(stderr,
+                     "warning: --max-ram: shard %u of %u keeps %llu postings, %.0f %% over the %llu a shard was to keep "
+                     "(the cut is one position of the file for all shards; their lists are unevenly long)\n",
+                     shard_index, shard_count, (unsigned long long)kept_total,
+                     100.0 * ((double)kept_total / (double)max_entries - 1.0), (unsigned long long)max_entries);
     // ---- by k-mer code: the sparse CSR the C ABI takes
     std::sort(records.begin(), records.end(), [](const kmer_record& a, const kmer_record& b) { return a.key < b.key; });
     db._keys.resize(records.size());
