@@ -418,13 +418,24 @@ int create_impl(const epik_amd_placer_desc *d, uint32_t shard_index, uint32_t sh
             if (p->team_front) {
                 // the streaming kernel: its own workgroups (4 waves), LDS and registers; the grid a multiple of
                 // the workgroups that share a read
-                g.stream_lds_bytes = (uint32_t)epik_amd::stream_lds_bytes(g.lds_wave_bytes, desc_bytes);
-                uint32_t stream_per_cu = epik_amd::stream_resident_blocks(plan.team_waves, g.stream_lds_bytes);
-                CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts, g.stream_lds_bytes));
-                CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, g.stream_lds_bytes, &by_query));
-                stream_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(stream_per_cu, (uint32_t)std::max(by_query, 1)));
-                const uint32_t parts = epik_amd::stream_parts(plan.team_waves);
-                g.stream_blocks = std::max(parts, (uint32_t)prop.multiProcessorCount * stream_per_cu / parts * parts);
+                // [0]: the halves of a sharded placement, workgroups of four; [1]: the one-pass placement, of four or two
+                g.stream_bw[0] = 4;
+                g.stream_bw[1] = epik_amd::stream_block_waves(plan.team_waves, g.lds_wave_bytes, desc_bytes);
+                if (const char *e = std::getenv("EPIK_AMD_STREAM_BLOCK")) g.stream_bw[1] = e[0] == '2' ? 2 : e[0] == '4' ? 4 : g.stream_bw[1];
+                for (int v = 0; v < 2; ++v) {
+                    const int bw = g.stream_bw[v];
+                    g.stream_lds_bytes[v] = (uint32_t)epik_amd::stream_lds_bytes(g.lds_wave_bytes, desc_bytes, bw);
+                    uint32_t stream_per_cu = epik_amd::stream_resident_blocks(plan.team_waves, g.stream_lds_bytes[v], bw);
+                    for (int mode = 0; mode < 5; ++mode) {
+                        if ((v == 1) != (mode == epik_amd::kTeamModePlace)) continue;
+                        CREATE_TRY(epik_amd::set_team_stream_lds_limit(plan.team_waves, counts, mode, bw, g.stream_lds_bytes[v]));
+                    }
+                    CREATE_TRY(epik_amd::team_stream_occupancy(plan.team_waves, counts, v == 1 ? epik_amd::kTeamModePlace : epik_amd::kTeamModeAccumulateLists,
+                                                               bw, g.stream_lds_bytes[v], &by_query));
+                    stream_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(stream_per_cu, (uint32_t)std::max(by_query, 1)));
+                    const uint32_t parts = epik_amd::stream_parts(plan.team_waves, bw);
+                    g.stream_blocks[v] = std::max(parts, (uint32_t)prop.multiProcessorCount * stream_per_cu / parts * parts);
+                }
             }
         }
         if (p->team_front) {
@@ -655,8 +666,9 @@ static int counts_for(const epik_amd_placer *p, uint64_t longest)
     if (kmers >= 32768u) return epik_amd::kCounts32;
     // (what counts where the streaming kernel places: ITS workgroups on a CU, with 8- and with 16-bit counts)
     const auto &g8 = p->geo[epik_amd::kCounts8], &g16 = p->geo[epik_amd::kCounts16];
-    const bool more_waves = p->team && p->team_front && g8.max_blocks != 0 ? g8.stream_blocks > g16.stream_blocks
-                                                                           : g8.resident_waves > g16.resident_waves;
+    const bool more_waves = p->team && p->team_front && g8.max_blocks != 0
+                                ? g8.stream_blocks[1] * (uint32_t)g8.stream_bw[1] > g16.stream_blocks[1] * (uint32_t)g16.stream_bw[1]
+                                : g8.resident_waves > g16.resident_waves;
     if (kmers <= 255u && more_waves) return epik_amd::kCounts8;
     return epik_amd::kCounts16;
 }
@@ -892,11 +904,12 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
                                                     dim3((unsigned)front_blocks), stream));
                 if (mode == kAccumulateLists) HIP_TRY(epik_amd::launch_team_sparse_scan(tp, p->team_waves, p->d_scan_tiles, stream));
             }
-            // (workgroups of four waves: W / 4 of them share a read, or -- two slices per pass -- one holds two reads)
-            const uint32_t parts = epik_amd::stream_parts(p->team_waves), per_block = epik_amd::stream_reads_per_block(p->team_waves);
+            // (workgroups of bw = four or two waves: W / bw of them share a read, or -- two slices per pass, four waves -- one holds two reads)
+            const int sv = mode == kPlace ? 1 : 0, bw = g.stream_bw[sv];
+            const uint32_t parts = epik_amd::stream_parts(p->team_waves, bw), per_block = epik_amd::stream_reads_per_block(p->team_waves, bw);
             const uint64_t n_units = (n + per_block - 1) / per_block;  // reads, or pairs of them
             uint64_t stream_blocks = n_units * parts;
-            const uint64_t stream_resident = p->max_blocks_cap ? std::min<uint64_t>(g.stream_blocks, (uint64_t)p->max_blocks_cap * parts) : g.stream_blocks;
+            const uint64_t stream_resident = p->max_blocks_cap ? std::min<uint64_t>(g.stream_blocks[sv], (uint64_t)p->max_blocks_cap * parts) : g.stream_blocks[sv];
             // (the dense halves are bound by the partial vectors in HBM: 65 536 reads per step, 16.4 M reads/s on the
             // resident grid against 15.1 spread)
             if (stream_blocks > stream_resident && (mode == kAccumulate || mode == kFinish)) stream_blocks = stream_resident;
@@ -908,8 +921,9 @@ static int launch(epik_amd_placer *p, launch_mode mode, const void *d_seqs, cons
             }
             p->last_blocks = (uint32_t)stream_blocks;
             p->last_streamed = true;
-            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, (int)mode, dim3((unsigned)stream_blocks),
-                                                 g.stream_lds_bytes, stream, shard.sources));
+            p->geo[p->counts].last_stream = (uint32_t)sv;
+            HIP_TRY(epik_amd::launch_team_stream(tp, p->team_waves, p->counts, (int)mode, bw, dim3((unsigned)stream_blocks),
+                                                 g.stream_lds_bytes[sv], stream, shard.sources));
             if (!is_accumulate(mode)) {
                 const uint64_t merge_blocks = std::min<uint64_t>((n + 3u) / 4u, (uint64_t)p->merge_blocks);
                 HIP_TRY(epik_amd::launch_team_merge(tp, p->team_waves, dim3((unsigned)merge_blocks), stream));
@@ -1055,7 +1069,8 @@ int epik_amd_placer_stream_build(const epik_amd_placer *p, uint32_t *wide, uint3
     if (!p || !wide || !sparse_quads) return fail(EPIK_AMD_ERR_INVALID, "null argument");
     *wide = *sparse_quads = 0;
     if (!p->team || !p->team_front) return EPIK_AMD_OK;
-    const bool is_wide = epik_amd::team_stream_is_wide(p->team_waves, p->geo[p->counts].stream_lds_bytes);
+    const auto &g = p->geo[p->counts];
+    const bool is_wide = epik_amd::team_stream_is_wide(p->team_waves, g.stream_lds_bytes[1], g.stream_bw[1]);
     *wide = is_wide ? 1u : 0u;
     // (the touched-quad epilogue is compiled into the wide build, for 8- and 16-bit counts)
     *sparse_quads = is_wide && p->counts != epik_amd::kCounts32 ? p->sparse_quads : 0u;
@@ -1326,9 +1341,9 @@ int epik_amd_placer_launch_info(const epik_amd_placer *p, uint32_t *waves_per_bl
     const auto &g = p->geo[p->last_geo];
     // (the team placement as front + streaming + merge kernels reports its streaming kernel)
     const bool streaming = p->team && p->team_front && p->last_streamed;
-    if (waves_per_block) *waves_per_block = streaming ? (uint32_t)epik_amd::kStreamWaves : g.waves_per_block;
-    if (blocks) *blocks = p->last_blocks ? p->last_blocks : streaming ? g.stream_blocks : g.max_blocks;
-    if (lds_bytes) *lds_bytes = streaming ? g.stream_lds_bytes : g.lds_block_bytes;
+    if (waves_per_block) *waves_per_block = streaming ? (uint32_t)g.stream_bw[g.last_stream] : g.waves_per_block;
+    if (blocks) *blocks = p->last_blocks ? p->last_blocks : streaming ? g.stream_blocks[g.last_stream] : g.max_blocks;
+    if (lds_bytes) *lds_bytes = streaming ? g.stream_lds_bytes[g.last_stream] : g.lds_block_bytes;
     return EPIK_AMD_OK;
 }
 

@@ -104,7 +104,9 @@ struct TeamChoice {
 // of that time -- e.g. two passes of half-size slices at N = 20 000 (3 workgroups per CU) beat one
 // pass (1 workgroup) 1.8 x.  4 waves always beat 8 (fewer slices to merge, fewer idle waves in the
 // front end): 8 only when forced; 2 -- half the items per read, each with twice the rows -- for trees of up to
-// 3 500 branches.  The 32-bit-count kernel must fit a CU.
+// 4 200 branches (3 500 until round 5: with two-wave workgroups where they fit more waves, a merge that packs four reads
+// to a wave and 8-byte table entries, two slices hold out longer: N = 3 999: 107.8 M reads/s against 102.5 with four).
+// The 32-bit-count kernel must fit a CU.
 constexpr bool kNarrowFilterByDefault = true;  // (protein k = 7, 998 M postings: 245.9 M reads/s against 237.9 M with 64-bit words)
 
 TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t forced_passes)
@@ -114,7 +116,7 @@ TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t for
     // (measured, round 4, 150 bp reads, million-read batches, M reads/s with one wavefront per read / 2 / 4 slices:
     // N = 1 999: 125 / 130 / 107; 2 499: 103 / 127 / 103; 2 999: 93 / 114 / 103; 3 999: 71 / 92 / 100; 4 999: 58 / 88 / 97;
     // 9 999: 25 / 63 / 67 -- an item's fixed cost against the slice epilogue's sweeps and the waves LDS leaves room for)
-    const int waves = forced_waves ? forced_waves : (n <= 3500u ? 2 : 4);
+    const int waves = forced_waves ? forced_waves : (n <= 4200u ? 2 : 4);
     // Passes (measured, round 4, `profiles/r04_sweep_tree_sizes_passes.txt` and DESIGN.md 3.2: M reads/s by passes --
     // N = 12 499: 42.6 / 44.7; 14 999: 41.8 / 43.4; 15 999: 23.1 / 42.3; 19 999: 19.2 / 41.9 / 26.1; 29 999: - / 29.2 / 24.9 /
     // 17.7; 39 999: - / - / 19.6 / 19.5 / 14.7; 49 999: - / - / - / 15.7 / 14.6 / 12.2): the fewest passes whose slices
@@ -132,10 +134,13 @@ TeamChoice choose_team(uint32_t n, uint32_t keep, int forced_waves, uint32_t for
         const int usual = (rows_pad + 7u) / 8u <= desc ? kCounts8 : kCounts16;
         const size_t normal = team_lds_bytes(waves, passes, team_slice_bytes(rows_pad, usual), desc, keep);
         const uint32_t blocks = team_resident_blocks(waves, normal);
-        const uint32_t stream_blocks = stream_blocks_by_lds(stream_lds_bytes(team_slice_bytes(rows_pad, usual), desc));
+        // (in waves of the streaming kernel that LDS leaves room for, with the better of its two workgroup sizes)
+        const uint32_t slice_bytes = team_slice_bytes(rows_pad, usual);
+        const uint32_t stream_waves = std::max(stream_blocks_by_lds(stream_lds_bytes(slice_bytes, desc, 2)) * 2u,
+                                               stream_blocks_by_lds(stream_lds_bytes(slice_bytes, desc, 4)) * 4u);
         const TeamChoice choice{waves, passes, rows, rows_pad, blocks * (uint32_t)waves};
-        if (best.waves == 0 || stream_blocks > best_blocks) best = choice, best_blocks = stream_blocks;  // (should none reach two)
-        if (forced_passes || stream_blocks >= (passes == 1 ? 3u : 2u)) return choice;
+        if (best.waves == 0 || stream_waves > best_blocks) best = choice, best_blocks = stream_waves;  // (should none reach eight)
+        if (forced_passes || stream_waves >= (passes == 1 ? 12u : 8u)) return choice;
     }
     return best;
 }

@@ -98,27 +98,34 @@ constexpr size_t team_lds_bytes(int waves, uint32_t passes, uint32_t slice_bytes
 // 4 slices (128 vector registers: the LDS of a large tree leaves room for three of its waves, and the fourth
 // wave's registers go to the front and merge kernels, which run beside it) and 5 with 8 (the slice epilogue
 // needs 70 VGPRs, the streaming loop fewer; only the cold ambiguous sweep spills).
-constexpr int kStreamWaves = 4;
-// ... each with one slice of some read: with W >= 4 slices per pass W / 4 consecutive workgroups share a read, with
-// W = 2 a workgroup holds the two slices of two reads
-constexpr uint32_t stream_parts(int slices_per_pass) { return slices_per_pass >= kStreamWaves ? (uint32_t)(slices_per_pass / kStreamWaves) : 1u; }
-constexpr uint32_t stream_reads_per_block(int slices_per_pass) { return slices_per_pass >= kStreamWaves ? 1u : (uint32_t)(kStreamWaves / slices_per_pass); }
-constexpr size_t stream_lds_bytes(uint32_t slice_bytes, uint32_t desc_bytes) { return (size_t)kStreamWaves * (slice_bytes + desc_bytes); }
+// Workgroups of FOUR or (round 5) TWO waves -- `bw`, a template parameter of the kernel, chosen per geometry by
+// stream_block_waves(): the waves of a workgroup share nothing but the LDS allocation, which the hardware hands out in
+// granules of 1 280 bytes per workgroup, and halves of a four-wave workgroup sometimes fit where a whole one does not
+// (waves per CU by LDS, four / two: N = 2 999 with two slices per pass 16 / 18, 3 999 12 / 14, 5 999 with four 16 / 18).
+// Measured, M reads/s, four / two: N = 2 999 121.3 / 128.2, 3 999 (two slices) 96.0 / 107.5, 5 999 86.2 / 90.0 -- and where
+// the waves stay the same two-wave workgroups LOSE 2-3 % (3 499: 120.5 / 118.4, 7 499: 81.8 / 79.3): two only where they
+// put more waves on a CU.
+constexpr int kStreamWaves = 4;  // the larger of the two
+// ... each wave with one slice of some read: with W >= bw slices per pass W / bw consecutive workgroups share a read, with
+// fewer a workgroup holds the slices of bw / W reads
+constexpr uint32_t stream_parts(int slices_per_pass, int bw) { return slices_per_pass >= bw ? (uint32_t)(slices_per_pass / bw) : 1u; }
+constexpr uint32_t stream_reads_per_block(int slices_per_pass, int bw) { return slices_per_pass >= bw ? 1u : (uint32_t)(bw / slices_per_pass); }
+constexpr size_t stream_lds_bytes(uint32_t slice_bytes, uint32_t desc_bytes, int bw) { return (size_t)bw * (slice_bytes + desc_bytes); }
 constexpr uint32_t stream_blocks_by_lds(size_t lds_bytes)
 {
     if (lds_bytes > kLdsPerCu) return 0;
     const uint32_t units = (uint32_t)((lds_bytes + kLdsGranule - 1) / kLdsGranule);
     return 128u / (units ? units : 1u);
 }
-// The streaming kernel comes in two builds.  WIDE (2 or 4 slices per pass, slices so large that LDS holds three workgroups
-// of it on a CU at most -- twelve waves, three per SIMD, whatever the registers): 168 vector registers, which the slice
+// The streaming kernel comes in two builds.  WIDE (2 or 4 slices per pass, slices so large that LDS holds twelve waves of it
+// on a CU at most -- three per SIMD, whatever the registers): 168 vector registers, which the slice
 // epilogue over the touched quads (team_epilogue.hpp) holds its rows in.  LEAN (everything else): the 96 registers of
 // five waves per SIMD -- the hardware fills a CU with as many workgroups as registers and LDS allow, whatever the
 // kernel was compiled for, and on the small slices of a mid-size tree that is twenty waves (measured, round 4: the
 // wide build on slices of 1 000 rows places 74 M reads/s, the lean one 100 M).
-constexpr bool stream_wide(int slices_per_pass, size_t lds_bytes)
+constexpr bool stream_wide(int slices_per_pass, size_t lds_bytes, int bw)
 {
-    return slices_per_pass <= 4 && stream_blocks_by_lds(lds_bytes) != 0 && stream_blocks_by_lds(lds_bytes) <= 3u;
+    return slices_per_pass <= 4 && stream_blocks_by_lds(lds_bytes) != 0 && stream_blocks_by_lds(lds_bytes) * (uint32_t)bw <= 13u;
 }
 // (what the builds are COMPILED for -- the lean build of 4 slices for three waves per SIMD like the wide one: held to the
 // 96 registers of five it spills seven of them, left alone it takes 96 and no scratch -- and what a CU then holds)
@@ -126,10 +133,20 @@ constexpr uint32_t stream_waves_per_simd(int slices_per_pass)
 {
     return EPIK_AMD_STREAM_OCC ? (uint32_t)EPIK_AMD_STREAM_OCC : slices_per_pass <= 4 ? 3u : 5u;
 }
-constexpr uint32_t stream_resident_blocks(int slices_per_pass, size_t lds_bytes)
+constexpr uint32_t stream_resident_blocks(int slices_per_pass, size_t lds_bytes, int bw)
 {
-    const uint32_t by_lds = stream_blocks_by_lds(lds_bytes), by_regs = stream_wide(slices_per_pass, lds_bytes) ? 3u : 5u;
+    const uint32_t by_lds = stream_blocks_by_lds(lds_bytes);
+    const uint32_t by_regs = (stream_wide(slices_per_pass, lds_bytes, bw) ? 12u : 20u) / (uint32_t)bw;
     return by_lds < by_regs ? by_lds : by_regs;
+}
+constexpr uint32_t stream_resident_waves(int slices_per_pass, uint32_t slice_bytes, uint32_t desc_bytes, int bw)
+{
+    return stream_resident_blocks(slices_per_pass, stream_lds_bytes(slice_bytes, desc_bytes, bw), bw) * (uint32_t)bw;
+}
+// the workgroup that leaves most waves on a CU (a tie: four)
+constexpr int stream_block_waves(int slices_per_pass, uint32_t slice_bytes, uint32_t desc_bytes)
+{
+    return stream_resident_waves(slices_per_pass, slice_bytes, desc_bytes, 2) > stream_resident_waves(slices_per_pass, slice_bytes, desc_bytes, 4) ? 2 : 4;
 }
 constexpr uint32_t team_resident_blocks(int waves, size_t lds_bytes)
 {

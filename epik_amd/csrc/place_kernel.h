@@ -155,7 +155,8 @@ hipError_t team_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_p
 // team_stream.hip: the front kernel (any grid of 256-thread workgroups, one read per wave) and the
 // streaming kernel (one workgroup per read, grid = resident workgroups, LDS as the team kernel's)
 hipError_t launch_team_front(const TeamParams &tp, int waves, int counts, bool lists, dim3 grid, hipStream_t stream);
-hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
+// (bw: waves of a workgroup of the streaming kernel, 4, or 2 for the one-pass placement where that puts more waves on a CU)
+hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, int bw, dim3 grid, size_t lds_bytes,
                               hipStream_t stream, const SparseSources *sources = nullptr);
 // (tile_sums: scratch of sparse_scan_tiles(reads per part, slices) * parts 64-bit words)
 uint64_t sparse_scan_tiles(uint64_t part_reads, uint32_t slices);
@@ -163,9 +164,9 @@ hipError_t launch_team_sparse_scan(const TeamParams &tp, int waves, unsigned lon
 hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipStream_t stream);
 hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStream_t stream);
 constexpr size_t kTeamPartialBytes = 24;  // sizeof(TeamPartial) (place_device.hpp)
-hipError_t set_team_stream_lds_limit(int waves, int counts, size_t lds_bytes);
-bool team_stream_is_wide(int waves, size_t lds_bytes);  // the build launch_team_stream picks (EPIK_AMD_STREAM_WIDE overrides the rule)
-hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu);
+hipError_t set_team_stream_lds_limit(int waves, int counts, int mode, int bw, size_t lds_bytes);
+bool team_stream_is_wide(int waves, size_t lds_bytes, int bw);  // the build launch_team_stream picks (EPIK_AMD_STREAM_WIDE overrides the rule)
+hipError_t team_stream_occupancy(int waves, int counts, int mode, int bw, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_team_algorithmic_bytes(const TeamParams &tp, int waves, unsigned long long *d_total, hipStream_t stream);
 
 hipError_t launch_place_reads(const PlaceParams &p, DbLayout layout, bool runs, int counts, dim3 grid, dim3 block,

@@ -68,8 +68,12 @@ struct epik_amd_placer {
         uint32_t lds_block_bytes = 0;
         uint32_t max_blocks = 0;
         uint32_t resident_waves = 0;  // per CU
-        // team_stream_kernel (team placement as front + streaming + merge kernels): workgroups of 4 waves
-        uint32_t stream_lds_bytes = 0, stream_blocks = 0;
+        // team_stream_kernel (team placement as front + streaming + merge kernels): workgroups of 4 waves -- [0], the
+        // halves of a k-mer-space-sharded placement -- or of stream_bw[1] = 4 or 2 -- [1], the one-pass placement
+        // (db_layout.h: stream_block_waves: two where that puts more waves on a CU)
+        uint32_t stream_lds_bytes[2] = {0, 0}, stream_blocks[2] = {0, 0};
+        int stream_bw[2] = {4, 4};
+        uint32_t last_stream = 0;  // which of the two the last launch used
     } geo[3];
     uint32_t *d_sparse_cap = nullptr;             // partial lists: room per (read, slice), front kernel -> scan kernel
     unsigned long long *d_scan_tiles = nullptr;   // ... and the scan's tile sums

@@ -344,8 +344,9 @@ __device__ __forceinline__ void slice_epilogue(const TeamParams *__restrict__ kt
 // added back in shard order (merge_partial_lists; `src` says where they lie).
 // kWide: the build for slices so large that LDS keeps a CU to twelve waves (db_layout.h: stream_wide) -- 168 vector
 // registers, and with them the slice epilogue over the touched quads.
-template <int W, typename CountT, int kMode, bool kWide>
-__global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp, SparseSources src)
+// kBW: waves of a workgroup, 4 or 2 (db_layout.h: stream_block_waves)
+template <int W, typename CountT, int kMode, bool kWide, int kBW>
+__global__ __launch_bounds__(kBW * 64, stream_waves_per_simd(W)) void team_stream_kernel(TeamParams tp, SparseSources src)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typedef WaveLds<CountT> Lds;
@@ -354,16 +355,16 @@ __global__ __launch_bounds__(kStreamWaves * 64, stream_waves_per_simd(W)) void t
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // W slices per pass, kStreamWaves waves per workgroup: W / kStreamWaves consecutive workgroups share a read -- or,
     // with two slices per pass, a workgroup holds two reads
-    constexpr uint32_t kParts = stream_parts(W), kReadsPerBlock = stream_reads_per_block(W);
-    static_assert(W % kStreamWaves == 0 || kStreamWaves % W == 0, "slices per pass: a multiple or a divisor of the workgroup's waves");
+    constexpr uint32_t kParts = stream_parts(W, kBW), kReadsPerBlock = stream_reads_per_block(W, kBW);
+    static_assert(W % kBW == 0 || kBW % W == 0, "slices per pass: a multiple or a divisor of the workgroup's waves");
     const uint32_t wave = kReadsPerBlock > 1 ? wave_in_block % (uint32_t)W
-                                             : (blockIdx.x % kParts) * kStreamWaves + wave_in_block;  // this wave's slice of a pass
+                                             : (blockIdx.x % kParts) * kBW + wave_in_block;  // this wave's slice of a pass
     // (the grid is a multiple of kParts)
     const uint64_t first_read = kReadsPerBlock > 1 ? (uint64_t)blockIdx.x * kReadsPerBlock + wave_in_block / (uint32_t)W : blockIdx.x / kParts;
     const uint64_t read_stride = kReadsPerBlock > 1 ? (uint64_t)gridDim.x * kReadsPerBlock : gridDim.x / kParts;
     const uint32_t rows_pad = tp.rows_pad;
     Lds lds;
-    unsigned char *desc_base = lds_raw + (size_t)kStreamWaves * tp.slice_bytes;
+    unsigned char *desc_base = lds_raw + (size_t)kBW * tp.slice_bytes;
     lds.score = (typename Lds::f32_t *)reinterpret_cast<float *>(lds_raw + (size_t)wave_in_block * tp.slice_bytes);
     lds.count = (typename Lds::count_t *)reinterpret_cast<CountT *>(lds_raw + (size_t)wave_in_block * tp.slice_bytes + (size_t)rows_pad * 4);
     lds.desc = (typename Lds::u64_t *)reinterpret_cast<uint64_t *>(desc_base + (size_t)wave_in_block * tp.desc_bytes);
@@ -903,18 +904,23 @@ __global__ __launch_bounds__(256) void team_merge_packed_kernel(TeamParams tp, u
 namespace {
 
 template <typename F>
-hipError_t stream_dispatch(int waves, int counts, int mode, bool wide, F &&f)
+hipError_t stream_dispatch(int waves, int counts, int mode, bool wide, int bw, F &&f)
 {
-#define EPIK_STREAM_CASE(W, C, M, WIDE) \
-    if (waves == W && counts == C && mode == M && wide == WIDE) \
-        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M, WIDE>();
-#define EPIK_STREAM_MODES(W, C, WIDE) EPIK_STREAM_CASE(W, C, kTeamModePlace, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate, WIDE) \
-    EPIK_STREAM_CASE(W, C, kTeamModeFinish, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeAccumulateLists, WIDE) EPIK_STREAM_CASE(W, C, kTeamModeFinishLists, WIDE)
-    EPIK_STREAM_MODES(2, kCounts8, false) EPIK_STREAM_MODES(2, kCounts16, false) EPIK_STREAM_MODES(2, kCounts32, false)
-    EPIK_STREAM_MODES(2, kCounts8, true) EPIK_STREAM_MODES(2, kCounts16, true) EPIK_STREAM_MODES(2, kCounts32, true)
-    EPIK_STREAM_MODES(4, kCounts8, false) EPIK_STREAM_MODES(4, kCounts16, false) EPIK_STREAM_MODES(4, kCounts32, false)
-    EPIK_STREAM_MODES(4, kCounts8, true) EPIK_STREAM_MODES(4, kCounts16, true) EPIK_STREAM_MODES(4, kCounts32, true)
-    EPIK_STREAM_MODES(8, kCounts8, false) EPIK_STREAM_MODES(8, kCounts16, false) EPIK_STREAM_MODES(8, kCounts32, false)
+#define EPIK_STREAM_CASE(W, C, M, WIDE, BW) \
+    if (waves == W && counts == C && mode == M && wide == WIDE && bw == BW) \
+        return f.template operator()<W, std::conditional_t<C == kCounts8, uint8_t, std::conditional_t<C == kCounts16, uint16_t, uint32_t>>, M, WIDE, BW>();
+#define EPIK_STREAM_MODES(W, C, WIDE, BW) EPIK_STREAM_CASE(W, C, kTeamModePlace, WIDE, BW) EPIK_STREAM_CASE(W, C, kTeamModeAccumulate, WIDE, BW) \
+    EPIK_STREAM_CASE(W, C, kTeamModeFinish, WIDE, BW) EPIK_STREAM_CASE(W, C, kTeamModeAccumulateLists, WIDE, BW) EPIK_STREAM_CASE(W, C, kTeamModeFinishLists, WIDE, BW)
+#define EPIK_STREAM_COUNTS(W, WIDE, BW) EPIK_STREAM_MODES(W, kCounts8, WIDE, BW) EPIK_STREAM_MODES(W, kCounts16, WIDE, BW) EPIK_STREAM_MODES(W, kCounts32, WIDE, BW)
+    EPIK_STREAM_COUNTS(2, false, 4) EPIK_STREAM_COUNTS(2, true, 4) EPIK_STREAM_COUNTS(4, false, 4) EPIK_STREAM_COUNTS(4, true, 4) EPIK_STREAM_COUNTS(8, false, 4)
+    // (two-wave workgroups: the one-pass placement only -- the halves of a sharded placement keep four)
+    if (mode == kTeamModePlace) {
+#define EPIK_STREAM_PLACE(W, WIDE) EPIK_STREAM_CASE(W, kCounts8, kTeamModePlace, WIDE, 2) EPIK_STREAM_CASE(W, kCounts16, kTeamModePlace, WIDE, 2) \
+    EPIK_STREAM_CASE(W, kCounts32, kTeamModePlace, WIDE, 2)
+        EPIK_STREAM_PLACE(2, false) EPIK_STREAM_PLACE(2, true) EPIK_STREAM_PLACE(4, false) EPIK_STREAM_PLACE(4, true) EPIK_STREAM_PLACE(8, false)
+#undef EPIK_STREAM_PLACE
+    }
+#undef EPIK_STREAM_COUNTS
 #undef EPIK_STREAM_MODES
 #undef EPIK_STREAM_CASE
     return hipErrorInvalidValue;
@@ -988,22 +994,22 @@ hipError_t launch_team_headers(const TeamParams &tp, int waves, int counts, hipS
 // the wide build whatever the slices' size (2 and 4 slices per pass have one) / the lean one.  The wide build holds
 // the slice epilogue over the touched quads (team_epilogue.hpp), which the small trees of the parity tests would
 // otherwise never reach.
-bool team_stream_is_wide(int waves, size_t lds_bytes)
+bool team_stream_is_wide(int waves, size_t lds_bytes, int bw)
 {
     // (read at every call: a handful per launch, and the tests create placers of several kinds in one process)
     const char *e = std::getenv("EPIK_AMD_STREAM_WIDE");
     const int forced = e && e[0] == '1' ? 1 : e && e[0] == '0' ? 0 : -1;
     if (forced == 1) return waves <= 4;
     if (forced == 0) return false;
-    return stream_wide(waves, lds_bytes);
+    return stream_wide(waves, lds_bytes, bw);
 }
 
-hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, dim3 grid, size_t lds_bytes,
+hipError_t launch_team_stream(const TeamParams &tp, int waves, int counts, int mode, int bw, dim3 grid, size_t lds_bytes,
                               hipStream_t stream, const SparseSources *sources)
 {
     const SparseSources src = sources ? *sources : SparseSources{};
-    return stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
-        hipLaunchKernelGGL((team_stream_kernel<W, C, M, kWide>), grid, dim3(kStreamWaves * 64), lds_bytes, stream, tp, src);
+    return stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes, bw), bw, [&]<int W, typename C, int M, bool kWide, int kBW>() {
+        hipLaunchKernelGGL((team_stream_kernel<W, C, M, kWide, kBW>), grid, dim3(kBW * 64), lds_bytes, stream, tp, src);
         return hipGetLastError();
     });
 }
@@ -1023,21 +1029,18 @@ hipError_t launch_team_merge(const TeamParams &tp, int waves, dim3 grid, hipStre
     return hipGetLastError();
 }
 
-hipError_t set_team_stream_lds_limit(int waves, int counts, size_t lds_bytes)  // (always the whole CU: see place_kernel.hip)
+hipError_t set_team_stream_lds_limit(int waves, int counts, int mode, int bw, size_t lds_bytes)  // (always the whole CU: see place_kernel.hip)
 {
-    hipError_t err = hipSuccess;
-    for (int mode = 0; mode < 5 && err == hipSuccess; ++mode)
-        err = stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M, kWide>),
+    return stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes, bw), bw, [&]<int W, typename C, int M, bool kWide, int kBW>() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&team_stream_kernel<W, C, M, kWide, kBW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
         });
-    return err;
 }
 
-hipError_t team_stream_occupancy(int waves, int counts, size_t lds_bytes, int *blocks_per_cu)
+hipError_t team_stream_occupancy(int waves, int counts, int mode, int bw, size_t lds_bytes, int *blocks_per_cu)
 {
-    return stream_dispatch(waves, counts, kTeamModePlace, team_stream_is_wide(waves, lds_bytes), [&]<int W, typename C, int M, bool kWide>() {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C, M, kWide>, kStreamWaves * 64,
+    return stream_dispatch(waves, counts, mode, team_stream_is_wide(waves, lds_bytes, bw), bw, [&]<int W, typename C, int M, bool kWide, int kBW>() {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, team_stream_kernel<W, C, M, kWide, kBW>, kBW * 64,
                                                             lds_bytes);
     });
 }

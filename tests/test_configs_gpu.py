@@ -188,11 +188,12 @@ def test_protein_reads_across_the_underflow_limits(amino_k7, amino_k7_placer, or
     assert_rows_match(*got, *ref)
 
 
-@pytest.mark.parametrize("n_branches", [1983, 1984, 1985, 2047, 2048, 2049, 3499, 3500, 3501, 4095, 4097, 10001, 14999, 19999, 30001, 50001])
+@pytest.mark.parametrize("n_branches", [1983, 1984, 1985, 2047, 2048, 2049, 2999, 3499, 3501, 3999, 4095, 4097, 4199, 4200, 4201, 5999, 10001, 14999, 19999, 30001, 50001])
 def test_tree_sizes_around_the_kernel_thresholds(gpu_available, oracle_lib, n_branches, monkeypatch):
     """What create() picks by itself on either side of its thresholds -- one wavefront per read below N = 1 984, two
-    slices per pass up to 3 500, four beyond (db_image.cpp: make_plan, choose_team) -- and around the powers of two
-    where the padded row counts step, and the sizes beyond one pass (two, three and more passes by the rule of
+    slices per pass up to 4 200, four beyond (db_image.cpp: make_plan, choose_team) -- and around the powers of two
+    where the padded row counts step, sizes on either side of the streaming kernel's choice of workgroup (two waves at
+    2 999, 3 999 and 5 999, four at 3 499: db_layout.h: stream_block_waves), and the sizes beyond one pass (two, three and more passes by the rule of
     choose_team): every one against the oracle."""
     assert gpu_available
     from epik_amd.placer import Placer
