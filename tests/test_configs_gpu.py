@@ -269,6 +269,7 @@ def test_placers_of_different_trees_share_a_process(large_tree, small_case, orac
     from epik_amd.placer import Placer
     monkeypatch.setenv("EPIK_AMD_KERNEL", kernel)
     monkeypatch.setenv("EPIK_AMD_WIDE_COUNTS", "1")   # 32-bit counts: 82 KB of LDS per workgroup
+    monkeypatch.setenv("EPIK_AMD_STREAM_BLOCK", "4")  # (... of four waves: by itself this geometry takes two, 41 KB)
     _, big = large_tree
     _, small = small_case
     rng = np.random.default_rng(51)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r04_* and
+"""Copies what `tools/profile_round.sh <tag>` left under gpurun_out/<tag>/ into profiles/ as r05_* and
 rewrites profiles/traffic.json from the PMC summaries, stamped with the hash of the kernel sources in
 the tree (run it on the same sources the GPU run used).
 
-    python tools/collect_profiles.py r04_a
+    python tools/collect_profiles.py r05
 """
 import json
 import os
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from epik_amd import provenance  # noqa: E402
 
-ROUND = "r04"
+ROUND = "r05"
 FILES = {
     "bench.json": f"{ROUND}_bench.json",
     "bench_headline.json": f"{ROUND}_bench_headline_trace_run.json",

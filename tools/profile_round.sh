@@ -6,7 +6,7 @@
 # database (k = 11) and the large tree (N = 9 999, team kernels); SQ counters, per-phase instruction counts and a
 # single-wave timeline of the team kernels; the tree-size sweep.
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

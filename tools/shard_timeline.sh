@@ -3,7 +3,7 @@
 #   bash tools/shard_timeline.sh <tag> [bench args, e.g. --shard-of 8]
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-shard}; shift
-OUT=$R/gpurun_out/r04/$TAG
+OUT=$R/gpurun_out/r05/$TAG
 mkdir -p $OUT
 cd $R
 for half in accumulate finish; do
