@@ -14,8 +14,9 @@ for f in sorted(glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         for key in ("place_reads_kernel", "team_place_kernel", "team_front_kernel", "team_stream_kernel",
-                    "team_merge_kernel", "stream_seq", "stream_rnd"):
+                    "team_merge", "stream_seq", "stream_rnd"):
             if key in name:
-                acc[(run.split("_")[0], key, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                # (team_merge_kernel, or since round 5 team_merge_packed_kernel<16 | 32>: one line either way)
+                acc[(run.split("_")[0], "team_merge_kernel" if key == "team_merge" else key, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (run, kern, ctr), vals in sorted(acc.items()):
     print(f"{run:6s} {kern:20s} {ctr:28s} mean={sum(vals) / len(vals):.6g}  n={len(vals)}")
