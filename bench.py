@@ -40,10 +40,11 @@ Rank 0 prints ONE JSON line.  Extra objects (rank 0, N=1 where they cost time):
                         -- the tree of BASELINE configs[4] (N = 9 999) placed in one pass by the front / streaming /
                            merge kernels, three steps: SURVEY 8d's random lists, and lists over the clades of
                            reference sequences with reads cut from them (synth.make_clade_db);
-  kmer_shard_1gpu, kmer_shard_0of8_1gpu
+  kmer_shard_1gpu, kmer_shard_0of8_1gpu, kmer_shard_rank_of8_1gpu
                         -- the two halves of the k-mer-space-sharded placement of that tree on this one GPU
-                           (65 536 reads per step, a process of its own): the whole database as one shard,
-                           and shard 0 of 8 alone -- what one of eight GPUs accumulates per batch;
+                           (65 536 reads per step, a process of its own): the whole database as one shard;
+                           shard 0 of 8 alone with ALL reads finished from that one source; and the same shard as one
+                           rank of eight works -- all reads accumulated, an eighth finished from eight sources;
   build                 -- compiler, kernel-source hash and ISA-lint record of the library (epik_amd/provenance.py).
 config.world_size is what the process group reports; config.ranks lists every rank's device ordinal, PCI bus id,
 host and own ms_per_step (the k-mer-space shard: the bytes it sent per step) -- a SCALE record says by itself
@@ -102,6 +103,10 @@ def parse_args():
                     help="--mode kmer-shard on ONE GPU: the database holds shard 0 of G only (the lists of the codes with "
                          "code %% G == 0) -- what one of G GPUs accumulates per batch; the rows that come out are those of "
                          "that shard alone (a timing experiment: DESIGN.md 6)")
+    ap.add_argument("--as-rank", action="store_true",
+                    help="with --shard-of G: what ONE of G GPUs computes per batch -- accumulate of ALL reads against its shard, "
+                         "then the finish of its n / G reads from G sources (all of them this shard's lists: the rows mean "
+                         "nothing, the work is a rank's; the exchange is not in it)")
     ap.add_argument("--mode", choices=["reads", "kmer-shard"], default="reads",
                     help="reads (default): reads sharded over the GPUs, database replicated, no collective.  "
                          "kmer-shard (BASELINE configs[4]: --leaves 5000 --reads-per-step 4096): rank g builds and "
@@ -474,6 +479,8 @@ def main():
                 f"{args.reads_per_step} x {args.read_length} {unit} reads per step per GPU"
                 + (", scattered branch sets" if args.scattered else "")
                 + (f", shard 0 of {args.shard_of} only" if args.shard_of and kmer_shard else "")
+                + (f", as one rank of {args.shard_of}: all reads accumulated, {args.reads_per_step // args.shard_of} finished from "
+                   f"{args.shard_of} sources" if args.as_rank and kmer_shard else "")
                 + (f", {args.p_present:g} of the codes present" if args.p_present != 0.6 and not args.clades else "")
                 + (", lists over the clades of 500 references of 1500 bp, reads cut from the references (1 % substitutions)"
                    if args.clades else ""))
@@ -505,8 +512,11 @@ def main():
     shard_info = None
     if kmer_shard:
         N = placer.num_branches
-        per = -(-n // world)
-        begin, end = edist.owner_bounds(n, rank, world)
+        if args.as_rank and not (args.shard_of and world == 1):
+            raise SystemExit("--as-rank: with --shard-of G on one GPU")
+        n_parts = args.shard_of if args.as_rank else world   # finishers the batch is divided among
+        per = -(-n // n_parts)
+        begin, end = edist.owner_bounds(n, 0 if args.as_rank else rank, n_parts)
         pinfo = placer.partial_info()
         shard_info = {"partials": "lists" if pinfo["lists"] else "dense"}
     if kmer_shard and pinfo["lists"]:
@@ -516,13 +526,13 @@ def main():
 
         def alloc(cap):
             return {"entries": torch.empty(max(cap, 1) * eb, dtype=torch.uint8, device=dev), "cap": cap,
-                    "index": torch.zeros((per * world, S, 2), dtype=torch.int32, device=dev),
-                    "part_entries": torch.zeros(world, dtype=torch.int64, device=dev), "done": None}
+                    "index": torch.zeros((per * n_parts, S, 2), dtype=torch.int32, device=dev),
+                    "part_entries": torch.zeros(n_parts, dtype=torch.int64, device=dev), "done": None}
 
         def accumulate(buf):
             if buf.get("finished") is not None:   # (the finish that read this set of buffers last)
                 stream.wait_event(buf["finished"])
-            placer.accumulate_lists_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, world, buf["entries"].data_ptr(),
+            placer.accumulate_lists_device(d_seqs.data_ptr(), d_offs.data_ptr(), n, n_parts, buf["entries"].data_ptr(),
                                            buf["cap"], buf["index"].data_ptr(), buf["part_entries"].data_ptr(),
                                            stream.cuda_stream)
             buf["done"] = stream.record_event()
@@ -549,7 +559,7 @@ def main():
         shard_info.update({"entry_bytes": eb, "slices": S, "entries_per_read": need / n,
                            "partial_bytes_per_read": (need * eb + S * 8 * n) / n,
                            "dense_bytes_per_read": 6 * N})
-        own = {"entries": [None] * world, "index": [None] * world}
+        own = {"entries": [None] * n_parts, "index": [None] * n_parts}
 
         def exchange(buf):
             """all-to-all of the parts (split sizes from a gather of the part sizes) and of their index, on the
@@ -601,7 +611,9 @@ def main():
 
         def complete(buf):
             if dist is None:
-                own["entries"][0], own["index"][0] = buf["entries"], buf["index"]
+                # (--as-rank: part 0 -- this rank's reads -- of every one of the G shards: here G times this shard's)
+                for g in range(n_parts):
+                    own["entries"][g], own["index"][g] = buf["entries"], buf["index"]
                 finish_lists(buf, buf["done"])
             else:
                 arrived = exchange(buf)
@@ -843,6 +855,8 @@ def main():
         log("k-mer-space shard (N = 9999) on this GPU: the whole database, then shard 0 of 8 ...")
         result["kmer_shard_1gpu"] = shard_line([])
         result["kmer_shard_0of8_1gpu"] = shard_line(["--shard-of", "8"])
+        # (what one rank of eight computes per batch: the accumulate of all reads, the finish of an eighth from eight sources)
+        result["kmer_shard_rank_of8_1gpu"] = shard_line(["--shard-of", "8", "--as-rank"])
     if extras and args.cpu_baseline_seconds > 0:
         log("CPU baseline (oracle) ...")
         result["cpu_baseline"], result["cpu_baseline_1thread"] = cpu_baseline(db, data, offs, args.cpu_baseline_seconds)
