@@ -37,12 +37,13 @@ def select_kernel(monkeypatch, name):
     teamW[xP]-smallpool -- a descriptor pool so small that some reads of a batch fall to
     team_place_kernel behind the streaming kernel; teamW[xP]-sparse / -dense -- the WIDE build of the streaming
     kernel (EPIK_AMD_STREAM_WIDE=1: by itself only large slices get it) with its slice epilogue over the touched quads
-    (team_epilogue.hpp) wherever their list holds them / nowhere.  A layout of the one-wavefront kernel with -runs: lists that
+    (team_epilogue.hpp) wherever their list holds them / nowhere; teamW[xP]-block2 / -block2wide -- the streaming kernel
+    in workgroups of two waves (EPIK_AMD_STREAM_BLOCK), lean / wide build.  A layout of the one-wavefront kernel with -runs: lists that
     are one ascending run of branches stored without their cells (the kernels with the run path).  Any of them with -fewblocks: a device that holds two
     workgroups (EPIK_AMD_MAX_BLOCKS), so that the waves of a test-sized batch place several reads one after
     the other on the grids of a million-read batch (capi.hip: spread_grid)."""
     for var in ("EPIK_AMD_TEAM_FRONT", "EPIK_AMD_TEAM_POOL", "EPIK_AMD_LAYOUT", "EPIK_AMD_MAX_BLOCKS", "EPIK_AMD_RUNS",
-                "EPIK_AMD_TEAM_SPARSE", "EPIK_AMD_STREAM_WIDE"):
+                "EPIK_AMD_TEAM_SPARSE", "EPIK_AMD_STREAM_WIDE", "EPIK_AMD_STREAM_BLOCK"):
         monkeypatch.delenv(var, raising=False)
     if name.endswith("-runs"):  # the packed lists run-coded (by itself the builder does that for large databases only)
         name = name[:-len("-runs")]
@@ -65,6 +66,13 @@ def select_kernel(monkeypatch, name):
         elif variant == "dense":  # ... and never: the wide build with its dense epilogue
             monkeypatch.setenv("EPIK_AMD_TEAM_SPARSE", "0")
             monkeypatch.setenv("EPIK_AMD_STREAM_WIDE", "1")
+        elif variant in ("block2", "block2wide"):
+            # the streaming kernel in workgroups of TWO waves (by itself where LDS then holds more waves on a CU:
+            # N = 2 999, 3 999, 5 999 -- never on the small trees of the tests), lean build / wide build
+            monkeypatch.setenv("EPIK_AMD_STREAM_BLOCK", "2")
+            if variant == "block2wide":
+                monkeypatch.setenv("EPIK_AMD_STREAM_WIDE", "1")
+                monkeypatch.setenv("EPIK_AMD_TEAM_SPARSE", "always")
         else:
             assert variant == "", name
     else:

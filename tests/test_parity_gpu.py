@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(autouse=True, params=["paired", "filtered", "packed", "compact", "paired-runs", "filtered-runs", "packed-runs",
-                                      "team4", "team8", "team4x3", "team2", "team2x3", "team2-classic", "team2-smallpool", "team2-sparse", "team4-sparse", "team4x2-sparse", "team4-dense",
+                                      "team4", "team8", "team4x3", "team2", "team2x3", "team2-classic", "team2-smallpool", "team2-sparse", "team4-sparse", "team4x2-sparse", "team4-dense", "team4-block2", "team2x2-block2", "team8-block2", "team4-block2wide",
                                       "team4-classic", "team4x3-classic", "team4-smallpool", "team8x2-smallpool",
                                       "paired-fewblocks", "team4-fewblocks", "team8x2-fewblocks", "team4-classic-fewblocks"])
 def db_layout(request, monkeypatch):
@@ -44,7 +44,7 @@ def test_the_sparse_variants_reach_the_touched_quad_epilogue(gpu_available, smal
         for longest in (40, 300, 40_000):   # 8-, 16-, 32-bit counts
             pl.choose_counts(longest)
             build = pl.stream_build()
-            if db_layout.endswith("-sparse"):
+            if db_layout.endswith(("-sparse", "-block2wide")):
                 assert build["wide"] and build["sparse_quads"] == (256 if longest < 40_000 else 0), (longest, build)
             elif db_layout.endswith("-dense"):
                 assert build["wide"] and build["sparse_quads"] == 0
