@@ -63,12 +63,23 @@ void write_chunks(uint8_t *dst, const epik_amd_pkdb_value *src, uint64_t len, ui
 // k = 11 database (1.13 GB explicit) gains 5-8 % from a third fewer lines per list, while the headline database
 // (285 MB, served mostly by the 256 MiB Infinity Cache) loses 3 % to the three more instructions per chunk.  So:
 // when the explicit image would be beyond twice the Infinity Cache.  EPIK_AMD_RUNS=0 / 1 forces it.
-inline bool choose_runs(uint64_t explicit_image_bytes, uint64_t postings, uint64_t postings_in_runs)
+// Round 5: ... or when it brings the image from beyond the Infinity Cache to inside it, on a tree whose kernel keeps its
+// full twenty waves on a CU -- there the kernel is bound by the memory system (0.885 of the roofline on the headline
+// database, 285 MB explicit, 213 MB run-coded) and the lines not fetched win: 171.0 -> 177.6 M reads/s, 0.887 -> 0.921
+// (round 3 had measured +1.2 % there, before the ring's stages lost an instruction).  With fewer waves (N = 1 303: 18,
+// 1 499 ... 1 949: 16, 14) the kernel is bound by the instructions it issues and the run path's three more per chunk
+// lose 4-10 % even though the image crosses under the cache (measured on the round's kernels: 165.7 -> 158.3, 159.1 ->
+// 149.1, 143.1 -> 129.3, 140.5 -> 127.1 M reads/s): those keep their cells.
+constexpr uint64_t kInfinityCacheBytes = 256ull << 20;
+inline bool choose_runs(uint64_t explicit_image_bytes, uint64_t run_coded_image_bytes, uint64_t postings, uint64_t postings_in_runs,
+                        bool full_occupancy)
 {
     if (const char *e = std::getenv("EPIK_AMD_RUNS")) return e[0] != '0';
     // (... and nearly all postings in runs: the kernels with the run path wait longer than needed behind chunks
     // with explicit cells, place_device.hpp)
-    return explicit_image_bytes > (512ull << 20) && postings_in_runs * 10u >= postings * 9u;
+    if (postings_in_runs * 10u < postings * 9u) return false;
+    if (explicit_image_bytes > (512ull << 20)) return true;
+    return full_occupancy && explicit_image_bytes > kInfinityCacheBytes && run_coded_image_bytes <= kInfinityCacheBytes;
 }
 inline bool is_run(const epik_amd_pkdb_value *v, uint64_t len)
 {
@@ -437,16 +448,19 @@ int make_plan(const Source &src, size_t free_mem, const char *forced_layout, con
     const uint64_t quarter = d->num_keys / 4;
     if (plan.n_pad > 65536u) return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the packed layouts");
     const uint64_t table_bytes = d->num_keys * (paired ? 16u : 8u) + 8u;
-    {   // how large the image is with every list explicit decides whether the lists are run-coded
-        uint64_t explicit_lines = 0, in_runs = 0;
+    {   // how large the image is with every list explicit, and run-coded, decides whether the lists are run-coded
+        uint64_t explicit_lines = 0, coded_lines = 0, in_runs = 0;
         Cursor walk(src);
         for (uint64_t key = 0; key < d->num_keys; ++key) {
             uint64_t first = 0;
             const uint64_t len = walk.list(key, &first);
             explicit_lines += (len * 6u + 127u) / 128u;
-            if (is_run(d->values + first, len)) in_runs += len;
+            const bool run = is_run(d->values + first, len);
+            coded_lines += ((run ? len * 4u : len * 6u) + 127u) / 128u;
+            if (run) in_runs += len;
         }
-        plan.runs = choose_runs(explicit_lines * 128u + table_bytes, plan.kept_entries, in_runs);
+        plan.runs = choose_runs(explicit_lines * 128u + table_bytes, coded_lines * 128u + table_bytes, plan.kept_entries, in_runs,
+                                plan.wave_resident[kCounts8] >= kWaveKernelWavesPerCu);
     }
     const bool runs = plan.runs;
     Cursor walk(src);
@@ -531,10 +545,17 @@ int plan_sizes(const SizeDesc &z, size_t free_mem, const char *forced_layout, co
     }
     plan.layout = w.paired ? DbLayout::kPaired : w.filtered ? DbLayout::kFiltered : DbLayout::kPacked;
     if (plan.n_pad > 65536u) return fail(EPIK_AMD_ERR_UNSUPPORTED, "num_branches too large for the packed layouts");
-    uint64_t explicit_lines = 0;
-    for (uint64_t i = 0; i < z.n_bins; ++i)
-        if (z.bins[i].length && z.bins[i].lists) explicit_lines += z.bins[i].lists * ((z.bins[i].length * 6u + 127u) / 128u);
-    plan.runs = choose_runs(explicit_lines * 128u + num_keys * (w.paired ? 16u : 8u) + 8u, plan.kept_entries, in_runs);
+    uint64_t explicit_lines = 0, coded_lines = 0;
+    for (uint64_t i = 0; i < z.n_bins; ++i) {
+        const epik_amd_list_bin &b = z.bins[i];
+        if (b.length == 0 || b.lists == 0) continue;
+        explicit_lines += b.lists * ((b.length * 6u + 127u) / 128u);
+        const uint64_t as_runs = b.length < 65536u ? b.lists_in_runs : 0;
+        coded_lines += (b.lists - as_runs) * ((b.length * 6u + 127u) / 128u) + as_runs * ((b.length * 4u + 127u) / 128u);
+    }
+    const uint64_t packed_table = num_keys * (w.paired ? 16u : 8u) + 8u;
+    plan.runs = choose_runs(explicit_lines * 128u + packed_table, coded_lines * 128u + packed_table, plan.kept_entries, in_runs,
+                            plan.wave_resident[kCounts8] >= kWaveKernelWavesPerCu);
     uint64_t lines = 0;
     for (uint64_t i = 0; i < z.n_bins; ++i) {
         const epik_amd_list_bin &b = z.bins[i];

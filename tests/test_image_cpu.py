@@ -271,7 +271,8 @@ def test_plan_chooses_the_kernel_by_tree_size(monkeypatch):
 
 def test_build_streams_without_a_host_copy():
     """create() must not hold a second copy of the database on the host: the builder's own memory is
-    bounded by its staging, not by the image (here 230 MB of postings + 16 MB of table)."""
+    bounded by its staging, not by the image (here 187 MB of postings, run-coded since round 5 -- the headline
+    database's image then lies inside the Infinity Cache --, + 16 MB of table)."""
     tree = synth.make_tree(500, seed=42)
     db = synth.make_db(tree.num_nodes, kmer_size=10, seed=43)
     proc = psutil.Process()
@@ -290,7 +291,7 @@ def test_build_streams_without_a_host_copy():
     finally:
         stop.set()
         t.join()
-    assert plan.posting_bytes > 200 << 20
+    assert plan.posting_bytes > 180 << 20 and plan.run_coded == 1
     grown = peak[0] - before
     assert grown < 32 << 20, f"the image build grew the process by {grown >> 20} MiB"
 
